@@ -1,0 +1,78 @@
+"""Quaternion / Euler helpers used on the OSC path (w,x,y,z quaternions, static 'sxyz' Euler).
+
+The reference takes these from the third-party ``transforms3d`` package
+(call sites: /root/reference/irl_control/osc.py:4-7,115-117 and
+/root/reference/irl_control/utils.py:3,14-15,30,33,53,57,67).  That package is neither vendored by
+the reference nor installed in this image, so these are restatements of its published formulas for
+the one convention the reference uses (axes='sxyz').  They are cross-checked against
+``scipy.spatial.transform.Rotation`` in tests/test_transforms.py.  PARITY UNPINNED with respect to
+transforms3d itself (SURVEY.md §8 a6').
+"""
+import math
+
+import numpy as np
+
+_EPS4 = float(np.finfo(np.float64).eps) * 4.0
+
+
+def qmult(q1, q2):
+    """Hamilton product, no normalisation (transforms3d.derivations.quaternions.qmult)."""
+    w1, x1, y1, z1 = q1
+    w2, x2, y2, z2 = q2
+    w = w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2
+    x = w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2
+    y = w1 * y2 + y1 * w2 + z1 * x2 - x1 * z2
+    z = w1 * z2 + z1 * w2 + x1 * y2 - y1 * x2
+    return w, x, y, z
+
+
+def qconjugate(q):
+    return np.array(q, dtype=np.float64) * np.array([1.0, -1.0, -1.0, -1.0])
+
+
+def normalized_vector(v):
+    v = np.asarray(v, dtype=np.float64)
+    return v / math.sqrt(float((v ** 2).sum()))
+
+
+def quat2mat(q):
+    w, x, y, z = q
+    Nq = w * w + x * x + y * y + z * z
+    if Nq < np.finfo(np.float64).eps:
+        return np.eye(3)
+    s = 2.0 / Nq
+    X, Y, Z = x * s, y * s, z * s
+    wX, wY, wZ = w * X, w * Y, w * Z
+    xX, xY, xZ = x * X, x * Y, x * Z
+    yY, yZ, zZ = y * Y, y * Z, z * Z
+    return np.array([[1.0 - (yY + zZ), xY - wZ, xZ + wY],
+                     [xY + wZ, 1.0 - (xX + zZ), yZ - wX],
+                     [xZ - wY, yZ + wX, 1.0 - (xX + yY)]])
+
+
+def mat2euler(M):
+    """Static-frame x-y-z ('sxyz') Euler angles of a rotation matrix."""
+    cy = math.sqrt(M[0, 0] * M[0, 0] + M[1, 0] * M[1, 0])
+    if cy > _EPS4:
+        ax = math.atan2(M[2, 1], M[2, 2])
+        ay = math.atan2(-M[2, 0], cy)
+        az = math.atan2(M[1, 0], M[0, 0])
+    else:
+        ax = math.atan2(-M[1, 2], M[1, 1])
+        ay = math.atan2(-M[2, 0], cy)
+        az = 0.0
+    return ax, ay, az
+
+
+def quat2euler(q):
+    return mat2euler(quat2mat(q))
+
+
+def euler2quat(ai, aj, ak):
+    """'sxyz' Euler angles -> (w,x,y,z)."""
+    ai, aj, ak = ai / 2.0, aj / 2.0, ak / 2.0
+    ci, si = math.cos(ai), math.sin(ai)
+    cj, sj = math.cos(aj), math.sin(aj)
+    ck, sk = math.cos(ak), math.sin(ak)
+    cc, cs, sc, ss = ci * ck, ci * sk, si * ck, si * sk
+    return np.array([cj * cc + sj * ss, cj * sc - sj * cs, cj * ss + sj * cc, cj * cs - sj * sc])

@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Mint golden vectors for the OSC hot path by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference, which never travels):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py          # rewrites tests/golden/*.npz
+
+It imports /root/reference/irl_control with the two import shims of oracle/shims/, builds the
+reference's own Device / Robot / OSC objects on a FakeSim (irl_control_amd.fakesim) filled with
+seeded synthetic states, calls the reference's ``OSC.generate`` and stores, per case,
+
+  inputs  in the C-ABI record layout of include/irlosc.h (M, stacked J, dq, bias, ee_pose,
+          tgt_pose, wrench, tgt_vel, gains, layout descriptor as JSON), extracted through the
+          reference's own ``Robot.get_all_states()``;
+  outputs the reference's (force_idxs, forces) plus the intermediates of its private ``__Mx``.
+
+Every fixture is data (numbers); no reference source text is stored.
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.dont_write_bytecode = True
+sys.path[:0] = [os.path.join(HERE, "shims"), "/root/reference", ROOT]
+
+import numpy as np  # noqa: E402
+import yaml  # noqa: E402
+
+import irl_control as ref  # noqa: E402  (the reference)
+from irl_control.device import DeviceState as RefDeviceState  # noqa: E402
+from irl_control.robot import RobotState as RefRobotState  # noqa: E402
+from irl_control.utils import Target as RefTarget  # noqa: E402
+
+from irl_control_amd import fakesim  # noqa: E402
+
+assert ref.__file__.startswith("/root/reference"), ref.__file__
+CFG_DIR = os.path.join(ROOT, "irl_control_amd", "robot_configs")
+OUT_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def load_cfg(name):
+    with open(os.path.join(CFG_DIR, name)) as f:
+        return yaml.safe_load(f)
+
+
+def ctrl_cfg(cfg, name):
+    import copy
+    for e in cfg["controller_configs"]:
+        if e["name"] == name:
+            return copy.deepcopy(e)
+    raise KeyError(name)
+
+
+def build_reference(cfg, sim, dev_gain_names, nullspace, use_g, admittance, gain_override=None):
+    devices = [ref.Device(d, sim.model, sim, True) for d in cfg["devices"]]
+    robot = ref.Robot(devices, "DualUR5", sim, True)
+    dev_cfgs = []
+    for dev_name, gname in dev_gain_names:
+        g = ctrl_cfg(cfg, gname)
+        if gain_override is not None:
+            g.update(gain_override.get(dev_name, {}))
+        dev_cfgs.append((dev_name, g))
+    ns = ctrl_cfg(cfg, "nullspace") if nullspace else None
+    osc = ref.OSC(robot, sim, dev_cfgs, ns, use_g=use_g, admittance=admittance)
+    return robot, osc
+
+
+def quat_about(axis, angle):
+    axis = np.asarray(axis, dtype=np.float64)
+    axis = axis / np.linalg.norm(axis)
+    return np.concatenate([[np.cos(angle / 2)], np.sin(angle / 2) * axis])
+
+
+def make_case(name, seed, B, cfg_file, target_order, dev_gain_names, nullspace=True, use_g=True,
+              admittance=False, all_actuated=False, branch_b=False, degenerate=None, gimbal=False,
+              random_gains=False, no_max_vel=(), n_free_bodies=0):
+    rng = np.random.default_rng(seed)
+    cfg = load_cfg(cfg_file)
+    for d in cfg["devices"]:
+        if d["name"] in no_max_vel:
+            d.pop("max_vel")
+    rec = {k: [] for k in ("M", "J", "dq", "bias", "ee_pose", "tgt_pose", "wrench", "tgt_vel",
+                           "kp", "kv", "ko", "kk", "dd", "max_vel", "null_kv",
+                           "Mx", "M_inv", "Mx_inv", "det", "forces_flat")}
+    layout = None
+    force_idxs_ref = None
+    for b in range(B):
+        if all_actuated:
+            names, parent, joints = fakesim.dual_ur5_tree()
+            model = fakesim.FakeModel(names, parent, joints,
+                                      [j for js in joints for j in js], n_free_bodies)
+            sim = fakesim.FakeSim(model)
+        else:
+            sim = fakesim.FakeSim(n_free_bodies=n_free_bodies)
+        fakesim.randomize(sim, rng, wrench=admittance)
+        gain_override = None
+        if random_gains:
+            gain_override = {dn: dict(kp=float(rng.uniform(100, 2000)), kv=float(rng.uniform(10, 50)),
+                                      ko=float(rng.uniform(50, 2000)),
+                                      k=[float(x) for x in rng.uniform(0.5, 3, 3)],
+                                      d=[float(x) for x in rng.uniform(0.2, 2, 3)])
+                             for dn, _ in dev_gain_names}
+        robot, osc = build_reference(cfg, sim, dev_gain_names, nullspace, use_g, admittance,
+                                     gain_override)
+        # Device.__init__ overwrote qpos[start angles]; states that matter are the derived arrays.
+        if degenerate is not None:
+            # make two translational rows of the right arm nearly parallel -> tiny eigenvalue of
+            # J M^-1 J^T (pinv-truncation regime when degenerate is small, osc.py:51-55)
+            bid = sim.model.body_name2id("ur_EE_ur5right")
+            jp = sim.data.body_jacp[bid].reshape(3, -1)
+            jp[1] = jp[0] * (1.0 + 0.1 * rng.normal()) + degenerate[b % len(degenerate)] * rng.normal(size=jp.shape[1]) * (jp[0] != 0)
+        targets = {}
+        for dn in target_order:
+            dev = robot.get_device(dn)
+            ee_xyz = dev.get_state(RefDeviceState.EE_XYZ)
+            ee_quat = dev.get_state(RefDeviceState.EE_QUAT)
+            t = RefTarget()
+            t.set_xyz(ee_xyz + rng.normal(0.0, 0.2, 3))
+            ax = rng.normal(size=3)
+            if gimbal and dn != "base":
+                # error rotation q_ee (x) conj(q_tgt) with sxyz ay = +-pi/2 (cy ~ 0 branch)
+                sgn = 1.0 if b % 2 == 0 else -1.0
+                off = [0.0, 1e-9, 1e-7, 1e-5][(b // 2) % 4]
+                q_err = fakesim.quat_mul(quat_about([0, 0, 1], rng.uniform(-1, 1)),
+                                         fakesim.quat_mul(quat_about([0, 1, 0], sgn * (np.pi / 2 - off)),
+                                                          quat_about([1, 0, 0], rng.uniform(-1, 1))))
+                # q_ee * conj(q_tgt) = q_err  ->  q_tgt = conj(q_err) * q_ee ... (unit quats)
+                q_tgt = fakesim.quat_mul(q_err * np.array([1, -1, -1, -1]), ee_quat)
+                # un-normalised target quaternion exercises normalized_vector (osc.py:114)
+                t.set_quat(q_tgt * rng.uniform(0.5, 2.0))
+            else:
+                dq_ = quat_about(ax, rng.uniform(0.0, 0.5 if b % 3 else 3.0))
+                t.set_quat(fakesim.quat_mul(ee_quat, dq_) * (1.0 if b % 4 else rng.uniform(0.5, 2.0)))
+            if branch_b:
+                v = rng.normal(0.0, 0.3, 6)
+                v[np.abs(v) < 1e-3] = 0.1
+                t.set_xyz_vel(v[:3])
+                t.set_abg_vel(v[3:])
+            targets[dn] = t
+        state = robot.get_all_states()
+        Js, J_idxs = state[RefRobotState.J]
+        J = np.vstack([Js[dn] for dn in target_order])
+        M = state[RefRobotState.M]
+        Mx, M_inv = osc._OSC__Mx(J, M)
+        Mx_inv = np.dot(J, np.dot(M_inv, J.T))
+        force_idxs, forces = osc.generate(targets)
+
+        rec["M"].append(M); rec["J"].append(J); rec["dq"].append(state[RefRobotState.DQ])
+        rec["bias"].append(np.array(sim.data.qfrc_bias[robot.joint_ids_all]))
+        rec["ee_pose"].append([np.concatenate([state[dn][RefDeviceState.EE_XYZ],
+                                               state[dn][RefDeviceState.EE_QUAT]]) for dn in target_order])
+        rec["tgt_pose"].append([np.concatenate([targets[dn].get_xyz(), targets[dn].get_quat()])
+                                for dn in target_order])
+        rec["wrench"].append([np.concatenate([state[dn][RefDeviceState.FORCE],
+                                              state[dn][RefDeviceState.TORQUE]]) for dn in target_order])
+        rec["tgt_vel"].append([np.hstack([targets[dn].get_xyz_vel(), targets[dn].get_abg_vel()])
+                               for dn in target_order])
+        dc = osc.device_configs
+        rec["kp"].append([dc[dn]["kp"] for dn in target_order])
+        rec["kv"].append([dc[dn]["kv"] for dn in target_order])
+        rec["ko"].append([dc[dn]["ko"] for dn in target_order])
+        rec["kk"].append([dc[dn]["k"] for dn in target_order])
+        rec["dd"].append([dc[dn]["d"] for dn in target_order])
+        rec["max_vel"].append([(robot.get_device(dn).max_vel or [0, 0]) for dn in target_order])
+        rec["null_kv"].append(osc.nullspace_config["kv"] if nullspace else 0.0)
+        rec["Mx"].append(Mx); rec["M_inv"].append(M_inv); rec["Mx_inv"].append(Mx_inv)
+        rec["det"].append(np.linalg.det(Mx_inv))
+        rec["forces_flat"].append(np.concatenate(forces))
+        if layout is None:
+            force_idxs_ref = [np.asarray(x).tolist() for x in force_idxs]
+            layout = dict(
+                n=int(robot.num_joints_total), nv=int(sim.model.nv), dev_names=list(target_order),
+                dev_rows=[int(Js[dn].shape[0]) for dn in target_order],
+                ctrlr_dof=[[bool(x) for x in robot.get_device(dn).ctrlr_dof] for dn in target_order],
+                joint_ids=[[int(x) for x in robot.get_device(dn).joint_ids_all] for dn in target_order],
+                j_idx0=[int(J_idxs[dn][0]) if len(J_idxs[dn]) else 0 for dn in target_order],
+                has_max_vel=[robot.get_device(dn).max_vel is not None for dn in target_order],
+                actuator_trnids=[[int(x) for x in robot.get_device(dn).actuator_trnids] for dn in target_order],
+                ctrl_idxs=force_idxs_ref,
+                use_g=bool(use_g), admittance=bool(admittance), nullspace=bool(nullspace),
+                cfg_file=cfg_file, dev_gain_names=[list(x) for x in dev_gain_names],
+                seed=seed, branch_b=bool(branch_b), all_actuated=bool(all_actuated))
+    arrays = {k: np.asarray(v, dtype=np.float64) for k, v in rec.items()}
+    arrays["layout_json"] = np.array(json.dumps(layout))
+    os.makedirs(OUT_DIR, exist_ok=True)
+    path = os.path.join(OUT_DIR, f"{name}.npz")
+    np.savez_compressed(path, **arrays)
+    det = arrays["det"]
+    cond = np.array([np.linalg.cond(a) for a in arrays["Mx_inv"]])
+    print(f"{name:28s} B={B:3d} k={arrays['J'].shape[1]:2d} |det|<1e-4: {int((np.abs(det) < 1e-4).sum()):3d} "
+          f"cond(Mx_inv) med {np.median(cond):.2e} max {cond.max():.2e}  -> {os.path.getsize(path) // 1024} KiB")
+
+
+RLB = ("ur5right", "ur5left", "base")
+BRL = ("base", "ur5right", "ur5left")
+G_GAIN = [("base", "osc0"), ("ur5right", "osc2"), ("ur5left", "osc2")]
+G_ADMIT = [("ur5right", "osc2"), ("ur5left", "osc2")]
+
+if __name__ == "__main__":
+    S = 20241008
+    # gain_test layout (examples/gain_test.py:27-36,124-128): arms xyz only, k = 7
+    make_case("k7_gain_test", S + 1, 32, "default_xyz.yaml", RLB, G_GAIN, all_actuated=True)
+    make_case("k7_real_actuators", S + 2, 8, "default_xyz.yaml", RLB, G_GAIN)
+    # xyz+abg arms, k = 13 (the 4 096 / 65 536 / 262 144-instance workload)
+    make_case("k13_xyz_abg", S + 3, 32, "default_xyz_abg.yaml", RLB, G_GAIN, all_actuated=True)
+    make_case("k13_base_first", S + 4, 16, "default_xyz_abg.yaml", BRL, G_GAIN, all_actuated=True)
+    make_case("k13_iros2022", S + 5, 16, "iros2022.yaml", RLB, G_GAIN, all_actuated=True)
+    # admit_test layout (examples/admit_test.py:19-25,55-58): two arms, admittance, nv = 37
+    make_case("k12_admittance", S + 6, 32, "default_xyz_abg.yaml", ("ur5right", "ur5left"), G_ADMIT,
+              admittance=True, all_actuated=True, n_free_bodies=2)
+    make_case("k13_no_g_no_null", S + 7, 16, "default_xyz_abg.yaml", RLB, G_GAIN, nullspace=False,
+              use_g=False, all_actuated=True)
+    make_case("k13_branch_b", S + 8, 16, "default_xyz_abg.yaml", BRL, G_GAIN, branch_b=True,
+              all_actuated=True)
+    make_case("k13_pinv_regime", S + 9, 32, "default_xyz_abg.yaml", RLB, G_GAIN, all_actuated=True,
+              degenerate=[1e-2, 1e-3, 1e-4, 3e-6, 1e-6, 1e-7, 0.0, 3e-3])
+    make_case("k13_gimbal", S + 10, 16, "default_xyz_abg.yaml", RLB, G_GAIN, all_actuated=True, gimbal=True)
+    make_case("k13_random_gains", S + 11, 16, "default_xyz_abg.yaml", RLB, G_GAIN, all_actuated=True,
+              random_gains=True)
+    make_case("k13_no_max_vel", S + 12, 8, "default_xyz_abg.yaml", RLB, G_GAIN, all_actuated=True,
+              no_max_vel=("ur5left",))
