@@ -1,0 +1,143 @@
+/*
+ * irlosc.h — C ABI of the MI355X-native batched operational-space controller (libirlosc.so).
+ *
+ * This is the drop-in boundary that sits UNDER irl_control's Python `OSC.generate()`:
+ * the reference has no FFI of its own (it is pure Python/NumPy), so each entry point below names
+ * the reference lines whose work it takes over.  Plain pointers and sizes only; no torch types.
+ *
+ *   reference work                                              -> entry point
+ *   ----------------------------------------------------------------------------------------------
+ *   OSC.__init__ gain tables (osc.py:19-39), device row masks /
+ *   joint sets (device.py:36,66-69; robot.py:28-32,50-55)       -> irlosc_create, irlosc_set_gains
+ *   Robot.get_all_states(): M, dq, J stack, EE pose, wrench
+ *   (robot.py:44-72,125-136; device.py:115-170; osc.py:132-138) -> irlosc_upload
+ *   targets dict (utils.py:5-67; osc.py:156-159,172)            -> irlosc_set_targets
+ *   OSC.generate numerical body (osc.py:41-118,144-200)         -> irlosc_step / irlosc_step_device
+ *   forces gather u_all[actuator_trnids] (osc.py:203-210)       -> host side, from u[B,n]
+ *
+ * Record layouts (batch-major, row-major, element type = cfg.dtype: float or double):
+ *   M[B][n][n]      joint-space inertia (symmetric positive definite; only the lower triangle is read)
+ *   J[B][k][n]      stacked task Jacobian, device blocks in TARGETS order, k = sum(dev_rows)
+ *   dq[B][n]        joint velocities
+ *   bias[B][n]      qfrc_bias (gravity + Coriolis); ignored unless IRLOSC_USE_G
+ *   ee_pose[B][ndev][7]   x y z qw qx qy qz of each target device's end effector
+ *   tgt_pose[B][ndev][7]  target x y z qw qx qy qz (quaternion need not be normalised)
+ *   tgt_vel[B][ndev][6]   hstack(xyz_vel, abg_vel) or NULL (= all zero -> damping branch A)
+ *   wrench[B][ndev][6]    world-frame F/T sensor reading or NULL; used only with IRLOSC_ADMITTANCE
+ *   u[B][n]         joint torques u_all (osc.py:152-200)
+ *   flags[B]        uint32 status bits per instance (IRLOSC_FLAG_*)
+ *
+ * Ownership: the caller owns every host buffer (borrowed for the duration of the call); the
+ * library owns its device buffers and its HIP stream.  Errors: 0 = success, negative irlosc_status
+ * otherwise, message via irlosc_last_error(); nothing throws across the ABI.  A context is bound
+ * to one GPU and is not thread-safe; distinct contexts may be driven from distinct threads.
+ * There is NO CPU fallback: every compute entry point fails with IRLOSC_ERR_HIP without a GPU.
+ */
+#ifndef IRLOSC_H
+#define IRLOSC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IRLOSC_ABI_VERSION 1
+#define IRLOSC_MAX_DEV 4
+#define IRLOSC_MAX_N 32
+#define IRLOSC_MAX_K 16
+#define IRLOSC_GAIN_WORDS 12 /* kp kv ko k0 k1 k2 d0 d1 d2 max_vel0 max_vel1 has_max_vel */
+
+typedef enum { IRLOSC_F32 = 0, IRLOSC_F64 = 1 } irlosc_dtype;
+
+typedef enum {
+    IRLOSC_OK = 0,
+    IRLOSC_ERR_ARG = -1,     /* bad argument / layout */
+    IRLOSC_ERR_HIP = -2,     /* HIP runtime error (no device, OOM, launch failure) */
+    IRLOSC_ERR_STATE = -3    /* call order (e.g. step before upload) */
+} irlosc_status;
+
+/* cfg.flags */
+#define IRLOSC_USE_G      1u  /* add bias forces, osc.py:190-191 */
+#define IRLOSC_ADMITTANCE 2u  /* add ext_f to the task signal, osc.py:184-185 */
+#define IRLOSC_NULLSPACE  4u  /* null-space damping, osc.py:195-200 */
+
+/* per-instance status bits written by the kernels */
+#define IRLOSC_FLAG_M_NOT_PD      1u   /* Cholesky of M met a non-positive pivot */
+#define IRLOSC_FLAG_PINV_BRANCH   2u   /* |det(J M^-1 J^T)| < 1e-4: reference takes np.linalg.pinv (osc.py:55) */
+#define IRLOSC_FLAG_EIGEN_PATH    4u   /* k x k eigen-decomposition was needed (not certifiably cond < 1e5) */
+#define IRLOSC_FLAG_TRUNCATED     8u   /* at least one eigenvalue <= 1e-5 * max was dropped */
+#define IRLOSC_FLAG_VEL_BRANCH_B 16u   /* some device had all six target-velocity components non-zero (osc.py:173-177) */
+#define IRLOSC_FLAG_BAD_JIDX     32u   /* branch B indexed dx out of range (IndexError in the reference) */
+#define IRLOSC_FLAG_NONFINITE    64u   /* output contains NaN/Inf */
+
+/* kernel selection (cfg.kernel) */
+#define IRLOSC_KERNEL_AUTO    0
+#define IRLOSC_KERNEL_GENERIC 1   /* one wavefront per instance, LDS tiles, any n<=32, k<=16 */
+#define IRLOSC_KERNEL_GROUP   2   /* G lanes per instance, register-resident factors (n=25 shapes) */
+
+typedef struct irlosc_cfg {
+    int32_t hip_device;                      /* HIP device ordinal */
+    int32_t dtype;                           /* irlosc_dtype */
+    int32_t max_batch;                       /* capacity B_max of the resident buffers */
+    int32_t n_slots;                         /* >=1 resident input sets (bench rotates them to defeat the 256 MiB L3) */
+    int32_t n;                               /* robot.num_joints_total (robot.py:32) */
+    int32_t ndev;                            /* number of target devices, targets order */
+    uint32_t flags;                          /* IRLOSC_USE_G | IRLOSC_ADMITTANCE | IRLOSC_NULLSPACE */
+    int32_t kernel;                          /* IRLOSC_KERNEL_* */
+    int32_t dev_rows[IRLOSC_MAX_DEV];        /* r_d = popcount(ctrlr_dof[d]) */
+    uint8_t ctrlr_dof[IRLOSC_MAX_DEV][6];    /* row mask hstack(ctrlr_dof_xyz, ctrlr_dof_abg), device.py:36 */
+    uint8_t calc_xyz[IRLOSC_MAX_DEV];        /* np.sum(device.ctrlr_dof_xyz) > 0, osc.py:108 */
+    uint8_t calc_abg[IRLOSC_MAX_DEV];        /* np.sum(device.ctrlr_dof_abg) > 0, osc.py:113 */
+    uint32_t joint_mask[IRLOSC_MAX_DEV];     /* bit j set <=> j in device.joint_ids_all (osc.py:174) */
+    int32_t j_idx0[IRLOSC_MAX_DEV];          /* first row of J_idxs[name] (robot.py:50-55), used by branch B */
+} irlosc_cfg;
+
+typedef struct irlosc_ctx irlosc_ctx;
+
+int irlosc_abi_version(void);
+
+/* Number of HIP devices visible, or a negative irlosc_status. */
+int irlosc_device_count(void);
+
+int irlosc_create(const irlosc_cfg* cfg, irlosc_ctx** out);
+void irlosc_destroy(irlosc_ctx* ctx);
+const char* irlosc_last_error(const irlosc_ctx* ctx); /* ctx may be NULL: last create() error */
+const char* irlosc_kernel_name(const irlosc_ctx* ctx); /* name of the kernel irlosc_step launches */
+
+/* gains[nb][ndev][IRLOSC_GAIN_WORDS] and null_kv[nb] as double; nb == 1 broadcasts one gain set to
+ * every instance (kept in constant/SGPR space), nb == max_batch gives per-instance gains. */
+int irlosc_set_gains(irlosc_ctx* ctx, const double* gains, const double* null_kv, int32_t nb);
+
+/* Host -> device copy of one batch of robot state into resident slot `slot`.  wrench may be NULL. */
+int irlosc_upload(irlosc_ctx* ctx, int32_t slot, int32_t B, const void* M, const void* J,
+                  const void* dq, const void* bias, const void* ee_pose, const void* wrench);
+/* Host -> device copy of the targets for slot `slot`.  tgt_vel may be NULL (all zero). */
+int irlosc_set_targets(irlosc_ctx* ctx, int32_t slot, int32_t B, const void* tgt_pose,
+                       const void* tgt_vel);
+
+/* One control step over the B instances of `slot`: launch, then copy u[B][n] (and flags[B], may
+ * be NULL) back to the host buffers.  u_host may be NULL to leave the result on the device. */
+int irlosc_step(irlosc_ctx* ctx, int32_t slot, int32_t B, void* u_host, uint32_t* flags_host);
+
+/* Benchmark form: `iters` back-to-back steps on resident data, slot = (first_slot + i) % n_slots,
+ * no host copies.  *ms_total receives the HIP-event time of the whole region measured on the
+ * library's own stream; *ms_kernel_avg the mean per-launch duration. */
+int irlosc_step_resident(irlosc_ctx* ctx, int32_t first_slot, int32_t B, int32_t iters,
+                         float* ms_total, float* ms_kernel_avg);
+
+int irlosc_download(irlosc_ctx* ctx, int32_t B, void* u_host, uint32_t* flags_host);
+int irlosc_sync(irlosc_ctx* ctx);
+
+/* Raw-device-pointer form for callers that already hold the state in HBM (e.g. an on-GPU
+ * simulator): same layouts as above, all pointers are device pointers, hip_stream is a
+ * hipStream_t (NULL = the context's stream).  No copies, no synchronisation. */
+int irlosc_step_device(irlosc_ctx* ctx, int32_t B, const void* dM, const void* dJ, const void* ddq,
+                       const void* dbias, const void* dee_pose, const void* dtgt_pose,
+                       const void* dtgt_vel, const void* dwrench, void* du, uint32_t* dflags,
+                       void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRLOSC_H */

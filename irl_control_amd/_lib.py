@@ -1,0 +1,79 @@
+"""ctypes binding of libirlosc.so (include/irlosc.h).  Loads the in-tree library; there is no
+fallback: if the HIP library is missing or no GPU is present, compute calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libirlosc.so")
+
+MAX_DEV, MAX_N, MAX_K, GAIN_WORDS = 4, 32, 16, 12
+F32, F64 = 0, 1
+USE_G, ADMITTANCE, NULLSPACE = 1, 2, 4
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_GROUP = 0, 1, 2
+FLAG_M_NOT_PD, FLAG_PINV_BRANCH, FLAG_EIGEN_PATH, FLAG_TRUNCATED = 1, 2, 4, 8
+FLAG_VEL_BRANCH_B, FLAG_BAD_JIDX, FLAG_NONFINITE = 16, 32, 64
+
+EXPORTS = ["irlosc_abi_version", "irlosc_device_count", "irlosc_create", "irlosc_destroy",
+           "irlosc_last_error", "irlosc_kernel_name", "irlosc_set_gains", "irlosc_upload",
+           "irlosc_set_targets", "irlosc_step", "irlosc_step_resident", "irlosc_download",
+           "irlosc_sync", "irlosc_step_device"]
+
+
+class Cfg(C.Structure):
+    _fields_ = [("hip_device", C.c_int32), ("dtype", C.c_int32), ("max_batch", C.c_int32),
+                ("n_slots", C.c_int32), ("n", C.c_int32), ("ndev", C.c_int32),
+                ("flags", C.c_uint32), ("kernel", C.c_int32),
+                ("dev_rows", C.c_int32 * MAX_DEV),
+                ("ctrlr_dof", (C.c_uint8 * 6) * MAX_DEV),
+                ("calc_xyz", C.c_uint8 * MAX_DEV), ("calc_abg", C.c_uint8 * MAX_DEV),
+                ("joint_mask", C.c_uint32 * MAX_DEV), ("j_idx0", C.c_int32 * MAX_DEV)]
+
+
+class IrloscError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libirlosc.so (built by __graft_entry__.build()).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IrloscError(f"{LIB_PATH} not built: run `python __graft_entry__.py` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int32
+    lib.irlosc_abi_version.restype = C.c_int
+    lib.irlosc_device_count.restype = C.c_int
+    lib.irlosc_create.argtypes = [C.POINTER(Cfg), C.POINTER(vp)]
+    lib.irlosc_destroy.argtypes = [vp]
+    lib.irlosc_destroy.restype = None
+    lib.irlosc_last_error.argtypes = [vp]
+    lib.irlosc_last_error.restype = C.c_char_p
+    lib.irlosc_kernel_name.argtypes = [vp]
+    lib.irlosc_kernel_name.restype = C.c_char_p
+    lib.irlosc_set_gains.argtypes = [vp, vp, vp, i32]
+    lib.irlosc_upload.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.irlosc_set_targets.argtypes = [vp, i32, i32, vp, vp]
+    lib.irlosc_step.argtypes = [vp, i32, i32, vp, vp]
+    lib.irlosc_step_resident.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.irlosc_download.argtypes = [vp, i32, vp, vp]
+    lib.irlosc_sync.argtypes = [vp]
+    lib.irlosc_step_device.argtypes = [vp, i32] + [vp] * 11
+    for name in EXPORTS:
+        getattr(lib, name)
+    _lib = lib
+    return lib
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def np_dtype(dtype_code):
+    return np.float64 if dtype_code == F64 else np.float32

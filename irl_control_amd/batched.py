@@ -1,0 +1,120 @@
+"""``BatchedOSC``: many independent robot instances per control tick through libirlosc.
+
+This is the batch-of-B form of ``OSC.generate`` (/root/reference/irl_control/osc.py:120-210): the
+same inputs the reference assembles per tick (M, stacked J, dq, bias, EE poses, targets, wrench),
+with a leading batch axis, in; joint torques ``u_all`` [B, n] out.  All arithmetic happens in the
+HIP kernels; this class only owns the context and checks shapes.
+"""
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from .layout import OSCLayout, pack_gains
+
+
+class BatchedOSC:
+    def __init__(self, layout: OSCLayout, max_batch: int, dtype=np.float64, hip_device: int = 0,
+                 n_slots: int = 1, kernel: int = _lib.KERNEL_AUTO):
+        self.lib = _lib.load()
+        self.layout = layout
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("dtype must be float32 or float64")
+        self.max_batch, self.n_slots = int(max_batch), int(n_slots)
+        code = _lib.F64 if self.dtype == np.float64 else _lib.F32
+        cfg = layout.to_cfg(code, self.max_batch, hip_device, self.n_slots, kernel)
+        h = C.c_void_p()
+        rc = self.lib.irlosc_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise _lib.IrloscError(f"irlosc_create failed ({rc}): "
+                                   f"{self.lib.irlosc_last_error(None).decode()}")
+        self._h = h
+        self._B = [0] * self.n_slots
+
+    # -- plumbing ---------------------------------------------------------------------------------
+    def _chk(self, rc):
+        if rc != 0:
+            raise _lib.IrloscError(f"libirlosc error {rc}: {self.lib.irlosc_last_error(self._h).decode()}")
+
+    def _arr(self, a, shape, name):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if a.shape != tuple(shape):
+            raise ValueError(f"{name}: expected shape {tuple(shape)}, got {a.shape}")
+        return a
+
+    @property
+    def kernel_name(self) -> str:
+        return self.lib.irlosc_kernel_name(self._h).decode()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.irlosc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- API ---------------------------------------------------------------------------------------
+    def set_gains(self, kp, kv, ko, k, d, max_vel, null_kv=0.0):
+        g, nk, nb = pack_gains(self.layout, kp, kv, ko, k, d, max_vel, null_kv)
+        if nb not in (1, self.max_batch):
+            raise ValueError(f"per-instance gains need a leading axis of max_batch={self.max_batch}")
+        self._chk(self.lib.irlosc_set_gains(self._h, _lib.ptr(g), _lib.ptr(nk), nb))
+
+    def upload(self, M, J, dq, bias, ee_pose, wrench=None, slot: int = 0):
+        L = self.layout
+        B = int(np.shape(M)[0])
+        M = self._arr(M, (B, L.n, L.n), "M")
+        J = self._arr(J, (B, L.k, L.n), "J")
+        dq = self._arr(dq, (B, L.n), "dq")
+        bias = self._arr(bias, (B, L.n), "bias")
+        ee = self._arr(ee_pose, (B, L.ndev, 7), "ee_pose")
+        wr = self._arr(wrench, (B, L.ndev, 6), "wrench")
+        self._chk(self.lib.irlosc_upload(self._h, slot, B, _lib.ptr(M), _lib.ptr(J), _lib.ptr(dq),
+                                         _lib.ptr(bias), _lib.ptr(ee), _lib.ptr(wr)))
+        self._B[slot] = B
+
+    def set_targets(self, tgt_pose, tgt_vel=None, slot: int = 0):
+        L = self.layout
+        B = int(np.shape(tgt_pose)[0])
+        tp = self._arr(tgt_pose, (B, L.ndev, 7), "tgt_pose")
+        tv = self._arr(tgt_vel, (B, L.ndev, 6), "tgt_vel")
+        self._chk(self.lib.irlosc_set_targets(self._h, slot, B, _lib.ptr(tp), _lib.ptr(tv)))
+
+    def step(self, slot: int = 0, return_flags: bool = False):
+        B = self._B[slot]
+        u = np.empty((B, self.layout.n), dtype=self.dtype)
+        fl = np.empty(B, dtype=np.uint32)
+        self._chk(self.lib.irlosc_step(self._h, slot, B, _lib.ptr(u), _lib.ptr(fl)))
+        return (u, fl) if return_flags else u
+
+    def step_resident(self, iters: int, first_slot: int = 0, B: Optional[int] = None):
+        """-> (ms_total, ms_kernel_avg): `iters` launches on resident data, HIP-event timed."""
+        B = self._B[first_slot] if B is None else B
+        t, a = C.c_float(), C.c_float()
+        self._chk(self.lib.irlosc_step_resident(self._h, first_slot, B, iters, C.byref(t), C.byref(a)))
+        return t.value, a.value
+
+    def download(self, B: Optional[int] = None):
+        B = self._B[0] if B is None else B
+        u = np.empty((B, self.layout.n), dtype=self.dtype)
+        fl = np.empty(B, dtype=np.uint32)
+        self._chk(self.lib.irlosc_download(self._h, B, _lib.ptr(u), _lib.ptr(fl)))
+        return u, fl
+
+    def sync(self):
+        self._chk(self.lib.irlosc_sync(self._h))
+
+    def generate_batched(self, M, J, dq, bias, ee_pose, tgt_pose, tgt_vel=None, wrench=None,
+                         return_flags: bool = False):
+        """One tick for B instances: upload, step, download."""
+        self.upload(M, J, dq, bias, ee_pose, wrench)
+        self.set_targets(tgt_pose, tgt_vel)
+        return self.step(return_flags=return_flags)

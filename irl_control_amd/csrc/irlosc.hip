@@ -1,0 +1,406 @@
+// libirlosc.so — C ABI (include/irlosc.h) over the gfx950 OSC kernels.  No CPU fallback: every
+// compute entry point needs a HIP device and reports IRLOSC_ERR_HIP otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/irlosc.h"
+#include "osc_common.hpp"
+#include "osc_generic.hpp"
+#ifndef IRLOSC_NO_GROUP_KERNEL
+#include "osc_group.hpp"
+#endif
+
+using namespace irlosc;
+
+static thread_local std::string g_create_error;
+
+struct irlosc_ctx {
+    irlosc_cfg cfg{};
+    int k = 0;
+    size_t esz = 4;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // resident inputs, one set per slot
+    std::vector<void*> dM, dJ, ddq, dbias, dee, dwrench, dtgt, dtvel;
+    std::vector<int> has_wrench, has_tvel, uploaded, targeted;
+    void* du = nullptr;
+    uint32_t* dflags = nullptr;
+    void* dgains = nullptr;   // [nb][ndev][12] in dtype
+    void* dnullkv = nullptr;  // [nb]
+    int gains_nb = 0;
+    int32_t* dworklist = nullptr;  // [max_batch] instance ids routed to the generic kernel
+    int32_t* dworkcount = nullptr; // [1]
+    int kernel = IRLOSC_KERNEL_GENERIC;
+    std::string kernel_name;
+    std::string err;
+};
+
+static int fail(irlosc_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail((c), IRLOSC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));     \
+    } while (0)
+
+extern "C" int irlosc_abi_version(void) { return IRLOSC_ABI_VERSION; }
+
+extern "C" int irlosc_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipGetDeviceCount failed: ") + hipGetErrorString(e);
+        return IRLOSC_ERR_HIP;
+    }
+    return n;
+}
+
+extern "C" const char* irlosc_last_error(const irlosc_ctx* ctx) {
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+extern "C" const char* irlosc_kernel_name(const irlosc_ctx* ctx) {
+    return ctx ? ctx->kernel_name.c_str() : "";
+}
+
+static int validate(const irlosc_cfg* c, int* k_out) {
+    if (!c) return fail(nullptr, IRLOSC_ERR_ARG, "cfg is NULL");
+    if (c->dtype != IRLOSC_F32 && c->dtype != IRLOSC_F64)
+        return fail(nullptr, IRLOSC_ERR_ARG, "dtype must be IRLOSC_F32 or IRLOSC_F64");
+    if (c->n < 1 || c->n > IRLOSC_MAX_N) return fail(nullptr, IRLOSC_ERR_ARG, "n=%d out of [1,%d]", c->n, IRLOSC_MAX_N);
+    if (c->ndev < 1 || c->ndev > IRLOSC_MAX_DEV)
+        return fail(nullptr, IRLOSC_ERR_ARG, "ndev=%d out of [1,%d]", c->ndev, IRLOSC_MAX_DEV);
+    if (c->max_batch < 1) return fail(nullptr, IRLOSC_ERR_ARG, "max_batch must be >= 1");
+    if (c->n_slots < 1) return fail(nullptr, IRLOSC_ERR_ARG, "n_slots must be >= 1");
+    int k = 0;
+    for (int d = 0; d < c->ndev; ++d) {
+        int pc = 0;
+        for (int i = 0; i < 6; ++i) pc += c->ctrlr_dof[d][i] ? 1 : 0;
+        if (pc != c->dev_rows[d])
+            return fail(nullptr, IRLOSC_ERR_ARG, "dev_rows[%d]=%d != popcount(ctrlr_dof)=%d", d, c->dev_rows[d], pc);
+        if (c->n < 32 && (c->joint_mask[d] >> c->n))
+            return fail(nullptr, IRLOSC_ERR_ARG, "joint_mask[%d] has bits >= n", d);
+        if (c->j_idx0[d] < 0) return fail(nullptr, IRLOSC_ERR_ARG, "j_idx0[%d] negative", d);
+        k += pc;
+    }
+    if (k < 1 || k > IRLOSC_MAX_K) return fail(nullptr, IRLOSC_ERR_ARG, "k=%d out of [1,%d]", k, IRLOSC_MAX_K);
+    if (c->kernel < IRLOSC_KERNEL_AUTO || c->kernel > IRLOSC_KERNEL_GROUP)
+        return fail(nullptr, IRLOSC_ERR_ARG, "unknown kernel id %d", c->kernel);
+    *k_out = k;
+    return IRLOSC_OK;
+}
+
+static void free_all(irlosc_ctx* c) {
+    auto fr = [](std::vector<void*>& v) { for (void* p : v) if (p) (void)hipFree(p); v.clear(); };
+    fr(c->dM); fr(c->dJ); fr(c->ddq); fr(c->dbias); fr(c->dee); fr(c->dwrench); fr(c->dtgt); fr(c->dtvel);
+    if (c->du) (void)hipFree(c->du);
+    if (c->dflags) (void)hipFree(c->dflags);
+    if (c->dgains) (void)hipFree(c->dgains);
+    if (c->dnullkv) (void)hipFree(c->dnullkv);
+    if (c->dworklist) (void)hipFree(c->dworklist);
+    if (c->dworkcount) (void)hipFree(c->dworkcount);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+}
+
+static int create_impl(irlosc_ctx* c) {
+    const irlosc_cfg& g = c->cfg;
+    HIPCHK(nullptr, hipSetDevice(g.hip_device));
+    HIPCHK(nullptr, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(nullptr, hipEventCreate(&c->ev0));
+    HIPCHK(nullptr, hipEventCreate(&c->ev1));
+    const size_t B = (size_t)g.max_batch, n = (size_t)g.n, k = (size_t)c->k, nd = (size_t)g.ndev, e = c->esz;
+    auto alloc_slots = [&](std::vector<void*>& v, size_t bytes) -> hipError_t {
+        v.assign(g.n_slots, nullptr);
+        for (int s = 0; s < g.n_slots; ++s) {
+            hipError_t r = hipMalloc(&v[s], bytes);
+            if (r != hipSuccess) return r;
+        }
+        return hipSuccess;
+    };
+    HIPCHK(nullptr, alloc_slots(c->dM, B * n * n * e));
+    HIPCHK(nullptr, alloc_slots(c->dJ, B * k * n * e));
+    HIPCHK(nullptr, alloc_slots(c->ddq, B * n * e));
+    HIPCHK(nullptr, alloc_slots(c->dbias, B * n * e));
+    HIPCHK(nullptr, alloc_slots(c->dee, B * nd * 7 * e));
+    HIPCHK(nullptr, alloc_slots(c->dwrench, B * nd * 6 * e));
+    HIPCHK(nullptr, alloc_slots(c->dtgt, B * nd * 7 * e));
+    HIPCHK(nullptr, alloc_slots(c->dtvel, B * nd * 6 * e));
+    c->has_wrench.assign(g.n_slots, 0);
+    c->has_tvel.assign(g.n_slots, 0);
+    c->uploaded.assign(g.n_slots, 0);
+    c->targeted.assign(g.n_slots, 0);
+    HIPCHK(nullptr, hipMalloc(&c->du, B * n * e));
+    HIPCHK(nullptr, hipMalloc((void**)&c->dflags, B * sizeof(uint32_t)));
+    HIPCHK(nullptr, hipMalloc(&c->dgains, B * nd * IRLOSC_GAIN_WORDS * e));
+    HIPCHK(nullptr, hipMalloc(&c->dnullkv, B * e));
+    HIPCHK(nullptr, hipMalloc((void**)&c->dworklist, B * sizeof(int32_t)));
+    HIPCHK(nullptr, hipMalloc((void**)&c->dworkcount, sizeof(int32_t)));
+    HIPCHK(nullptr, hipMemsetAsync(c->dflags, 0, B * sizeof(uint32_t), c->stream));
+    HIPCHK(nullptr, hipStreamSynchronize(c->stream));
+    return IRLOSC_OK;
+}
+
+static bool group_supported(const irlosc_ctx* c) {
+#ifndef IRLOSC_NO_GROUP_KERNEL
+    return group_kernel_supports(c->cfg.dtype, c->cfg.n, c->k, c->cfg.ndev);
+#else
+    (void)c;
+    return false;
+#endif
+}
+
+extern "C" int irlosc_create(const irlosc_cfg* cfg, irlosc_ctx** out) {
+    if (!out) return fail(nullptr, IRLOSC_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    int k = 0;
+    int rc = validate(cfg, &k);
+    if (rc) return rc;
+    int ndevs = 0;
+    if (hipGetDeviceCount(&ndevs) != hipSuccess || ndevs < 1)
+        return fail(nullptr, IRLOSC_ERR_HIP, "no HIP device available (libirlosc has no CPU fallback)");
+    if (cfg->hip_device < 0 || cfg->hip_device >= ndevs)
+        return fail(nullptr, IRLOSC_ERR_ARG, "hip_device=%d but %d device(s) visible", cfg->hip_device, ndevs);
+    irlosc_ctx* c = new (std::nothrow) irlosc_ctx();
+    if (!c) return fail(nullptr, IRLOSC_ERR_HIP, "out of host memory");
+    c->cfg = *cfg;
+    c->k = k;
+    c->esz = cfg->dtype == IRLOSC_F64 ? 8 : 4;
+    if (cfg->kernel == IRLOSC_KERNEL_GROUP && !group_supported(c)) {
+        delete c;
+        return fail(nullptr, IRLOSC_ERR_ARG, "group kernel not available for n=%d k=%d ndev=%d", cfg->n, k, cfg->ndev);
+    }
+    c->kernel = (cfg->kernel == IRLOSC_KERNEL_GENERIC || !group_supported(c)) ? IRLOSC_KERNEL_GENERIC
+                                                                              : IRLOSC_KERNEL_GROUP;
+    char nm[96];
+    snprintf(nm, sizeof nm, "%s_%s_n%d_k%d", c->kernel == IRLOSC_KERNEL_GROUP ? "osc_group" : "osc_generic",
+             cfg->dtype == IRLOSC_F64 ? "f64" : "f32", cfg->n, k);
+    c->kernel_name = nm;
+    rc = create_impl(c);
+    if (rc) {
+        free_all(c);
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return IRLOSC_OK;
+}
+
+extern "C" void irlosc_destroy(irlosc_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.hip_device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_all(c);
+    delete c;
+}
+
+template <typename T>
+static void convert(const double* src, std::vector<unsigned char>& dst, size_t count) {
+    dst.resize(count * sizeof(T));
+    T* d = reinterpret_cast<T*>(dst.data());
+    for (size_t i = 0; i < count; ++i) d[i] = (T)src[i];
+}
+
+extern "C" int irlosc_set_gains(irlosc_ctx* c, const double* gains, const double* null_kv, int32_t nb) {
+    if (!c) return IRLOSC_ERR_ARG;
+    if (!gains) return fail(c, IRLOSC_ERR_ARG, "gains is NULL");
+    if (nb != 1 && nb != c->cfg.max_batch)
+        return fail(c, IRLOSC_ERR_ARG, "nb must be 1 (broadcast) or max_batch=%d, got %d", c->cfg.max_batch, nb);
+    if ((c->cfg.flags & IRLOSC_NULLSPACE) && !null_kv)
+        return fail(c, IRLOSC_ERR_ARG, "null_kv required with IRLOSC_NULLSPACE");
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    const size_t cnt = (size_t)nb * c->cfg.ndev * IRLOSC_GAIN_WORDS;
+    std::vector<double> zero(nb, 0.0);
+    const double* nk = null_kv ? null_kv : zero.data();
+    std::vector<unsigned char> a, b;
+    if (c->cfg.dtype == IRLOSC_F64) { convert<double>(gains, a, cnt); convert<double>(nk, b, nb); }
+    else { convert<float>(gains, a, cnt); convert<float>(nk, b, nb); }
+    HIPCHK(c, hipMemcpyAsync(c->dgains, a.data(), a.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dnullkv, b.data(), b.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->gains_nb = nb;
+    return IRLOSC_OK;
+}
+
+static int check_slot(irlosc_ctx* c, int slot, int B) {
+    if (slot < 0 || slot >= c->cfg.n_slots) return fail(c, IRLOSC_ERR_ARG, "slot %d out of [0,%d)", slot, c->cfg.n_slots);
+    if (B < 0 || B > c->cfg.max_batch) return fail(c, IRLOSC_ERR_ARG, "B=%d out of [0,%d]", B, c->cfg.max_batch);
+    return IRLOSC_OK;
+}
+
+extern "C" int irlosc_upload(irlosc_ctx* c, int32_t slot, int32_t B, const void* M, const void* J, const void* dq,
+                             const void* bias, const void* ee_pose, const void* wrench) {
+    if (!c) return IRLOSC_ERR_ARG;
+    int rc = check_slot(c, slot, B);
+    if (rc) return rc;
+    if (B == 0) { c->uploaded[slot] = 1; return IRLOSC_OK; }
+    if (!M || !J || !dq || !ee_pose) return fail(c, IRLOSC_ERR_ARG, "M, J, dq and ee_pose are required");
+    if ((c->cfg.flags & IRLOSC_USE_G) && !bias) return fail(c, IRLOSC_ERR_ARG, "bias required with IRLOSC_USE_G");
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    const size_t b = (size_t)B, n = (size_t)c->cfg.n, k = (size_t)c->k, nd = (size_t)c->cfg.ndev, e = c->esz;
+    HIPCHK(c, hipMemcpyAsync(c->dM[slot], M, b * n * n * e, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dJ[slot], J, b * k * n * e, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->ddq[slot], dq, b * n * e, hipMemcpyHostToDevice, c->stream));
+    if (bias) HIPCHK(c, hipMemcpyAsync(c->dbias[slot], bias, b * n * e, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dee[slot], ee_pose, b * nd * 7 * e, hipMemcpyHostToDevice, c->stream));
+    if (wrench) HIPCHK(c, hipMemcpyAsync(c->dwrench[slot], wrench, b * nd * 6 * e, hipMemcpyHostToDevice, c->stream));
+    c->has_wrench[slot] = wrench != nullptr;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->uploaded[slot] = 1;
+    return IRLOSC_OK;
+}
+
+extern "C" int irlosc_set_targets(irlosc_ctx* c, int32_t slot, int32_t B, const void* tgt_pose, const void* tgt_vel) {
+    if (!c) return IRLOSC_ERR_ARG;
+    int rc = check_slot(c, slot, B);
+    if (rc) return rc;
+    if (B == 0) { c->targeted[slot] = 1; return IRLOSC_OK; }
+    if (!tgt_pose) return fail(c, IRLOSC_ERR_ARG, "tgt_pose is NULL");
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    const size_t b = (size_t)B, nd = (size_t)c->cfg.ndev, e = c->esz;
+    HIPCHK(c, hipMemcpyAsync(c->dtgt[slot], tgt_pose, b * nd * 7 * e, hipMemcpyHostToDevice, c->stream));
+    if (tgt_vel) HIPCHK(c, hipMemcpyAsync(c->dtvel[slot], tgt_vel, b * nd * 6 * e, hipMemcpyHostToDevice, c->stream));
+    c->has_tvel[slot] = tgt_vel != nullptr;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->targeted[slot] = 1;
+    return IRLOSC_OK;
+}
+
+template <typename T>
+static void fill_params(const irlosc_ctx* c, KParams<T>& p, int B, const void* M, const void* J, const void* dq,
+                        const void* bias, const void* ee, const void* tgt, const void* tvel, const void* wrench,
+                        void* u, uint32_t* flags) {
+    memset(&p, 0, sizeof p);
+    p.M = (const T*)M; p.J = (const T*)J; p.dq = (const T*)dq; p.bias = (const T*)bias;
+    p.ee = (const T*)ee; p.tgt = (const T*)tgt; p.tvel = (const T*)tvel; p.wrench = (const T*)wrench;
+    p.u = (T*)u; p.flags = flags;
+    p.gains = (const T*)c->dgains; p.null_kv = (const T*)c->dnullkv;
+    p.index = nullptr;
+    p.gains_per_instance = c->gains_nb > 1;
+    p.B = B; p.n = c->cfg.n; p.k = c->k; p.ndev = c->cfg.ndev; p.cfgflags = c->cfg.flags;
+    int row = 0;
+    for (int d = 0; d < c->cfg.ndev; ++d) {
+        DevMeta& m = p.dev[d];
+        m.row0 = row; m.rows = c->cfg.dev_rows[d]; row += m.rows;
+        m.dofmask = 0;
+        for (int i = 0; i < 6; ++i) if (c->cfg.ctrlr_dof[d][i]) m.dofmask |= 1u << i;
+        m.calc = (c->cfg.calc_xyz[d] ? 1u : 0u) | (c->cfg.calc_abg[d] ? 2u : 0u);
+        m.joint_mask = c->cfg.joint_mask[d];
+        m.jidx0 = c->cfg.j_idx0[d];
+    }
+}
+
+template <typename T>
+static int launch_t(irlosc_ctx* c, int B, const void* M, const void* J, const void* dq, const void* bias,
+                    const void* ee, const void* tgt, const void* tvel, const void* wrench, void* u,
+                    uint32_t* flags, hipStream_t st) {
+    KParams<T> p;
+    fill_params<T>(c, p, B, M, J, dq, bias, ee, tgt, tvel, wrench, u, flags);
+#ifndef IRLOSC_NO_GROUP_KERNEL
+    if (c->kernel == IRLOSC_KERNEL_GROUP) {
+        int rc = launch_group<T>(p, c->dworklist, c->dworkcount, st);
+        if (rc) return fail(c, IRLOSC_ERR_HIP, "group kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return IRLOSC_OK;
+    }
+#endif
+    size_t smem = generic_smem_bytes<T>(p.n, p.k, p.ndev);
+    hipLaunchKernelGGL(osc_generic_kernel<T>, dim3(B), dim3(64), smem, st, p);
+    HIPCHK(c, hipGetLastError());
+    return IRLOSC_OK;
+}
+
+static int launch(irlosc_ctx* c, int B, const void* M, const void* J, const void* dq, const void* bias,
+                  const void* ee, const void* tgt, const void* tvel, const void* wrench, void* u,
+                  uint32_t* flags, hipStream_t st) {
+    if (B == 0) return IRLOSC_OK;
+    if (c->gains_nb == 0) return fail(c, IRLOSC_ERR_STATE, "irlosc_set_gains has not been called");
+    if (c->cfg.dtype == IRLOSC_F64) return launch_t<double>(c, B, M, J, dq, bias, ee, tgt, tvel, wrench, u, flags, st);
+    return launch_t<float>(c, B, M, J, dq, bias, ee, tgt, tvel, wrench, u, flags, st);
+}
+
+static int launch_slot(irlosc_ctx* c, int slot, int B) {
+    if (!c->uploaded[slot] || !c->targeted[slot])
+        return fail(c, IRLOSC_ERR_STATE, "slot %d: irlosc_upload and irlosc_set_targets must precede a step", slot);
+    return launch(c, B, c->dM[slot], c->dJ[slot], c->ddq[slot], c->dbias[slot], c->dee[slot], c->dtgt[slot],
+                  c->has_tvel[slot] ? c->dtvel[slot] : nullptr, c->has_wrench[slot] ? c->dwrench[slot] : nullptr,
+                  c->du, c->dflags, c->stream);
+}
+
+extern "C" int irlosc_download(irlosc_ctx* c, int32_t B, void* u_host, uint32_t* flags_host) {
+    if (!c) return IRLOSC_ERR_ARG;
+    if (B < 0 || B > c->cfg.max_batch) return fail(c, IRLOSC_ERR_ARG, "B out of range");
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    if (u_host && B) HIPCHK(c, hipMemcpyAsync(u_host, c->du, (size_t)B * c->cfg.n * c->esz, hipMemcpyDeviceToHost, c->stream));
+    if (flags_host && B) HIPCHK(c, hipMemcpyAsync(flags_host, c->dflags, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return IRLOSC_OK;
+}
+
+extern "C" int irlosc_step(irlosc_ctx* c, int32_t slot, int32_t B, void* u_host, uint32_t* flags_host) {
+    if (!c) return IRLOSC_ERR_ARG;
+    int rc = check_slot(c, slot, B);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    rc = launch_slot(c, slot, B);
+    if (rc) return rc;
+    if (u_host || flags_host) return irlosc_download(c, B, u_host, flags_host);
+    return IRLOSC_OK;
+}
+
+extern "C" int irlosc_step_resident(irlosc_ctx* c, int32_t first_slot, int32_t B, int32_t iters, float* ms_total,
+                                    float* ms_kernel_avg) {
+    if (!c) return IRLOSC_ERR_ARG;
+    int rc = check_slot(c, first_slot, B);
+    if (rc) return rc;
+    if (iters < 1) return fail(c, IRLOSC_ERR_ARG, "iters must be >= 1");
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < iters; ++i) {
+        rc = launch_slot(c, (first_slot + i) % c->cfg.n_slots, B);
+        if (rc) return rc;
+    }
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (ms_total) *ms_total = ms;
+    if (ms_kernel_avg) *ms_kernel_avg = ms / (float)iters;
+    return IRLOSC_OK;
+}
+
+extern "C" int irlosc_sync(irlosc_ctx* c) {
+    if (!c) return IRLOSC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return IRLOSC_OK;
+}
+
+extern "C" int irlosc_step_device(irlosc_ctx* c, int32_t B, const void* dM, const void* dJ, const void* ddq,
+                                  const void* dbias, const void* dee_pose, const void* dtgt_pose,
+                                  const void* dtgt_vel, const void* dwrench, void* du, uint32_t* dflags,
+                                  void* hip_stream) {
+    if (!c) return IRLOSC_ERR_ARG;
+    if (B < 0 || B > c->cfg.max_batch) return fail(c, IRLOSC_ERR_ARG, "B=%d out of [0,%d]", B, c->cfg.max_batch);
+    if (!dM || !dJ || !ddq || !dee_pose || !dtgt_pose || !du || !dflags)
+        return fail(c, IRLOSC_ERR_ARG, "dM, dJ, ddq, dee_pose, dtgt_pose, du and dflags are required");
+    if ((c->cfg.flags & IRLOSC_USE_G) && !dbias) return fail(c, IRLOSC_ERR_ARG, "dbias required with IRLOSC_USE_G");
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    return launch(c, B, dM, dJ, ddq, dbias, dee_pose, dtgt_pose, dtgt_vel, dwrench, du, dflags, st);
+}

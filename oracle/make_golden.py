@@ -193,6 +193,62 @@ def make_case(name, seed, B, cfg_file, target_order, dev_gain_names, nullspace=T
           f"cond(Mx_inv) med {np.median(cond):.2e} max {cond.max():.2e}  -> {os.path.getsize(path) // 1024} KiB")
 
 
+def make_e2e_case(name, seed, B, cfg_file, target_order, dev_gain_names, nullspace=True, use_g=True,
+                  admittance=False, n_free_bodies=0):
+    """End-to-end fixture: the RAW simulator arrays (what a backend holds) plus the reference's
+    assembled state and its (force_idxs, forces).  Lets tests rebuild a FakeSim, run the build's own
+    MujocoApp/Robot/Device/OSC on it and compare every stage with the reference's."""
+    rng = np.random.default_rng(seed)
+    cfg = load_cfg(cfg_file)
+    ee_bodies = ["ur_stand_dummy", "ur_EE_ur5right", "ur_EE_ur5left"]
+    keys = ("qM", "qvel", "qfrc_bias", "sensordata", "jacp", "jacr", "xpos", "xquat", "xmat_right",
+            "xmat_left", "tgt_xyz", "tgt_quat", "M", "J", "dq", "wrench", "forces_flat")
+    rec = {k: [] for k in keys}
+    meta = None
+    for b in range(B):
+        sim = fakesim.FakeSim(n_free_bodies=n_free_bodies)
+        fakesim.randomize(sim, rng, wrench=admittance)
+        robot, osc = build_reference(cfg, sim, dev_gain_names, nullspace, use_g, admittance)
+        targets = {}
+        for dn in target_order:
+            dev = robot.get_device(dn)
+            t = RefTarget()
+            t.set_xyz(dev.get_state(RefDeviceState.EE_XYZ) + rng.normal(0.0, 0.2, 3))
+            t.set_abg(rng.uniform(-1.0, 1.0, 3))
+            targets[dn] = t
+        state = robot.get_all_states()
+        Js, J_idxs = state[RefRobotState.J]
+        force_idxs, forces = osc.generate(targets)
+        d = sim.data
+        bids = [sim.model.body_name2id(x) for x in ee_bodies]
+        rec["qM"].append(np.array(d.qM)); rec["qvel"].append(np.array(d.qvel))
+        rec["qfrc_bias"].append(np.array(d.qfrc_bias)); rec["sensordata"].append(np.array(d.sensordata))
+        rec["jacp"].append(d.body_jacp[bids]); rec["jacr"].append(d.body_jacr[bids])
+        rec["xpos"].append(d.body_xpos[bids]); rec["xquat"].append(d.body_xquat[bids])
+        rec["xmat_right"].append(d.site_xmat["ft_frame_ur5right"]); rec["xmat_left"].append(d.site_xmat["ft_frame_ur5left"])
+        rec["tgt_xyz"].append([targets[dn].get_xyz() for dn in target_order])
+        rec["tgt_quat"].append([targets[dn].get_quat() for dn in target_order])
+        rec["M"].append(state[RefRobotState.M]); rec["dq"].append(state[RefRobotState.DQ])
+        rec["J"].append(np.vstack([Js[dn] for dn in target_order]))
+        rec["wrench"].append([np.concatenate([state[dn][RefDeviceState.FORCE], state[dn][RefDeviceState.TORQUE]])
+                              for dn in target_order])
+        rec["forces_flat"].append(np.concatenate(forces))
+        if meta is None:
+            meta = dict(cfg_file=cfg_file, target_order=list(target_order), ee_bodies=ee_bodies,
+                        dev_gain_names=[list(x) for x in dev_gain_names], nullspace=nullspace, use_g=use_g,
+                        admittance=admittance, n_free_bodies=n_free_bodies, seed=seed,
+                        force_idxs=[np.asarray(x).tolist() for x in force_idxs],
+                        force_lens=[len(f) for f in forces],
+                        joint_ids={dn: [int(x) for x in robot.get_device(dn).joint_ids] for dn in target_order},
+                        joint_names={dn: list(robot.get_device(dn).joint_names) for dn in target_order},
+                        J_idxs={dn: [int(x) for x in J_idxs[dn]] for dn in J_idxs})
+    arrays = {k: np.asarray(v, dtype=np.float64) for k, v in rec.items()}
+    arrays["layout_json"] = np.array(json.dumps(meta))
+    path = os.path.join(OUT_DIR, f"{name}.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name:28s} B={B:3d} (end-to-end sim state) -> {os.path.getsize(path) // 1024} KiB")
+
+
 RLB = ("ur5right", "ur5left", "base")
 BRL = ("base", "ur5right", "ur5left")
 G_GAIN = [("base", "osc0"), ("ur5right", "osc2"), ("ur5left", "osc2")]
@@ -219,5 +275,8 @@ if __name__ == "__main__":
     make_case("k13_gimbal", S + 10, 16, "default_xyz_abg.yaml", RLB, G_GAIN, all_actuated=True, gimbal=True)
     make_case("k13_random_gains", S + 11, 16, "default_xyz_abg.yaml", RLB, G_GAIN, all_actuated=True,
               random_gains=True)
+    make_e2e_case("e2e_gain_test", S + 21, 6, "default_xyz.yaml", RLB, G_GAIN)
+    make_e2e_case("e2e_admit_test", S + 22, 6, "default_xyz_abg.yaml", ("ur5right", "ur5left"), G_ADMIT,
+                  admittance=True, n_free_bodies=2)
     make_case("k13_no_max_vel", S + 12, 8, "default_xyz_abg.yaml", RLB, G_GAIN, all_actuated=True,
               no_max_vel=("ur5left",))

@@ -16,7 +16,53 @@ def pytest_configure(config):
 
 
 def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith("e2e_"))
+
+
+def load_e2e(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    g = {k: z[k] for k in z.files if k != "layout_json"}
+    g["meta"] = json.loads(str(z["layout_json"]))
+    return g
+
+
+def sim_from_e2e(g, b):
+    """Rebuild the FakeSim state of instance b of an end-to-end fixture."""
+    from irl_control_amd.fakesim import FakeSim
+    meta = g["meta"]
+    sim = FakeSim(n_free_bodies=meta["n_free_bodies"])
+    d = sim.data
+    d.qM = g["qM"][b].copy()
+    d.qvel[:] = g["qvel"][b]
+    d.qfrc_bias[:] = g["qfrc_bias"][b]
+    d.sensordata[:] = g["sensordata"][b]
+    for i, body in enumerate(meta["ee_bodies"]):
+        bid = sim.model.body_name2id(body)
+        d.body_jacp[bid] = g["jacp"][b, i]
+        d.body_jacr[bid] = g["jacr"][b, i]
+        d.body_xpos[bid] = g["xpos"][b, i]
+        d.body_xquat[bid] = g["xquat"][b, i]
+    d.site_xmat["ft_frame_ur5right"] = g["xmat_right"][b].copy()
+    d.site_xmat["ft_frame_ur5left"] = g["xmat_left"][b].copy()
+    return sim
+
+
+def app_from_e2e(g, b):
+    """-> (app, robot, osc, targets) built with the build's own classes on the fixture's state."""
+    import irl_control_amd as ic
+    meta = g["meta"]
+    sim = sim_from_e2e(g, b)
+    app = ic.MujocoApp(meta["cfg_file"], None, sim=sim)
+    robot = app.get_robot("DualUR5")
+    cfgs = [(dn, app.get_controller_config(gn)) for dn, gn in meta["dev_gain_names"]]
+    ns = app.get_controller_config("nullspace") if meta["nullspace"] else None
+    osc = ic.OSC(robot, sim, cfgs, ns, use_g=meta["use_g"], admittance=meta["admittance"])
+    targets = {}
+    for i, dn in enumerate(meta["target_order"]):
+        t = ic.Target()
+        t.set_all_quat(g["tgt_xyz"][b, i], g["tgt_quat"][b, i])
+        targets[dn] = t
+    return app, robot, osc, targets
 
 
 def load_golden(name):

@@ -1,0 +1,78 @@
+"""The C-ABI shared library loads and exports every symbol include/irlosc.h declares (CPU box:
+no compute calls).  Compute without a GPU must fail loudly, never fall back."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from irl_control_amd import _lib
+from irl_control_amd.layout import OSCLayout
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "irlosc.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(irlosc_[a-z_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 14
+    for nm in names:
+        assert hasattr(lib, nm), nm
+    assert sorted(names) == sorted(_lib.EXPORTS)
+    assert lib.irlosc_abi_version() == 1
+
+
+def test_cfg_struct_matches_header_layout():
+    # 8 int32 + 4 int32 + 24 u8 + 4 u8 + 4 u8 + 4 u32 + 4 i32
+    assert C.sizeof(_lib.Cfg) == 8 * 4 + 16 + 24 + 4 + 4 + 16 + 16
+
+
+def _layout():
+    return OSCLayout(n=25, dev_names=["a", "b"], ctrlr_dof=[[True] * 6, [True] * 6],
+                     joint_ids=[list(range(1, 13)), list(range(13, 25))], j_idx0=[1, 7])
+
+
+def test_create_validates_arguments():
+    lib = _lib.load()
+    cfg = _layout().to_cfg(_lib.F64, 4)
+    cfg.dev_rows[0] = 5                      # inconsistent with the row mask
+    h = C.c_void_p()
+    assert lib.irlosc_create(C.byref(cfg), C.byref(h)) == -1
+    assert b"dev_rows" in lib.irlosc_last_error(None)
+    cfg = _layout().to_cfg(_lib.F64, 4)
+    cfg.dtype = 7
+    assert lib.irlosc_create(C.byref(cfg), C.byref(h)) == -1
+
+
+def test_no_cpu_fallback_without_gpu():
+    lib = _lib.load()
+    if lib.irlosc_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from irl_control_amd import BatchedOSC
+    with pytest.raises(_lib.IrloscError, match="no HIP device"):
+        BatchedOSC(_layout(), 4)
+
+
+def test_layout_rejects_out_of_range_joint_ids():
+    lay = OSCLayout(n=12, dev_names=["a"], ctrlr_dof=[[True] * 6], joint_ids=[[3, 12]], j_idx0=[0])
+    with pytest.raises(ValueError):
+        lay.to_cfg(_lib.F64, 1)
+
+
+def test_pack_gains_shapes():
+    from irl_control_amd.layout import pack_gains
+    lay = _layout()
+    g, nk, nb = pack_gains(lay, [200, 200], [50, 50], [200, 200], [[1, 2, 3]] * 2, [[.5, 1, 1]] * 2,
+                           [[1, 5]] * 2, 10.0)
+    assert g.shape == (1, 2, 12) and nb == 1 and nk.shape == (1,)
+    assert list(g[0, 0]) == [200, 50, 200, 1, 2, 3, .5, 1, 1, 1, 5, 1]
+    g, nk, nb = pack_gains(lay, np.full((4, 2), 200.), np.full((4, 2), 50.), np.full((4, 2), 200.),
+                           [[1, 2, 3]] * 2, [[.5, 1, 1]] * 2, [[1, 5]] * 2, np.full(4, 10.0))
+    assert g.shape == (4, 2, 12) and nb == 4

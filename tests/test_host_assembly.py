@@ -1,0 +1,107 @@
+"""Host side (no GPU): the build's Device / Robot / MujocoApp assemble the same index maps and
+the same M, J, dq, wrench as the reference's classes did on the same simulator state
+(fixtures e2e_*.npz hold both the raw sim arrays and the reference's assembled state)."""
+import numpy as np
+import pytest
+
+import irl_control_amd as ic
+from irl_control_amd import DeviceState, RobotState
+from conftest import app_from_e2e, load_e2e
+
+
+@pytest.mark.parametrize("name", ["e2e_gain_test", "e2e_admit_test"])
+def test_assembly_matches_reference(name):
+    g = load_e2e(name)
+    meta = g["meta"]
+    for b in range(g["M"].shape[0]):
+        app, robot, osc, targets = app_from_e2e(g, b)
+        st = robot.get_all_states()
+        Js, J_idxs = st[RobotState.J]
+        order = meta["target_order"]
+        assert np.array_equal(st[RobotState.M], g["M"][b])
+        assert np.array_equal(st[RobotState.DQ], g["dq"][b])
+        assert np.array_equal(np.vstack([Js[dn] for dn in order]), g["J"][b])
+        wr = np.array([np.concatenate([st[dn][DeviceState.FORCE], st[dn][DeviceState.TORQUE]]) for dn in order])
+        assert np.allclose(wr, g["wrench"][b], rtol=0, atol=0)
+        for dn in order:
+            dev = robot.get_device(dn)
+            assert list(dev.joint_ids) == meta["joint_ids"][dn]
+            assert list(dev.joint_names) == meta["joint_names"][dn]
+        assert {k: list(v) for k, v in J_idxs.items()} == meta["J_idxs"]
+        assert [list(robot.get_device(dn).ctrl_idxs) for dn in order] == meta["force_idxs"]
+
+
+def test_dual_ur5_index_tables():
+    """joint / actuator maps of the Dual-UR5."""
+    app = ic.MujocoApp("iros2022.yaml", None, sim=ic.FakeSim())
+    robot = app.get_robot("DualUR5")
+    base, right, left = (robot.get_device(n) for n in ("base", "ur5right", "ur5left"))
+    assert list(base.joint_ids_all) == [0]
+    assert list(right.joint_ids) == list(range(1, 7)) and list(right.gripper_ids) == list(range(7, 13))
+    assert list(left.joint_ids) == list(range(13, 19)) and list(left.gripper_ids) == list(range(19, 25))
+    assert list(base.ctrl_idxs) == [0] and list(right.ctrl_idxs) == list(range(1, 8)) \
+        and list(left.ctrl_idxs) == list(range(8, 15))
+    assert list(right.actuator_trnids) == [1, 2, 3, 4, 5, 6, 10]
+    assert list(left.actuator_trnids) == [13, 14, 15, 16, 17, 18, 22]
+    assert robot.num_joints_total == 25 and robot.num_scene_joints == 25
+    # start angles written into qpos by the constructor (device.py:76-79)
+    assert np.allclose(app.sim.data.qpos[0], -1.56)
+
+
+def test_missing_start_body_reproduces_reference_failure():
+    """Without start_body the arm chain swallows the stand joint and the 6 start angles no longer
+    fit the 7 joint ids: the reference raises ValueError there; so do we."""
+    import yaml, os, tempfile
+    from irl_control_amd import mujoco_app
+    path = os.path.join(os.path.dirname(mujoco_app.__file__), "robot_configs", "default_xyz.yaml")
+    cfg = yaml.safe_load(open(path))
+    for d in cfg["devices"]:
+        d.pop("start_body", None)
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+        yaml.safe_dump(cfg, f)
+    with pytest.raises(ValueError):
+        ic.MujocoApp(f.name, None, sim=ic.FakeSim())
+    os.unlink(f.name)
+
+
+def test_polling_thread_mode_contract():
+    sim = ic.FakeSim()
+    app = ic.MujocoApp("iros2022.yaml", None, use_sim=False, sim=sim)
+    robot = app.get_robot("DualUR5")
+    with pytest.raises(AssertionError):
+        robot.stop()                      # not running (robot.py:119)
+    import threading, time
+    th = threading.Thread(target=robot.start)
+    th.start()
+    time.sleep(0.05)
+    assert robot.is_running()
+    st = robot.get_all_states()
+    assert st[RobotState.M].shape == (25, 25)
+    robot.stop()
+    th.join(timeout=2)
+    assert not th.is_alive()
+    app2 = ic.MujocoApp("iros2022.yaml", None, use_sim=True, sim=ic.FakeSim())
+    with pytest.raises(AssertionError):
+        app2.get_robot("DualUR5").start()  # use_sim must be False (robot.py:104)
+
+
+def test_target_api():
+    t = ic.Target()
+    assert np.array_equal(t.get_quat(), [1, 0, 0, 0]) and np.array_equal(t.get_xyz(), np.zeros(3))
+    assert np.all(np.hstack([t.get_xyz_vel(), t.get_abg_vel()]) == 0)
+    t.set_abg([0.1, -0.2, 0.3])
+    assert np.allclose(t.get_abg(), [0.1, -0.2, 0.3])
+    with pytest.raises(AssertionError):
+        t.set_xyz([1, 2])
+    with pytest.raises(AssertionError):
+        ic.Target([0] * 5)
+    t.set_all_quat([1, 2, 3], [0, 1, 0, 0])
+    assert np.array_equal(t.pose7(), [1, 2, 3, 0, 1, 0, 0])
+
+
+def test_osc_ctor_mutates_gain_dicts_like_reference():
+    app = ic.MujocoApp("default_xyz_abg.yaml", None, sim=ic.FakeSim())
+    g = app.get_controller_config("osc2")
+    ic.OSC(app.get_robot("DualUR5"), app.sim, [("ur5right", g)])
+    assert np.array_equal(g["task_space_gains"], [200] * 6)
+    assert np.allclose(g["lamb"], np.array([200] * 6) / 50)
