@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd SQLite result (kernel trace) into a small text table:
+per kernel name -> calls, total ms, avg us, min us, max us, VGPRs, LDS.  Usage:
+    python tools/rocprof_summary.py gpurun_out/prof_x/x_results.db > profiles/r01_x_kernel_stats.txt
+"""
+import sqlite3
+import sys
+
+
+def main(path):
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    rows = db.execute("select * from kernels").fetchall()
+    ix = {c: i for i, c in enumerate(cols)}
+    name_c = "name" if "name" in ix else "kernel_name"
+    agg = {}
+    for r in rows:
+        nm = r[ix[name_c]]
+        dur = (r[ix["end"]] - r[ix["start"]]) / 1e3   # ns -> us
+        a = agg.setdefault(nm, dict(n=0, tot=0.0, mn=1e30, mx=0.0, row=r))
+        a["n"] += 1; a["tot"] += dur; a["mn"] = min(a["mn"], dur); a["mx"] = max(a["mx"], dur)
+    tot_all = sum(a["tot"] for a in agg.values()) or 1.0
+    print(f"# rocprofv3 --kernel-trace summary of {path}")
+    print(f"{'kernel':70s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}  extra")
+    for nm, a in sorted(agg.items(), key=lambda kv: -kv[1]["tot"]):
+        r = a["row"]
+        extra = " ".join(f"{c}={r[ix[c]]}" for c in ("grid_size", "workgroup_size", "lds_size", "scratch_size",
+                                                     "vgpr_count", "accum_vgpr_count", "sgpr_count",
+                                                     "grid_x", "workgroup_x", "lds_block_size", "arch_vgpr_count")
+                         if c in ix)
+        print(f"{nm[:70]:70s} {a['n']:6d} {a['tot'] / 1e3:10.3f} {a['tot'] / a['n']:10.2f} {a['mn']:10.2f} "
+              f"{a['mx']:10.2f} {100 * a['tot'] / tot_all:6.2f}  {extra}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
