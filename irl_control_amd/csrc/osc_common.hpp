@@ -34,7 +34,9 @@ struct KParams {
     uint32_t* flags;  // [B]
     const T* gains;   // [nb][ndev][12]
     const T* null_kv; // [nb]
-    const int32_t* index;  // optional worklist of instance ids (nullptr = identity)
+    const int32_t* index;        // optional worklist of instance ids (nullptr = identity)
+    const int32_t* index_count;  // device-side length of the worklist (grid-strided) when index != nullptr
+    int32_t b0;                  // first instance handled by block 0 when index == nullptr
     int32_t gains_per_instance;
     int32_t B, n, k, ndev;
     uint32_t cfgflags;

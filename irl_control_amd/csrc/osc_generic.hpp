@@ -60,8 +60,10 @@ __global__ __launch_bounds__(64) void osc_generic_kernel(const KParams<T> p) {
     const int lane = threadIdx.x;
     const int n = p.n, k = p.k, ndev = p.ndev;
     const int ldn = n | 1, ldk = k | 1;
-    int b = blockIdx.x;
-    if (p.index) b = p.index[b];
+    // identity mode: block i handles instance b0 + i; worklist mode: grid-stride over index[0..*index_count)
+    const int wl_count = p.index ? *p.index_count : 0;
+    for (int it = blockIdx.x; p.index ? (it < wl_count) : (it == (int)blockIdx.x); it += gridDim.x) {
+    const int b = p.index ? p.index[it] : p.b0 + it;
 
     T* Ms = smem;                 // n x ldn   (M, then its Cholesky factor L in the lower triangle)
     T* Js = Ms + n * ldn;         // k x ldn
@@ -306,6 +308,8 @@ __global__ __launch_bounds__(64) void osc_generic_kernel(const KParams<T> p) {
     }
     if (__ballot(bad)) flags |= IRLOSC_FLAG_NONFINITE;
     if (lane == 0) p.flags[b] = flags;
+    __syncthreads();
+    }  // instance loop
 }
 
 template <typename T>

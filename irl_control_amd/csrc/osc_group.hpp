@@ -1,0 +1,517 @@
+// Throughput OSC kernel for the Dual-UR5 shapes (n = 25): FOUR LANES PER ROBOT INSTANCE.
+//
+// Why not one wavefront per instance: with n = 25 and k <= 13 a 64-lane wave is 60-80 % idle in
+// every phase and every operand has to be broadcast, so the VALU issue rate — not HBM — bounds
+// the generic kernel at ~5e7 steps/s.  Here a wave carries 16 instances; the 4 lanes of a quad own
+// the joint rows i = 4s + g (slot s = 0..6, g = lane & 3; rows 25..27 are zero padding) and keep
+// their rows of the Cholesky factor L, of Y = L^-1 J^T and of J in VGPRs with COMPILE-TIME indices
+// (everything below is fully unrolled).  The only cross-lane traffic is quad-local DPP
+// (quad_perm broadcasts / butterflies), which costs no LDS and no extra issue slot when fused.
+//
+// Data movement: inputs stay in the caller's batch-major AoS layout (include/irlosc.h).  Each
+// wave streams its 16-instance tile HBM -> LDS with the asynchronous LDS-DMA path
+// (global_load_lds_dwordx4, 4-row chunks of M and J = 16 x 400 B segments; single rows with
+// global_load_lds_dword) through a 3-deep ring, with counted s_waitcnt vmcnt(N) so that two
+// chunks (12.5 KB) are always in flight per wave while the current one is consumed.  The LDS image
+// of a chunk is instance-major with a 100-dword stride: quad q reads dwords 100q + 4s + g, which
+// spreads a 32-lane ds_read_b32 group over all 32 banks.
+//
+// Math per instance (same algebra as osc_generic.hpp; osc.py:41-200):
+//   column-by-column (left-looking) Cholesky of M while its rows stream in, Mdq accumulated from
+//   the same reads; per Jacobian row r: y_r = L^-1 J_r^T by column-oriented substitution, dx_r;
+//   A = Y^T Y by quad-reduced partial dot products; then per lane (replicated in the quad):
+//   Cholesky of A, W = L_A^-1, the cond(A) certificate, t = W^T W w; finally
+//   u = u0 + bias - kvn*Mdq - J^T t from the register copy of J.
+// Instances whose k x k solve is not certifiably the reference's branch (cond bound >= 1e5 with
+// |det| < 1e-4, or A not positive definite) are appended to a worklist and redone by the generic
+// kernel, which owns the eigen-decomposition.
+#pragma once
+#include "osc_common.hpp"
+#include "osc_generic.hpp"
+
+namespace irlosc {
+
+namespace grp {
+
+constexpr int N = 25;        // joints
+constexpr int S = 7;         // row slots per lane (4 * 7 = 28 >= 25)
+constexpr int TILE = 16;     // instances per wave
+constexpr int BUF_FLOATS = 1792;   // 7 DMA instructions x 1 KiB
+constexpr int NBUF = 3;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// broadcast lane g of each quad to the whole quad
+__device__ __forceinline__ float qbcast(float v, int g) {
+    switch (g & 3) {
+        case 0: return dpp_f<0x00>(v);
+        case 1: return dpp_f<0x55>(v);
+        case 2: return dpp_f<0xAA>(v);
+        default: return dpp_f<0xFF>(v);
+    }
+}
+// sum over the 4 lanes of a quad (result in every lane)
+__device__ __forceinline__ float qsum(float v) {
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+    return v;
+}
+__device__ __forceinline__ int qbcast_i(int v, int g) {
+    switch (g & 3) {
+        case 0: return __builtin_amdgcn_update_dpp(0, v, 0x00, 0xf, 0xf, false);
+        case 1: return __builtin_amdgcn_update_dpp(0, v, 0x55, 0xf, 0xf, false);
+        case 2: return __builtin_amdgcn_update_dpp(0, v, 0xAA, 0xf, 0xf, false);
+        default: return __builtin_amdgcn_update_dpp(0, v, 0xFF, 0xf, 0xf, false);
+    }
+}
+__device__ __forceinline__ uint32_t qor(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);
+    return v;
+}
+
+// s_waitcnt with only vmcnt constrained (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14])
+template <int NV>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(NV >= 0 && NV < 64, "vmcnt range");
+    __builtin_amdgcn_s_waitcnt((NV & 0xF) | (0x7 << 4) | (0xF << 8) | ((NV >> 4) << 14));
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void wait_lgkm0() {
+    __builtin_amdgcn_s_waitcnt(0xF | (0x7 << 4) | (0x0 << 8) | (0x3 << 14));
+    asm volatile("" ::: "memory");
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// DMA a 4-row chunk (100 floats = 25 x 16 B per instance, 16 instances): 7 wave instructions.
+// src = first float of (tile instance 0, row0); stride = floats between instances.
+__device__ __forceinline__ void dma_rows4(const float* src, int stride, float* buf, int lane) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        int x = j * 64 + lane;               // 16-byte piece index, instance-major (25 per instance)
+        x = x > 399 ? 399 : x;
+        int inst = (x * 5243) >> 17;         // x / 25 for x < 2^12
+        int pc = x - inst * 25;
+        const float* g = src + inst * stride + pc * 4;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(buf + j * 256), 16, 0, 0);
+    }
+}
+// DMA a single-row chunk (25 floats per instance): 7 wave instructions of 4 B per lane.
+__device__ __forceinline__ void dma_rows1(const float* src, int stride, float* buf, int lane) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        int x = j * 64 + lane;
+        x = x > 399 ? 399 : x;
+        int inst = (x * 5243) >> 17;
+        int e = x - inst * 25;
+        const float* g = src + inst * stride + e;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(buf + j * 64), 4, 0, 0);
+    }
+}
+// DMA a contiguous block of `pieces` 16-byte pieces (pieces <= 128): 2 wave instructions.
+__device__ __forceinline__ void dma_linear2(const float* src, int pieces, float* buf, int lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int x = j * 64 + lane;
+        x = x >= pieces ? pieces - 1 : x;
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + x * 4), (lptr_t)(buf + j * 256), 16, 0, 0);
+    }
+}
+
+// Row rr of J chunk jc for quad q.  Chunks 0,1,2 (4 rows, stride 100) sit in ring slots 1,2,0;
+// chunk 3 (1 row, stride 25) in the tail buffer.
+__device__ __forceinline__ const float* jrow_ptr(const float* ring, const float* jtail, int jc, int q, int rr) {
+    if (jc < 3) return ring + ((jc + 1) % 3) * BUF_FLOATS + q * 100 + rr * N;
+    return jtail + q * N;
+}
+
+}  // namespace grp
+
+// One wave = 16 instances.  K = stacked task rows, NDEV = target devices (<= 4, one quad lane each).
+template <int K, int NDEV>
+__global__ __launch_bounds__(64, 1) void osc_group_kernel_f32(const KParams<float> p, int32_t* __restrict__ worklist,
+                                                             int32_t* __restrict__ workcount) {
+    using namespace grp;
+    constexpr int NCHM = 7;                                   // M chunks: 6 x 4 rows + 1 row
+    constexpr int NCHJ = (K + 3) / 4;                         // J chunks of 4 rows; the last may be shorter
+    static_assert(K % 4 == 0 || K % 4 == 1, "the last J chunk must be 4 rows or 1 row");
+    constexpr int VEC_DQ = 0, VEC_BIAS = 512, VEC_EE = 1024, VEC_TGT = 1536, VEC_TV = 2048, VEC_WR = 2560;
+    constexpr int VEC_W = 3072;                               // [16][16] exchange area for the task vector
+    constexpr int VEC_X = 3328;                               // [16][48] per-quad Mdq (25) and dx (K) parking
+    __shared__ __attribute__((aligned(16))) float ring[NBUF * BUF_FLOATS];
+    __shared__ __attribute__((aligned(16))) float vec[3328 + 768];
+    __shared__ __attribute__((aligned(16))) float jtail[448];   // 1-row chunk J[12] (k = 13): 7 x 64 dwords
+    constexpr bool HASJ3 = (K % 4) == 1;
+
+    const int lane = threadIdx.x;
+    const int g = lane & 3, q = lane >> 2;
+    const int tile = blockIdx.x;
+    const int b = tile * TILE + q;
+    const size_t t0 = (size_t)tile * TILE;
+    const bool has_tv = p.tvel != nullptr;
+    const bool has_wr = (p.cfgflags & IRLOSC_ADMITTANCE) && p.wrench != nullptr;
+
+    // ---------------- prologue: vectors + first chunks in flight -----------------------------------
+    // Issue order (7 DMA instructions per chunk):  vec(12) M0 M1 M2 | M3 | M4 | M5 | M6 [J3] | J0 | J1 | J2
+    // where "| X" means X is issued right after the chunk three places earlier has been consumed.
+    // M chunk c lives in ring slot c % 3 and is recycled; J chunks 0,1,2 land in slots 1,2,0 once
+    // M4,M5,M6 are consumed and then STAY (J is re-read for u -= J^T t); the 1-row chunk J3 (k = 13)
+    // has its own small buffer.  vmcnt retires in order, so "wait until at most n younger DMA
+    // instructions are outstanding" is exact.
+    dma_linear2(p.dq + t0 * N, TILE * N / 4, vec + VEC_DQ, lane);
+    dma_linear2((p.cfgflags & IRLOSC_USE_G) ? p.bias + t0 * N : p.dq + t0 * N, TILE * N / 4, vec + VEC_BIAS, lane);
+    dma_linear2(p.ee + t0 * NDEV * 7, TILE * NDEV * 7 / 4, vec + VEC_EE, lane);
+    dma_linear2(p.tgt + t0 * NDEV * 7, TILE * NDEV * 7 / 4, vec + VEC_TGT, lane);
+    dma_linear2(has_tv ? p.tvel + t0 * NDEV * 6 : p.dq + t0 * N, TILE * NDEV * 6 / 4, vec + VEC_TV, lane);
+    dma_linear2(has_wr ? p.wrench + t0 * NDEV * 6 : p.dq + t0 * N, TILE * NDEV * 6 / 4, vec + VEC_WR, lane);
+    const float* Mt = p.M + t0 * (N * N);
+    const float* Jt = p.J + t0 * (K * N);
+    dma_rows4(Mt, N * N, ring + 0 * BUF_FLOATS, lane);
+    dma_rows4(Mt + 4 * N, N * N, ring + 1 * BUF_FLOATS, lane);
+    dma_rows4(Mt + 8 * N, N * N, ring + 2 * BUF_FLOATS, lane);
+
+    // ---------------- register state ----------------------------------------------------------------
+    float Ls[S][28];       // strictly-lower rows of L owned by this lane; upper/diagonal entries are 0
+    float DinvOwn[S];      // 1 / L[i][i] for the lane's own rows
+    float mdq[S];          // (M dq)[i] for own rows
+    float dqOwn[S];
+    float Yo[K][S];        // own rows of Y = L^-1 J^T
+    uint32_t flags = 0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) { DinvOwn[s] = 0.f; mdq[s] = 0.f; }
+
+    // own-column validity (row 4s+g < 25): only slot 6 of lanes g >= 1 is padding
+    const bool pad6 = g != 0;
+    const int col6 = pad6 ? 0 : 24;      // safe in-range column for the masked slot
+    float* xq = vec + VEC_X + q * 48;    // per-quad exchange: [0..24] Mdq, [25..37] dx, [32+..] unused
+
+    wait_vm<21>();                        // the 12 vector DMAs have landed (3 chunks = 21 still in flight)
+    {
+        const float* dqv = vec + VEC_DQ + q * N;
+#pragma unroll
+        for (int s = 0; s < S - 1; ++s) dqOwn[s] = dqv[4 * s + g];
+        const float t6 = dqv[col6];
+        dqOwn[6] = pad6 ? 0.f : t6;
+    }
+
+    // ---------------- stream M: Cholesky column by column -----------------------------------------------
+#pragma unroll
+    for (int ch = 0; ch < NCHM; ++ch) {
+        float* buf = ring + (ch % NBUF) * BUF_FLOATS;
+        if (ch <= 3) wait_vm<14>(); else wait_vm<7 * (HASJ3 ? 3 : 2)>();
+        const int R = ch < 6 ? 4 : 1;
+        const int istride = R * N;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int j = ch * 4 + rr;
+            const int sj = j >> 2, gj = j & 3;
+            const float* row = buf + q * istride + rr * N;
+            float mrow[S];
+#pragma unroll
+            for (int s = 0; s < S - 1; ++s) mrow[s] = row[4 * s + g];
+            const float m6 = row[col6];
+            mrow[6] = pad6 ? 0.f : m6;
+            const float dqj = vec[VEC_DQ + q * N + j];
+#pragma unroll
+            for (int s = 0; s < S; ++s) mdq[s] = fmaf(mrow[s], dqj, mdq[s]);   // (M^T dq) = (M dq), M symmetric
+            // left-looking column j: acc[s] = M[j][i] - sum_{c<j} L[i][c] L[j][c]
+            float acc[S];
+#pragma unroll
+            for (int s = sj; s < S; ++s) acc[s] = mrow[s];
+#pragma unroll
+            for (int c = 0; c < j; ++c) {
+                const float lj = qbcast(Ls[sj][c], gj);
+#pragma unroll
+                for (int s = sj; s < S; ++s) acc[s] = fmaf(-Ls[s][c], lj, acc[s]);
+            }
+            float d = qbcast(acc[sj], gj);
+            const bool notpd = !(d > 0.f);
+            flags |= notpd ? IRLOSC_FLAG_M_NOT_PD : 0u;
+            const float dfix = (d == d && d != 0.f) ? fabsf(d) : 1.f;
+            d = notpd ? dfix : d;
+            const float dinv = __builtin_amdgcn_rsqf(d);
+#pragma unroll
+            for (int s = sj + 1; s < S; ++s) Ls[s][j] = acc[s] * dinv;
+            Ls[sj][j] = (g > gj) ? acc[sj] * dinv : 0.f;
+            DinvOwn[sj] = (g == gj) ? dinv : DinvOwn[sj];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // recycle the ring slot just consumed
+        wait_lgkm0();
+        if (ch < 3) dma_rows4(Mt + (ch + 3) * 4 * N, N * N, buf, lane);
+        else if (ch == 3) {
+            dma_rows1(Mt + 24 * N, N * N, buf, lane);
+            if (HASJ3) dma_rows1(Jt + 12 * N, K * N, jtail, lane);
+        } else dma_rows4(Jt + (ch - 4) * 4 * N, K * N, buf, lane);   // J0,J1,J2 -> slots 1,2,0 (resident)
+    }
+    // park Mdq in LDS (own rows; rows >= 25 never written)
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s) xq[4 * s + g] = mdq[s];
+    if (!pad6) xq[24] = mdq[6];
+
+    // ---------------- J rows: dx and forward substitutions ------------------------------------------------
+#pragma unroll
+    for (int jc = 0; jc < NCHJ; ++jc) {
+        if (jc == 0) wait_vm<14>(); else if (jc == 1) wait_vm<7>(); else wait_vm<0>();
+        const int R = jc < 3 ? 4 : 1;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int r = jc * 4 + rr;
+            const float* row = jrow_ptr(ring, jtail, jc, q, rr);
+            float bb[S];
+#pragma unroll
+            for (int s = 0; s < S - 1; ++s) bb[s] = row[4 * s + g];
+            const float b6 = row[col6];
+            bb[6] = pad6 ? 0.f : b6;
+            float dxp = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) dxp = fmaf(bb[s], dqOwn[s], dxp);
+            dxp = qsum(dxp);
+            if (g == 0) xq[25 + r] = dxp;
+            // column-oriented substitution: y_c = b_c / L[c][c] (owner lane), then b_i -= L[i][c] y_c
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                const int sc = c >> 2, gc = c & 3;
+                const float yc = qbcast(bb[sc] * DinvOwn[sc], gc);
+#pragma unroll
+                for (int s = sc; s < S; ++s) bb[s] = fmaf(-Ls[s][c], yc, bb[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s) Yo[r][s] = bb[s] * DinvOwn[s];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---------------- A = Y^T Y (lower), replicated in the quad ---------------------------------------------------
+    float A[K][K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+#pragma unroll
+        for (int s2 = 0; s2 <= r; ++s2) {
+            float a = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) a = fmaf(Yo[r][s], Yo[s2][s], a);
+            A[r][s2] = qsum(a);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---------------- task-space signal: lane g of the quad handles device g ---------------------------------------
+    float kvn = 0.f;
+    if (p.cfgflags & IRLOSC_NULLSPACE) kvn = p.null_kv[p.gains_per_instance ? b : 0];
+    const float* gbase = p.gains + (p.gains_per_instance ? (size_t)b * NDEV * IRLOSC_GAIN_WORDS : 0);
+    float* wls = vec + VEC_W + q * 16;
+    int brA_own = 1;
+    float kv_own = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    if (g < NDEV) {
+        const DevMeta dm = p.dev[g];
+        const float* gg = gbase + g * IRLOSC_GAIN_WORDS;
+        float gl[IRLOSC_GAIN_WORDS];
+#pragma unroll
+        for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) gl[i] = gg[i];
+        kv_own = gl[1];
+        float ee[7], tg[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            ee[i] = vec[VEC_EE + (q * NDEV + g) * 7 + i];
+            tg[i] = vec[VEC_TGT + (q * NDEV + g) * 7 + i];
+        }
+        float e[6];
+        task_error6<float>(ee, tg, dm.calc & 1u, dm.calc & 2u, e);
+        apply_gains6<float>(gl, e);
+        float tv[6];
+        bool all_nonzero = has_tv;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            tv[i] = has_tv ? vec[VEC_TV + (q * NDEV + g) * 6 + i] : 0.f;
+            all_nonzero = all_nonzero && (tv[i] != 0.f);
+        }
+        brA_own = all_nonzero ? 0 : 1;
+        if (all_nonzero) {
+            flags |= IRLOSC_FLAG_VEL_BRANCH_B;
+            if (dm.jidx0 + dm.rows > K) flags |= IRLOSC_FLAG_BAD_JIDX;
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (dm.dofmask & (1u << i)) {
+                float v = e[i];
+                if (all_nonzero) {
+                    const int row = dm.jidx0 + cnt;
+                    const float dxv = xq[25 + (row < K ? row : 0)];
+                    const float damp = (i < 3) ? gl[6 + i] : 1.f;
+                    v += gl[1] * ((row < K ? dxv : 0.f) - tv[i]) * damp;
+                }
+                if (has_wr) v += vec[VEC_WR + (q * NDEV + g) * 6 + i];
+                wls[dm.row0 + cnt] = v;
+                ++cnt;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    wait_lgkm0();
+    float w[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) w[r] = wls[r] - kvn * xq[25 + r];
+
+    // ---------------- k x k (per lane): Cholesky of A in place, cond certificate, t = A^-1 w ------------------
+    float nA2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+#pragma unroll
+        for (int c = 0; c < r; ++c) nA2 = fmaf(2.f * A[r][c], A[r][c], nA2);
+        nA2 = fmaf(A[r][r], A[r][r], nA2);
+    }
+    bool pdA = true;
+    float detA = 1.f;
+    float dA[K];                       // 1 / L_A[j][j]
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        float d = A[j][j];
+#pragma unroll
+        for (int c = 0; c < j; ++c) d = fmaf(-A[j][c], A[j][c], d);
+        const bool npd = !(d > 0.f);
+        pdA = pdA && !npd;
+        const float dfix = (d == d && d != 0.f) ? fabsf(d) : 1.f;
+        d = npd ? dfix : d;
+        detA *= d;
+        const float di = __builtin_amdgcn_rsqf(d);
+        dA[j] = di;
+#pragma unroll
+        for (int i = j + 1; i < K; ++i) {
+            float a = A[i][j];
+#pragma unroll
+            for (int c = 0; c < j; ++c) a = fmaf(-A[i][c], A[j][c], a);
+            A[i][j] = a * di;
+        }
+    }
+    // ||L_A^-1||_F^2 = trace(A^-1): column j of W = L_A^-1 by forward substitution, used and dropped
+    float nW2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        float wc[K];
+        wc[j] = dA[j];
+        nW2 = fmaf(wc[j], wc[j], nW2);
+#pragma unroll
+        for (int i = j + 1; i < K; ++i) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int c = j; c < i; ++c) s2 = fmaf(A[i][c], wc[c], s2);
+            wc[i] = -dA[i] * s2;
+            nW2 = fmaf(wc[i], wc[i], nW2);
+        }
+    }
+    const bool small_det = !(fabsf(detA) >= 1e-4f);
+    const float cond_bound = sqrtf(nA2) * nW2;        // >= cond_2(A) for SPD A
+    const bool plain = pdA && t_finite(cond_bound) && (!small_det || cond_bound < 0.99e5f);
+    flags |= small_det ? IRLOSC_FLAG_PINV_BRANCH : 0u;
+    float t[K];
+    // forward: z = L_A^-1 w ; backward: t = L_A^-T z
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        float s2 = w[i];
+#pragma unroll
+        for (int c = 0; c < i; ++c) s2 = fmaf(-A[i][c], t[c], s2);
+        t[i] = s2 * dA[i];
+    }
+#pragma unroll
+    for (int i = K - 1; i >= 0; --i) {
+        float s2 = t[i];
+#pragma unroll
+        for (int c = i + 1; c < K; ++c) s2 = fmaf(-A[c][i], t[c], s2);
+        t[i] = s2 * dA[i];
+    }
+
+    // ---------------- joint torques for the own rows ------------------------------------------------------------------
+    const float* biasv = vec + VEC_BIAS + q * N;
+    bool bad = false;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int i = 4 * s + g;
+        const bool valid = (s < 6) || !pad6;
+        const int icol = valid ? i : 0;
+        const float mdq_i = xq[icol];
+        float uu = 0.f;
+#pragma unroll
+        for (int d = 0; d < NDEV; ++d) {
+            const int brA_d = qbcast_i(brA_own, d);
+            const float kv_d = qbcast(kv_own, d);
+            if (brA_d && (p.dev[d].joint_mask & (1u << i))) uu = -kv_d * mdq_i;
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < K; ++r) acc = fmaf(jrow_ptr(ring, jtail, r >> 2, q, r & 3)[icol], t[r], acc);
+        uu -= acc;
+        if (p.cfgflags & IRLOSC_USE_G) uu += biasv[icol];
+        uu -= kvn * mdq_i;
+        if (valid) {
+            p.u[(size_t)b * N + i] = uu;
+            bad = bad || !t_finite(uu);
+        }
+    }
+    flags |= bad ? IRLOSC_FLAG_NONFINITE : 0u;
+    flags = grp::qor(flags);
+    if (g == 0) {
+        if (!plain) {
+            flags |= IRLOSC_FLAG_EIGEN_PATH;
+            const int pos = atomicAdd(workcount, 1);
+            worklist[pos] = b;
+        }
+        p.flags[b] = flags;
+    }
+}
+
+inline bool group_kernel_supports(int dtype, int n, int k, int ndev) {
+    return dtype == IRLOSC_F32 && n == 25 && ((k == 13 && ndev == 3) || (k == 12 && ndev == 2));
+}
+
+template <typename T>
+int launch_group(const KParams<T>& p, int32_t* worklist, int32_t* workcount, hipStream_t st);
+
+template <>
+inline int launch_group<double>(const KParams<double>&, int32_t*, int32_t*, hipStream_t) {
+    return (int)hipErrorNotSupported;
+}
+
+template <>
+inline int launch_group<float>(const KParams<float>& p, int32_t* worklist, int32_t* workcount, hipStream_t st) {
+    const int tiles = p.B / grp::TILE;
+    const int rem = p.B - tiles * grp::TILE;
+    hipError_t e = hipMemsetAsync(workcount, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) return (int)e;
+    if (tiles > 0) {
+        if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_group_kernel_f32<13, 3>), dim3(tiles), dim3(64), 0, st, p, worklist, workcount);
+        else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_group_kernel_f32<12, 2>), dim3(tiles), dim3(64), 0, st, p, worklist, workcount);
+        else return (int)hipErrorNotSupported;
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    const size_t smem = generic_smem_bytes<float>(p.n, p.k, p.ndev);
+    if (rem > 0) {   // ragged tail (< 16 instances): generic kernel on the last instances
+        KParams<float> pt = p;
+        pt.index = nullptr;
+        pt.b0 = tiles * grp::TILE;
+        hipLaunchKernelGGL(osc_generic_kernel<float>, dim3(rem), dim3(64), smem, st, pt);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    if (tiles > 0) {
+        // worklist pass: grid sized for the worst case is wasteful, so launch a fixed grid that strides
+        KParams<float> pw = p;
+        pw.index = worklist;
+        pw.index_count = workcount;
+        pw.b0 = 0;
+        const int grid = tiles * grp::TILE < 8192 ? tiles * grp::TILE : 8192;
+        hipLaunchKernelGGL(osc_generic_kernel<float>, dim3(grid), dim3(64), smem, st, pw);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+}  // namespace irlosc
