@@ -34,8 +34,10 @@ struct irlosc_ctx {
     void* dgains = nullptr;   // [nb][ndev][12] in dtype
     void* dnullkv = nullptr;  // [nb]
     int gains_nb = 0;
-    int32_t* dworklist = nullptr;  // [max_batch] instance ids routed to the generic kernel
-    int32_t* dworkcount = nullptr; // [1]
+    int32_t* dworklist = nullptr;   // [max_batch] instances flagged by the group kernel's first stage
+    int32_t* dworklist2 = nullptr;  // [max_batch] instances its second stage hands to the generic kernel
+    int32_t* dworkcount = nullptr;  // [2]
+    float* dside = nullptr;         // [104][max_batch] A and w of flagged instances
     int kernel = IRLOSC_KERNEL_GENERIC;
     std::string kernel_name;
     std::string err;
@@ -113,6 +115,8 @@ static void free_all(irlosc_ctx* c) {
     if (c->dgains) (void)hipFree(c->dgains);
     if (c->dnullkv) (void)hipFree(c->dnullkv);
     if (c->dworklist) (void)hipFree(c->dworklist);
+    if (c->dworklist2) (void)hipFree(c->dworklist2);
+    if (c->dside) (void)hipFree(c->dside);
     if (c->dworkcount) (void)hipFree(c->dworkcount);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -151,7 +155,9 @@ static int create_impl(irlosc_ctx* c) {
     HIPCHK(nullptr, hipMalloc(&c->dgains, B * nd * IRLOSC_GAIN_WORDS * e));
     HIPCHK(nullptr, hipMalloc(&c->dnullkv, B * e));
     HIPCHK(nullptr, hipMalloc((void**)&c->dworklist, B * sizeof(int32_t)));
-    HIPCHK(nullptr, hipMalloc((void**)&c->dworkcount, sizeof(int32_t)));
+    HIPCHK(nullptr, hipMalloc((void**)&c->dworklist2, B * sizeof(int32_t)));
+    HIPCHK(nullptr, hipMalloc((void**)&c->dworkcount, 2 * sizeof(int32_t)));
+    if (c->kernel == IRLOSC_KERNEL_GROUP) HIPCHK(nullptr, hipMalloc((void**)&c->dside, B * 104 * sizeof(float)));
     HIPCHK(nullptr, hipMemsetAsync(c->dflags, 0, B * sizeof(uint32_t), c->stream));
     HIPCHK(nullptr, hipStreamSynchronize(c->stream));
     return IRLOSC_OK;
@@ -314,7 +320,8 @@ static int launch_t(irlosc_ctx* c, int B, const void* M, const void* J, const vo
     fill_params<T>(c, p, B, M, J, dq, bias, ee, tgt, tvel, wrench, u, flags);
 #ifndef IRLOSC_NO_GROUP_KERNEL
     if (c->kernel == IRLOSC_KERNEL_GROUP) {
-        int rc = launch_group<T>(p, c->dworklist, c->dworkcount, st);
+        GroupScratch gs{c->dworklist, c->dworklist2, c->dworkcount, c->dside, c->cfg.max_batch};
+        int rc = launch_group<T>(p, gs, st);
         if (rc) return fail(c, IRLOSC_ERR_HIP, "group kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         return IRLOSC_OK;
     }

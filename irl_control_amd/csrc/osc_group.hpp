@@ -84,42 +84,80 @@ __device__ __forceinline__ void wait_lgkm0() {
     asm volatile("" ::: "memory");
 }
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
+// ---- LDS-DMA issue (global_load_lds_*), hand-counted -----------------------------------------------
+// Issued through inline asm on purpose: hipcc treats the builtin form as a store to LDS that may
+// alias every later ds_read and drains it with s_waitcnt vmcnt(0), which would serialise the ring.
+// In asm the compiler neither counts nor waits for these loads; the kernel's own wait_vm<N>() calls
+// are the only synchronisation (guide §5.7: M0 written in the same statement, s_nop 0 before use).
+// Address form: SGPR-pair base (wave-uniform) + 32-bit VGPR byte offset.  LDS destination:
+// M0 + lane * size, M0 advanced by `step` bytes per instruction.
+#define IRLOSC_GLDS7(OP, STEP)                                                                         \
+    asm volatile("s_mov_b32 %[keep], m0\n\t"                                                            \
+                 "s_mov_b32 m0, %[lds]\n\t"                                                             \
+                 "s_nop 0\n\t" OP " %[o0], %[base]\n\t"                                                \
+                 "s_add_u32 m0, m0, " STEP "\n\ts_nop 0\n\t" OP " %[o1], %[base]\n\t"                  \
+                 "s_add_u32 m0, m0, " STEP "\n\ts_nop 0\n\t" OP " %[o2], %[base]\n\t"                  \
+                 "s_add_u32 m0, m0, " STEP "\n\ts_nop 0\n\t" OP " %[o3], %[base]\n\t"                  \
+                 "s_add_u32 m0, m0, " STEP "\n\ts_nop 0\n\t" OP " %[o4], %[base]\n\t"                  \
+                 "s_add_u32 m0, m0, " STEP "\n\ts_nop 0\n\t" OP " %[o5], %[base]\n\t"                  \
+                 "s_add_u32 m0, m0, " STEP "\n\ts_nop 0\n\t" OP " %[o6], %[base]\n\t"                  \
+                 "s_mov_b32 m0, %[keep]"                                                                \
+                 : [keep] "=&s"(keep)                                                                   \
+                 : [o0] "v"(o[0]), [o1] "v"(o[1]), [o2] "v"(o[2]), [o3] "v"(o[3]), [o4] "v"(o[4]),      \
+                   [o5] "v"(o[5]), [o6] "v"(o[6]), [base] "s"(base), [lds] "s"(lds)                     \
+                 : "memory", "scc")
+
+__device__ __forceinline__ uint32_t lds_addr(const float* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+}
 
 // DMA a 4-row chunk (100 floats = 25 x 16 B per instance, 16 instances): 7 wave instructions.
-// src = first float of (tile instance 0, row0); stride = floats between instances.
+// src = first float of (tile instance 0, row0), wave-uniform; stride = floats between instances.
 __device__ __forceinline__ void dma_rows4(const float* src, int stride, float* buf, int lane) {
+    uint32_t o[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
         int x = j * 64 + lane;               // 16-byte piece index, instance-major (25 per instance)
         x = x > 399 ? 399 : x;
         int inst = (x * 5243) >> 17;         // x / 25 for x < 2^12
         int pc = x - inst * 25;
-        const float* g = src + inst * stride + pc * 4;
-        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(buf + j * 256), 16, 0, 0);
+        o[j] = (uint32_t)(inst * stride + pc * 4) * 4u;
     }
+    const float* base = src;
+    uint32_t lds = lds_addr(buf), keep;
+    IRLOSC_GLDS7("global_load_lds_dwordx4", "0x400");
 }
 // DMA a single-row chunk (25 floats per instance): 7 wave instructions of 4 B per lane.
 __device__ __forceinline__ void dma_rows1(const float* src, int stride, float* buf, int lane) {
+    uint32_t o[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
         int x = j * 64 + lane;
         x = x > 399 ? 399 : x;
         int inst = (x * 5243) >> 17;
         int e = x - inst * 25;
-        const float* g = src + inst * stride + e;
-        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(buf + j * 64), 4, 0, 0);
+        o[j] = (uint32_t)(inst * stride + e) * 4u;
     }
+    const float* base = src;
+    uint32_t lds = lds_addr(buf), keep;
+    IRLOSC_GLDS7("global_load_lds_dword", "0x100");
 }
 // DMA a contiguous block of `pieces` 16-byte pieces (pieces <= 128): 2 wave instructions.
 __device__ __forceinline__ void dma_linear2(const float* src, int pieces, float* buf, int lane) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        int x = j * 64 + lane;
-        x = x >= pieces ? pieces - 1 : x;
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + x * 4), (lptr_t)(buf + j * 256), 16, 0, 0);
-    }
+    int x0 = lane, x1 = 64 + lane;
+    x0 = x0 >= pieces ? pieces - 1 : x0;
+    x1 = x1 >= pieces ? pieces - 1 : x1;
+    const uint32_t o0 = (uint32_t)x0 * 16u, o1 = (uint32_t)x1 * 16u;
+    const float* base = src;
+    uint32_t lds = lds_addr(buf), keep;
+    asm volatile("s_mov_b32 %[keep], m0\n\t"
+                 "s_mov_b32 m0, %[lds]\n\t"
+                 "s_nop 0\n\tglobal_load_lds_dwordx4 %[o0], %[base]\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o1], %[base]\n\t"
+                 "s_mov_b32 m0, %[keep]"
+                 : [keep] "=&s"(keep)
+                 : [o0] "v"(o0), [o1] "v"(o1), [base] "s"(base), [lds] "s"(lds)
+                 : "memory", "scc");
 }
 
 // Row rr of J chunk jc for quad q.  Chunks 0,1,2 (4 rows, stride 100) sit in ring slots 1,2,0;
@@ -134,7 +172,8 @@ __device__ __forceinline__ const float* jrow_ptr(const float* ring, const float*
 // One wave = 16 instances.  K = stacked task rows, NDEV = target devices (<= 4, one quad lane each).
 template <int K, int NDEV>
 __global__ __launch_bounds__(64, 1) void osc_group_kernel_f32(const KParams<float> p, int32_t* __restrict__ worklist,
-                                                             int32_t* __restrict__ workcount) {
+                                                             int32_t* __restrict__ workcount,
+                                                             float* __restrict__ side, int side_cap) {
     using namespace grp;
     constexpr int NCHM = 7;                                   // M chunks: 6 x 4 rows + 1 row
     constexpr int NCHJ = (K + 3) / 4;                         // J chunks of 4 rows; the last may be shorter
@@ -286,20 +325,6 @@ __global__ __launch_bounds__(64, 1) void osc_group_kernel_f32(const KParams<floa
         }
     }
 
-    // ---------------- A = Y^T Y (lower), replicated in the quad ---------------------------------------------------
-    float A[K][K];
-#pragma unroll
-    for (int r = 0; r < K; ++r) {
-#pragma unroll
-        for (int s2 = 0; s2 <= r; ++s2) {
-            float a = 0.f;
-#pragma unroll
-            for (int s = 0; s < S; ++s) a = fmaf(Yo[r][s], Yo[s2][s], a);
-            A[r][s2] = qsum(a);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
     // ---------------- task-space signal: lane g of the quad handles device g ---------------------------------------
     float kvn = 0.f;
     if (p.cfgflags & IRLOSC_NULLSPACE) kvn = p.null_kv[p.gains_per_instance ? b : 0];
@@ -358,6 +383,34 @@ __global__ __launch_bounds__(64, 1) void osc_group_kernel_f32(const KParams<floa
     float w[K];
 #pragma unroll
     for (int r = 0; r < K; ++r) w[r] = wls[r] - kvn * xq[25 + r];
+
+    // ---------------- A = Y^T Y (lower), replicated in the quad ---------------------------------------------------
+    float A[K][K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+#pragma unroll
+        for (int s2 = 0; s2 <= r; ++s2) {
+            float a = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) a = fmaf(Yo[r][s], Yo[s2][s], a);
+            A[r][s2] = qsum(a);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // Park A in LDS (the ee/tgt/tvel/wrench regions are dead by now): lane g stores entries e = g mod 4.
+    // Read back only by flagged quads, which hand A and w to the second stage.
+    float* aq = vec + VEC_EE + q * 96;
+    {
+        int e = 0;
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+#pragma unroll
+            for (int c2 = 0; c2 <= r; ++c2) {
+                if ((e & 3) == g) aq[e] = A[r][c2];
+                ++e;
+            }
+        }
+    }
 
     // ---------------- k x k (per lane): Cholesky of A in place, cond certificate, t = A^-1 w ------------------
     float nA2 = 0.f;
@@ -446,7 +499,7 @@ __global__ __launch_bounds__(64, 1) void osc_group_kernel_f32(const KParams<floa
         float acc = 0.f;
 #pragma unroll
         for (int r = 0; r < K; ++r) acc = fmaf(jrow_ptr(ring, jtail, r >> 2, q, r & 3)[icol], t[r], acc);
-        uu -= acc;
+        uu -= plain ? acc : 0.f;             // flagged instances keep u_base; stage 2 subtracts J^T t
         if (p.cfgflags & IRLOSC_USE_G) uu += biasv[icol];
         uu -= kvn * mdq_i;
         if (valid) {
@@ -456,13 +509,256 @@ __global__ __launch_bounds__(64, 1) void osc_group_kernel_f32(const KParams<floa
     }
     flags |= bad ? IRLOSC_FLAG_NONFINITE : 0u;
     flags = grp::qor(flags);
-    if (g == 0) {
-        if (!plain) {
-            flags |= IRLOSC_FLAG_EIGEN_PATH;
-            const int pos = atomicAdd(workcount, 1);
+    if (!plain) {
+        flags |= IRLOSC_FLAG_EIGEN_PATH;
+        int pos = 0;
+        if (g == 0) {
+            pos = atomicAdd(workcount, 1);
             worklist[pos] = b;
         }
-        p.flags[b] = flags;
+        pos = qbcast_i(pos, 0);
+        __builtin_amdgcn_wave_barrier();
+        wait_lgkm0();
+        // side[e][pos]: A (K(K+1)/2 lower entries, row-major) then w (K)
+        constexpr int NA = K * (K + 1) / 2;
+        for (int e = g; e < NA; e += 4) side[(size_t)e * side_cap + pos] = aq[e];
+#pragma unroll
+        for (int r = 0; r < K; ++r)
+            if ((r & 3) == g) side[(size_t)(NA + r) * side_cap + pos] = w[r];
+    }
+    if (g == 0) p.flags[b] = flags;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Second stage for the group kernel: truncated pseudo-inverse solve t = pinv(A, rcond 1e-5) w for the
+// instances the first stage could not certify (osc.py:51-55 when |det A| < 1e-4 and cond(A) may exceed
+// 1e5), then u -= J^T t.  4 lanes per instance like stage 1 (k x k math replicated in the quad, the
+// J^T t update split by joint rows).
+//
+// Method (A = J M^-1 J^T is symmetric positive semi-definite, k <= 13):
+//   * factor A + sigma I = L L^T (sigma = 0, raised to ~2e-6 ||A||_F only if a pivot fails in fp32);
+//   * lambda_max by 12 power iterations through the factor (A x = L (L^T x) - sigma x);
+//   * the eigenpairs below the cut 1e-5 lambda_max one at a time by inverse iteration with
+//     deflation (at most 3; typically exactly one: a nearly rank-deficient Jacobian stack);
+//   * t = P (A + sigma I)^-1 P w with P the projector off those eigenvectors (one refinement step
+//     when sigma > 0), which equals sum over the kept eigenpairs of v v^T w / lambda.
+// Instances with more than 3 sub-threshold eigenvalues are handed to the generic kernel (Jacobi).
+template <int K>
+__global__ __launch_bounds__(64) void osc_group_stage2_f32(const KParams<float> p, const int32_t* __restrict__ worklist,
+                                                          const int32_t* __restrict__ workcount,
+                                                          const float* __restrict__ side, int side_cap,
+                                                          int32_t* __restrict__ worklist2, int32_t* __restrict__ workcount2) {
+    using namespace grp;
+    constexpr int NA = K * (K + 1) / 2;
+    const int lane = threadIdx.x, g = lane & 3, q = lane >> 2;
+    const int count = *workcount;
+    const int ntile = (count + TILE - 1) / TILE;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int pos = tile * TILE + q;
+        const bool live = pos < count;
+        const int posc = live ? pos : count - 1;
+        const int b = worklist[posc];
+        float w[K], L[K][K], Ld[K], Li[K];     // factor: strictly-lower L, diagonal Ld, inverse diagonal Li
+#pragma unroll
+        for (int r = 0; r < K; ++r) w[r] = side[(size_t)(NA + r) * side_cap + posc];
+        float sigma = 0.f, hi = 0.f, det = 1.f;
+        bool ok = false;
+        for (int attempt = 0; attempt < 4; ++attempt) {
+            float nA2 = 0.f;
+            int e = 0;
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+#pragma unroll
+                for (int c = 0; c <= r; ++c) {
+                    const float a = side[(size_t)e * side_cap + posc];
+                    ++e;
+                    L[r][c] = a;
+                    nA2 = fmaf(c < r ? 2.f * a : a, a, nA2);
+                }
+            }
+            hi = sqrtf(nA2);
+            bool okk = true;
+            float dd = 1.f;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                float d = L[j][j] + sigma;
+#pragma unroll
+                for (int c = 0; c < j; ++c) d = fmaf(-L[j][c], L[j][c], d);
+                const bool npd = !(d > 1e-7f * hi * 1e-1f);
+                okk = okk && !npd;
+                d = npd ? hi : d;
+                dd *= d;
+                const float di = __builtin_amdgcn_rsqf(d);
+                Li[j] = di;
+                Ld[j] = d * di;
+#pragma unroll
+                for (int i = j + 1; i < K; ++i) {
+                    float a = L[i][j];
+#pragma unroll
+                    for (int c = 0; c < j; ++c) a = fmaf(-L[i][c], L[j][c], a);
+                    L[i][j] = a * di;
+                }
+            }
+            if (attempt == 0) det = okk ? dd : 0.f;
+            ok = okk;
+            if (!__any(!okk)) break;
+            if (!okk) sigma = (sigma == 0.f) ? 2e-6f * hi : sigma * 8.f;
+        }
+        // y = (A + sigma I)^-1 x, in place
+        auto solve = [&](float (&x)[K]) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                float s2 = x[i];
+#pragma unroll
+                for (int c = 0; c < i; ++c) s2 = fmaf(-L[i][c], x[c], s2);
+                x[i] = s2 * Li[i];
+            }
+#pragma unroll
+            for (int i = K - 1; i >= 0; --i) {
+                float s2 = x[i];
+#pragma unroll
+                for (int c = i + 1; c < K; ++c) s2 = fmaf(-L[c][i], x[c], s2);
+                x[i] = s2 * Li[i];
+            }
+        };
+        // y = A x = L (L^T x) - sigma x
+        auto amul = [&](const float (&x)[K], float (&y)[K]) {
+            float z[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                float s2 = Ld[j] * x[j];
+#pragma unroll
+                for (int i = j + 1; i < K; ++i) s2 = fmaf(L[i][j], x[i], s2);
+                z[j] = s2;
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                float s2 = Ld[i] * z[i];
+#pragma unroll
+                for (int c = 0; c < i; ++c) s2 = fmaf(L[i][c], z[c], s2);
+                y[i] = s2 - sigma * x[i];
+            }
+        };
+        auto dot = [&](const float (&x)[K], const float (&y)[K]) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < K; ++i) s2 = fmaf(x[i], y[i], s2);
+            return s2;
+        };
+        // lambda_max: power iteration (start vector with all components, not an eigenvector of anything special)
+        float x[K], y[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) x[i] = 0.2f + 0.05f * (float)((i * 7) % 5);
+        float lmax = hi;
+        for (int it = 0; it < 12; ++it) {
+            amul(x, y);
+            const float n2 = dot(y, y);
+            const float rn = __builtin_amdgcn_rsqf(n2 > 0.f ? n2 : 1.f);
+#pragma unroll
+            for (int i = 0; i < K; ++i) x[i] = y[i] * rn;
+        }
+        amul(x, y);
+        lmax = dot(x, y);
+        lmax = (lmax > 0.f && lmax <= hi * 1.0001f) ? lmax : hi;
+        const bool trunc = !(fabsf(det) >= 1e-4f);
+        const float cutoff = 1e-5f * lmax;
+        // sub-threshold eigenpairs by deflated inverse iteration
+        float v[3][K];
+#pragma unroll
+        for (int s0 = 0; s0 < 3; ++s0) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) v[s0][i] = 0.f;     // unused slots must be exact zeros (0 * NaN = NaN)
+        }
+        int m = 0;
+        bool active = trunc && ok;
+        bool giveup = !ok;
+#pragma unroll
+        for (int slot = 0; slot < 4; ++slot) {
+            if (!__any(active)) break;
+#pragma unroll
+            for (int i = 0; i < K; ++i) x[i] = 0.3f + 0.1f * (float)(((i + 3 * slot) * 5) % 7) - 0.05f * (float)slot;
+            float lam = 0.f;
+            for (int it = 0; it < 6; ++it) {
+#pragma unroll
+                for (int s0 = 0; s0 < 3; ++s0) {
+                    if (s0 < slot) {
+                        const float pr = (s0 < m) ? dot(v[s0], x) : 0.f;
+#pragma unroll
+                        for (int i = 0; i < K; ++i) x[i] = fmaf(-pr, v[s0][i], x[i]);
+                    }
+                }
+                solve(x);
+                const float n2 = dot(x, x);
+                const float rn = __builtin_amdgcn_rsqf(n2 > 0.f ? n2 : 1.f);
+                lam = rn - sigma;                          // 1/||(A+sigma)^-1 x|| -> lambda + sigma
+#pragma unroll
+                for (int i = 0; i < K; ++i) x[i] *= rn;
+            }
+            // final clean-up of the accepted vector against the earlier ones
+            const bool below = active && (lam <= cutoff);
+            if (slot < 3) {
+#pragma unroll
+                for (int i = 0; i < K; ++i) v[slot][i] = below ? x[i] : 0.f;
+                m += below ? 1 : 0;
+            } else {
+                giveup = giveup || below;              // a 4th sub-threshold eigenvalue: not handled here
+            }
+            active = below;
+        }
+        // t = P (A + sigma I)^-1 P w  (+ one refinement step against A when sigma > 0)
+        float t[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) t[i] = w[i];
+        auto project = [&](float (&z)[K]) {
+#pragma unroll
+            for (int s0 = 0; s0 < 3; ++s0) {
+                const float pr = (s0 < m) ? dot(v[s0], z) : 0.f;
+#pragma unroll
+                for (int i = 0; i < K; ++i) z[i] = fmaf(-pr, v[s0][i], z[i]);
+            }
+        };
+        project(t);
+        float wp[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) wp[i] = t[i];
+        solve(t);
+        project(t);
+        if (__any(sigma > 0.f)) {
+            for (int ref = 0; ref < 2; ++ref) {
+                amul(t, y);
+#pragma unroll
+                for (int i = 0; i < K; ++i) y[i] = wp[i] - y[i];
+                project(y);
+                solve(y);
+                project(y);
+#pragma unroll
+                for (int i = 0; i < K; ++i) t[i] += (sigma > 0.f) ? y[i] : 0.f;
+            }
+        }
+        // u -= J^T t on the own joint rows; J straight from global (L2-resident: it was just streamed)
+        uint32_t fl = (m > 0 ? IRLOSC_FLAG_TRUNCATED : 0u);
+        bool bad = false;
+        if (live) {
+            const float* Jb = p.J + (size_t)b * K * N;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int i = 4 * s + g;
+                if (i < N) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int r = 0; r < K; ++r) acc = fmaf(Jb[r * N + i], t[r], acc);
+                    const float uu = p.u[(size_t)b * N + i] - acc;
+                    p.u[(size_t)b * N + i] = uu;
+                    bad = bad || !t_finite(uu);
+                }
+            }
+        }
+        fl |= bad ? IRLOSC_FLAG_NONFINITE : 0u;
+        fl = qor(fl);
+        if (live && g == 0) {
+            p.flags[b] |= fl;
+            if (giveup) worklist2[atomicAdd(workcount2, 1)] = b;
+        }
     }
 }
 
@@ -470,24 +766,40 @@ inline bool group_kernel_supports(int dtype, int n, int k, int ndev) {
     return dtype == IRLOSC_F32 && n == 25 && ((k == 13 && ndev == 3) || (k == 12 && ndev == 2));
 }
 
+// Device scratch owned by the context for the two-stage group path.
+struct GroupScratch {
+    int32_t* worklist;    // [max_batch] instances flagged by stage 1
+    int32_t* worklist2;   // [max_batch] instances stage 2 hands to the generic kernel
+    int32_t* counts;      // [2] lengths of the two lists
+    float* side;          // [(K(K+1)/2 + K)][side_cap]: A and w of flagged instances
+    int side_cap;
+};
+
 template <typename T>
-int launch_group(const KParams<T>& p, int32_t* worklist, int32_t* workcount, hipStream_t st);
+int launch_group(const KParams<T>& p, const GroupScratch& gs, hipStream_t st);
 
 template <>
-inline int launch_group<double>(const KParams<double>&, int32_t*, int32_t*, hipStream_t) {
+inline int launch_group<double>(const KParams<double>&, const GroupScratch&, hipStream_t) {
     return (int)hipErrorNotSupported;
 }
 
 template <>
-inline int launch_group<float>(const KParams<float>& p, int32_t* worklist, int32_t* workcount, hipStream_t st) {
+inline int launch_group<float>(const KParams<float>& p, const GroupScratch& gs, hipStream_t st) {
     const int tiles = p.B / grp::TILE;
     const int rem = p.B - tiles * grp::TILE;
-    hipError_t e = hipMemsetAsync(workcount, 0, sizeof(int32_t), st);
+    hipError_t e = hipMemsetAsync(gs.counts, 0, 2 * sizeof(int32_t), st);
     if (e != hipSuccess) return (int)e;
+    int32_t* wc1 = gs.counts;
+    int32_t* wc2 = gs.counts + 1;
     if (tiles > 0) {
-        if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_group_kernel_f32<13, 3>), dim3(tiles), dim3(64), 0, st, p, worklist, workcount);
-        else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_group_kernel_f32<12, 2>), dim3(tiles), dim3(64), 0, st, p, worklist, workcount);
-        else return (int)hipErrorNotSupported;
+        const int g2 = tiles < 1024 ? tiles : 1024;
+        if (p.k == 13 && p.ndev == 3) {
+            hipLaunchKernelGGL((osc_group_kernel_f32<13, 3>), dim3(tiles), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap);
+            hipLaunchKernelGGL((osc_group_stage2_f32<13>), dim3(g2), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, gs.worklist2, wc2);
+        } else if (p.k == 12 && p.ndev == 2) {
+            hipLaunchKernelGGL((osc_group_kernel_f32<12, 2>), dim3(tiles), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap);
+            hipLaunchKernelGGL((osc_group_stage2_f32<12>), dim3(g2), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, gs.worklist2, wc2);
+        } else return (int)hipErrorNotSupported;
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
@@ -501,13 +813,12 @@ inline int launch_group<float>(const KParams<float>& p, int32_t* worklist, int32
         if (e != hipSuccess) return (int)e;
     }
     if (tiles > 0) {
-        // worklist pass: grid sized for the worst case is wasteful, so launch a fixed grid that strides
+        // instances stage 2 gave up on (> 3 sub-threshold eigenvalues): generic kernel, grid-strided
         KParams<float> pw = p;
-        pw.index = worklist;
-        pw.index_count = workcount;
+        pw.index = gs.worklist2;
+        pw.index_count = wc2;
         pw.b0 = 0;
-        const int grid = tiles * grp::TILE < 8192 ? tiles * grp::TILE : 8192;
-        hipLaunchKernelGGL(osc_generic_kernel<float>, dim3(grid), dim3(64), smem, st, pw);
+        hipLaunchKernelGGL(osc_generic_kernel<float>, dim3(256), dim3(64), smem, st, pw);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
