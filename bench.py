@@ -84,7 +84,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from irl_control_amd import BatchedOSC, synth
+    from irl_control_amd import BatchedOSC, sharding, synth
 
     def measure(dtype_name, steps, warmup, with_check):
         dt = np.float32 if dtype_name == "f32" else np.float64
@@ -114,13 +114,14 @@ def main():
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        el = torch.tensor([elapsed, ms_kernel], device="cuda", dtype=torch.float64)
+        total_steps, elapsed, rate = sharding.reduce_throughput(B * steps, elapsed, device="cuda")
         if world > 1:
-            dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed, ms_kernel = float(el[0]), float(el[1])
+            mk = torch.tensor([ms_kernel], device="cuda", dtype=torch.float64)
+            dist.all_reduce(mk, op=dist.ReduceOp.MAX)
+            ms_kernel = float(mk[0])
         bytes_launch = algorithmic_bytes(lay.n, lay.k, lay.ndev, lay.admittance, esz) * B
         achieved = bytes_launch / (ms_kernel * 1e-3) / 1e9
-        res = dict(value=world * B * steps / elapsed, ms_per_step=elapsed / steps * 1e3, kernel=osc.kernel_name,
+        res = dict(value=rate, ms_per_step=elapsed / steps * 1e3, kernel=osc.kernel_name,
                    roofline=dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                                  frac=achieved / HBM_PEAK_GBS, traffic=None,
                                  kernel_ms=ms_kernel, algorithmic_bytes_per_launch=bytes_launch))
