@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -38,6 +39,7 @@ struct irlosc_ctx {
     int32_t* dworklist2 = nullptr;  // [max_batch] instances its second stage hands to the generic kernel
     int32_t* dworkcount = nullptr;  // [2]
     float* dside = nullptr;         // [104][max_batch] A and w of flagged instances
+    unsigned long long* ddbg = nullptr;  // IRLOSC_PHASE_TIMING=1: 8 cycle stamps per stage-1 wave
     int kernel = IRLOSC_KERNEL_GENERIC;
     std::string kernel_name;
     std::string err;
@@ -117,6 +119,7 @@ static void free_all(irlosc_ctx* c) {
     if (c->dworklist) (void)hipFree(c->dworklist);
     if (c->dworklist2) (void)hipFree(c->dworklist2);
     if (c->dside) (void)hipFree(c->dside);
+    if (c->ddbg) (void)hipFree(c->ddbg);
     if (c->dworkcount) (void)hipFree(c->dworkcount);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -154,10 +157,12 @@ static int create_impl(irlosc_ctx* c) {
     HIPCHK(nullptr, hipMalloc((void**)&c->dflags, B * sizeof(uint32_t)));
     HIPCHK(nullptr, hipMalloc(&c->dgains, B * nd * IRLOSC_GAIN_WORDS * e));
     HIPCHK(nullptr, hipMalloc(&c->dnullkv, B * e));
-    HIPCHK(nullptr, hipMalloc((void**)&c->dworklist, B * sizeof(int32_t)));
+    HIPCHK(nullptr, hipMalloc((void**)&c->dworklist, (B + 16 * 64) * sizeof(int32_t)));
     HIPCHK(nullptr, hipMalloc((void**)&c->dworklist2, B * sizeof(int32_t)));
-    HIPCHK(nullptr, hipMalloc((void**)&c->dworkcount, 2 * sizeof(int32_t)));
-    if (c->kernel == IRLOSC_KERNEL_GROUP) HIPCHK(nullptr, hipMalloc((void**)&c->dside, B * 104 * sizeof(float)));
+    HIPCHK(nullptr, hipMalloc((void**)&c->dworkcount, 64 * sizeof(int32_t)));
+    if (c->kernel == IRLOSC_KERNEL_GROUP) HIPCHK(nullptr, hipMalloc((void**)&c->dside, (B + 16 * 64) * 104 * sizeof(float)));
+    if (c->kernel == IRLOSC_KERNEL_GROUP && getenv("IRLOSC_PHASE_TIMING"))
+        HIPCHK(nullptr, hipMalloc((void**)&c->ddbg, (B / 16 + 1) * 8 * sizeof(unsigned long long)));
     HIPCHK(nullptr, hipMemsetAsync(c->dflags, 0, B * sizeof(uint32_t), c->stream));
     HIPCHK(nullptr, hipStreamSynchronize(c->stream));
     return IRLOSC_OK;
@@ -298,6 +303,7 @@ static void fill_params(const irlosc_ctx* c, KParams<T>& p, int B, const void* M
     p.u = (T*)u; p.flags = flags;
     p.gains = (const T*)c->dgains; p.null_kv = (const T*)c->dnullkv;
     p.index = nullptr;
+    p.dbg = c->ddbg;
     p.gains_per_instance = c->gains_nb > 1;
     p.B = B; p.n = c->cfg.n; p.k = c->k; p.ndev = c->cfg.ndev; p.cfgflags = c->cfg.flags;
     int row = 0;
@@ -320,7 +326,7 @@ static int launch_t(irlosc_ctx* c, int B, const void* M, const void* J, const vo
     fill_params<T>(c, p, B, M, J, dq, bias, ee, tgt, tvel, wrench, u, flags);
 #ifndef IRLOSC_NO_GROUP_KERNEL
     if (c->kernel == IRLOSC_KERNEL_GROUP) {
-        GroupScratch gs{c->dworklist, c->dworklist2, c->dworkcount, c->dside, c->cfg.max_batch};
+        GroupScratch gs{c->dworklist, c->dworklist2, c->dworkcount, c->dside, c->cfg.max_batch + 16 * 64};
         int rc = launch_group<T>(p, gs, st);
         if (rc) return fail(c, IRLOSC_ERR_HIP, "group kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         return IRLOSC_OK;
@@ -356,6 +362,18 @@ extern "C" int irlosc_download(irlosc_ctx* c, int32_t B, void* u_host, uint32_t*
     if (u_host && B) HIPCHK(c, hipMemcpyAsync(u_host, c->du, (size_t)B * c->cfg.n * c->esz, hipMemcpyDeviceToHost, c->stream));
     if (flags_host && B) HIPCHK(c, hipMemcpyAsync(flags_host, c->dflags, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->ddbg && B >= 16) {   // debug: mean cycles per stage-1 phase over all waves
+        const int tiles = B / 16;
+        std::vector<unsigned long long> h((size_t)tiles * 8);
+        HIPCHK(c, hipMemcpy(h.data(), c->ddbg, h.size() * 8, hipMemcpyDeviceToHost));
+        static const char* nm[7] = {"vec-wait", "M-stream+Cholesky", "J+fwd-subst", "task-error", "A=YtY", "kxk", "torques+store"};
+        double acc[7] = {0};
+        for (int t = 0; t < tiles; ++t) for (int i = 0; i < 7; ++i) acc[i] += (double)(h[(size_t)t * 8 + i + 1] - h[(size_t)t * 8 + i]);
+        double tot = 0; for (int i = 0; i < 7; ++i) tot += acc[i];
+        fprintf(stderr, "[irlosc phase timing] %d waves, mean cycles/wave %.0f:", tiles, tot / tiles);
+        for (int i = 0; i < 7; ++i) fprintf(stderr, " %s=%.0f", nm[i], acc[i] / tiles);
+        fprintf(stderr, "\n");
+    }
     return IRLOSC_OK;
 }
 

@@ -37,6 +37,7 @@ struct KParams {
     const int32_t* index;        // optional worklist of instance ids (nullptr = identity)
     const int32_t* index_count;  // device-side length of the worklist (grid-strided) when index != nullptr
     int32_t b0;                  // first instance handled by block 0 when index == nullptr
+    unsigned long long* dbg;     // phase-timing buffer (IRLOSC_PHASE_TIMING=1 debug runs), else nullptr
     int32_t gains_per_instance;
     int32_t B, n, k, ndev;
     uint32_t cfgflags;

@@ -33,15 +33,20 @@ namespace irlosc {
 
 namespace grp {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 constexpr int N = 25;        // joints
 constexpr int S = 7;         // row slots per lane (4 * 7 = 28 >= 25)
 constexpr int TILE = 16;     // instances per wave
 constexpr int BUF_FLOATS = 1792;   // 7 DMA instructions x 1 KiB
 constexpr int NBUF = 3;
+constexpr int NLISTS = 32;   // sharded worklists (counter l owns worklist[l * list_cap ...))
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+    // mov_dpp (no `old` operand): with all rows/banks enabled every lane has a valid source, and not
+    // materialising an `old` value saves a v_mov + the VALU->DPP wait state per broadcast
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 // broadcast lane g of each quad to the whole quad
 __device__ __forceinline__ float qbcast(float v, int g) {
@@ -60,15 +65,15 @@ __device__ __forceinline__ float qsum(float v) {
 }
 __device__ __forceinline__ int qbcast_i(int v, int g) {
     switch (g & 3) {
-        case 0: return __builtin_amdgcn_update_dpp(0, v, 0x00, 0xf, 0xf, false);
-        case 1: return __builtin_amdgcn_update_dpp(0, v, 0x55, 0xf, 0xf, false);
-        case 2: return __builtin_amdgcn_update_dpp(0, v, 0xAA, 0xf, 0xf, false);
-        default: return __builtin_amdgcn_update_dpp(0, v, 0xFF, 0xf, 0xf, false);
+        case 0: return __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true);
+        case 1: return __builtin_amdgcn_mov_dpp(v, 0x55, 0xf, 0xf, true);
+        case 2: return __builtin_amdgcn_mov_dpp(v, 0xAA, 0xf, 0xf, true);
+        default: return __builtin_amdgcn_mov_dpp(v, 0xFF, 0xf, 0xf, true);
     }
 }
 __device__ __forceinline__ uint32_t qor(uint32_t v) {
-    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
-    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);
     return v;
 }
 
@@ -173,7 +178,7 @@ __device__ __forceinline__ const float* jrow_ptr(const float* ring, const float*
 template <int K, int NDEV>
 __global__ __launch_bounds__(64, 1) void osc_group_kernel_f32(const KParams<float> p, int32_t* __restrict__ worklist,
                                                              int32_t* __restrict__ workcount,
-                                                             float* __restrict__ side, int side_cap) {
+                                                             float* __restrict__ side, int side_cap, int list_cap) {
     using namespace grp;
     constexpr int NCHM = 7;                                   // M chunks: 6 x 4 rows + 1 row
     constexpr int NCHJ = (K + 3) / 4;                         // J chunks of 4 rows; the last may be shorter
@@ -193,6 +198,9 @@ __global__ __launch_bounds__(64, 1) void osc_group_kernel_f32(const KParams<floa
     const size_t t0 = (size_t)tile * TILE;
     const bool has_tv = p.tvel != nullptr;
     const bool has_wr = (p.cfgflags & IRLOSC_ADMITTANCE) && p.wrench != nullptr;
+    unsigned long long ts[8];
+#define IRLOSC_TS(i) ts[i] = p.dbg ? __builtin_readcyclecounter() : 0ull
+    IRLOSC_TS(0);
 
     // ---------------- prologue: vectors + first chunks in flight -----------------------------------
     // Issue order (7 DMA instructions per chunk):  vec(12) M0 M1 M2 | M3 | M4 | M5 | M6 [J3] | J0 | J1 | J2
@@ -214,28 +222,40 @@ __global__ __launch_bounds__(64, 1) void osc_group_kernel_f32(const KParams<floa
     dma_rows4(Mt + 8 * N, N * N, ring + 2 * BUF_FLOATS, lane);
 
     // ---------------- register state ----------------------------------------------------------------
-    float Ls[S][28];       // strictly-lower rows of L owned by this lane; upper/diagonal entries are 0
-    float DinvOwn[S];      // 1 / L[i][i] for the lane's own rows
-    float mdq[S];          // (M dq)[i] for own rows
-    float dqOwn[S];
-    float Yo[K][S];        // own rows of Y = L^-1 J^T
+    // Row slots 0..5 are kept as PAIRS (slots 2p, 2p+1 in one float2) so that the multiply-adds below
+    // are v_pk_fma_f32: a lone wave per SIMD issues one VALU op per quad-cycle, so halving the
+    // instruction count matters more than anything else.  Slot 6 (row 24, real only for g == 0) stays
+    // scalar: pairing it with an all-padding slot 7 cost ~60 registers and pushed L into AGPRs.
+    constexpr int P = 3;
+    v2f Lp[P][24];         // strictly-lower rows of L owned by this lane (slots 0..5); upper/diagonal = 0
+    float L6[24];          // row 24 (g == 0), zeros elsewhere
+    v2f DinvP[P];          // 1 / L[i][i] for the lane's own rows
+    float Dinv6 = 0.f;
+    v2f mdqP[P];           // (M dq)[i] for own rows
+    float mdq6 = 0.f;
+    v2f dqP[P];
+    float dq6;
+    v2f Yp[K][P];          // own rows of Y = L^-1 J^T
+    float Y6[K];
     uint32_t flags = 0;
 #pragma unroll
-    for (int s = 0; s < S; ++s) { DinvOwn[s] = 0.f; mdq[s] = 0.f; }
+    for (int pp = 0; pp < P; ++pp) { DinvP[pp] = v2f{0.f, 0.f}; mdqP[pp] = v2f{0.f, 0.f}; }
 
-    // own-column validity (row 4s+g < 25): only slot 6 of lanes g >= 1 is padding
-    const bool pad6 = g != 0;
+    const bool pad6 = g != 0;            // slot 6 is padding except on quad lane 0
     const int col6 = pad6 ? 0 : 24;      // safe in-range column for the masked slot
-    float* xq = vec + VEC_X + q * 48;    // per-quad exchange: [0..24] Mdq, [25..37] dx, [32+..] unused
+    float* xq = vec + VEC_X + q * 48;    // per-quad exchange: [0..24] Mdq, [25..37] dx
+
+    // read one 25-float row (quad q): slots 0..5 into 3 pairs, slot 6 into a scalar (padding -> 0)
+    auto load_row = [&](const float* row, v2f (&dst)[P], float& d6) {
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) dst[pp] = v2f{row[8 * pp + g], row[8 * pp + 4 + g]};
+        const float t6 = row[col6];
+        d6 = pad6 ? 0.f : t6;
+    };
 
     wait_vm<21>();                        // the 12 vector DMAs have landed (3 chunks = 21 still in flight)
-    {
-        const float* dqv = vec + VEC_DQ + q * N;
-#pragma unroll
-        for (int s = 0; s < S - 1; ++s) dqOwn[s] = dqv[4 * s + g];
-        const float t6 = dqv[col6];
-        dqOwn[6] = pad6 ? 0.f : t6;
-    }
+    IRLOSC_TS(1);
+    load_row(vec + VEC_DQ + q * N, dqP, dq6);
 
     // ---------------- stream M: Cholesky column by column -----------------------------------------------
 #pragma unroll
@@ -244,39 +264,65 @@ __global__ __launch_bounds__(64, 1) void osc_group_kernel_f32(const KParams<floa
         if (ch <= 3) wait_vm<14>(); else wait_vm<7 * (HASJ3 ? 3 : 2)>();
         const int R = ch < 6 ? 4 : 1;
         const int istride = R * N;
+        // all rows of the chunk are read up front (one LDS round trip per chunk instead of per column)
+        v2f mrow[4][P];
+        float mrow6[4], dqj[4];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            load_row(buf + q * istride + rr * N, mrow[rr], mrow6[rr]);
+            dqj[rr] = vec[VEC_DQ + q * N + ch * 4 + rr];
+        }
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
             const int j = ch * 4 + rr;
-            const int sj = j >> 2, gj = j & 3;
-            const float* row = buf + q * istride + rr * N;
-            float mrow[S];
+            const int sj = j >> 2, gj = j & 3, pj = sj >> 1;     // row j lives in slot sj of quad lane gj
+            const v2f dq2 = v2f{dqj[rr], dqj[rr]};
 #pragma unroll
-            for (int s = 0; s < S - 1; ++s) mrow[s] = row[4 * s + g];
-            const float m6 = row[col6];
-            mrow[6] = pad6 ? 0.f : m6;
-            const float dqj = vec[VEC_DQ + q * N + j];
+            for (int pp = 0; pp < P; ++pp) mdqP[pp] = __builtin_elementwise_fma(mrow[rr][pp], dq2, mdqP[pp]);   // M symmetric
+            mdq6 = fmaf(mrow6[rr], dqj[rr], mdq6);
+            // left-looking column j: acc = M[j][i] - sum_{c<j} L[i][c] L[j][c] for the rows i >= j
+            v2f acc[P];
+            float acc6 = mrow6[rr];
 #pragma unroll
-            for (int s = 0; s < S; ++s) mdq[s] = fmaf(mrow[s], dqj, mdq[s]);   // (M^T dq) = (M dq), M symmetric
-            // left-looking column j: acc[s] = M[j][i] - sum_{c<j} L[i][c] L[j][c]
-            float acc[S];
-#pragma unroll
-            for (int s = sj; s < S; ++s) acc[s] = mrow[s];
+            for (int pp = 0; pp < P; ++pp) acc[pp] = mrow[rr][pp];
 #pragma unroll
             for (int c = 0; c < j; ++c) {
-                const float lj = qbcast(Ls[sj][c], gj);
+                const float own = sj == 6 ? L6[c] : ((sj & 1) ? Lp[pj < P ? pj : 0][c].y : Lp[pj < P ? pj : 0][c].x);
+                const float ljs = -qbcast(own, gj);
+                const v2f lj = v2f{ljs, ljs};
 #pragma unroll
-                for (int s = sj; s < S; ++s) acc[s] = fmaf(-Ls[s][c], lj, acc[s]);
+                for (int pp = pj; pp < P; ++pp) acc[pp] = __builtin_elementwise_fma(Lp[pp][c], lj, acc[pp]);
+                acc6 = fmaf(L6[c], ljs, acc6);
+                // keep the scalar slot-6 chain in step with the packed chains: left alone, the scheduler
+                // sinks it to the end of the column and every broadcast value stays live (-> scratch)
+                asm volatile("" : "+v"(acc6), "+v"(acc[P - 1]));
             }
-            float d = qbcast(acc[sj], gj);
+            const float dsel = sj == 6 ? acc6 : ((sj & 1) ? acc[pj < P ? pj : 0].y : acc[pj < P ? pj : 0].x);
+            float d = qbcast(dsel, gj);
             const bool notpd = !(d > 0.f);
             flags |= notpd ? IRLOSC_FLAG_M_NOT_PD : 0u;
             const float dfix = (d == d && d != 0.f) ? fabsf(d) : 1.f;
             d = notpd ? dfix : d;
             const float dinv = __builtin_amdgcn_rsqf(d);
+            const v2f dinv2 = v2f{dinv, dinv};
+            const bool own_row = (g == gj);
+            const float below = (g > gj) ? 1.f : 0.f;
+            if (j < 24) {
 #pragma unroll
-            for (int s = sj + 1; s < S; ++s) Ls[s][j] = acc[s] * dinv;
-            Ls[sj][j] = (g > gj) ? acc[sj] * dinv : 0.f;
-            DinvOwn[sj] = (g == gj) ? dinv : DinvOwn[sj];
+                for (int pp = pj + 1; pp < P; ++pp) Lp[pp][j] = acc[pp] * dinv2;
+                if (sj < 6) {   // the pair that contains slot sj: rows above / on the diagonal get exact zeros
+                    const v2f sc2 = acc[pj < P ? pj : 0] * dinv2;
+                    if (sj & 1) Lp[pj < P ? pj : 0][j] = v2f{0.f, sc2.y * below};
+                    else Lp[pj < P ? pj : 0][j] = v2f{sc2.x * below, sc2.y};
+                }
+                L6[j] = acc6 * dinv;             // row 24 > j always; padding lanes carry exact zeros
+            }
+            if (sj < 6) {
+                if (sj & 1) DinvP[pj < P ? pj : 0].y = own_row ? dinv : DinvP[pj < P ? pj : 0].y;
+                else DinvP[pj < P ? pj : 0].x = own_row ? dinv : DinvP[pj < P ? pj : 0].x;
+            } else {
+                Dinv6 = own_row ? dinv : 0.f;
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // recycle the ring slot just consumed
@@ -286,45 +332,56 @@ __global__ __launch_bounds__(64, 1) void osc_group_kernel_f32(const KParams<floa
             dma_rows1(Mt + 24 * N, N * N, buf, lane);
             if (HASJ3) dma_rows1(Jt + 12 * N, K * N, jtail, lane);
         } else dma_rows4(Jt + (ch - 4) * 4 * N, K * N, buf, lane);   // J0,J1,J2 -> slots 1,2,0 (resident)
+        __builtin_amdgcn_sched_barrier(0);
     }
+    IRLOSC_TS(2);
     // park Mdq in LDS (own rows; rows >= 25 never written)
 #pragma unroll
-    for (int s = 0; s < S - 1; ++s) xq[4 * s + g] = mdq[s];
-    if (!pad6) xq[24] = mdq[6];
+    for (int pp = 0; pp < P; ++pp) { xq[8 * pp + g] = mdqP[pp].x; xq[8 * pp + 4 + g] = mdqP[pp].y; }
+    if (!pad6) xq[24] = mdq6;
 
     // ---------------- J rows: dx and forward substitutions ------------------------------------------------
+    // The R rows of a chunk are substituted together: R independent dependency chains per column step.
 #pragma unroll
     for (int jc = 0; jc < NCHJ; ++jc) {
         if (jc == 0) wait_vm<14>(); else if (jc == 1) wait_vm<7>(); else wait_vm<0>();
+        constexpr int RMAX = 4;
         const int R = jc < 3 ? 4 : 1;
+        v2f bb[RMAX][P];
+        float b6[RMAX];
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
             const int r = jc * 4 + rr;
-            const float* row = jrow_ptr(ring, jtail, jc, q, rr);
-            float bb[S];
+            load_row(jrow_ptr(ring, jtail, jc, q, rr), bb[rr], b6[rr]);
+            v2f dx2 = v2f{0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < S - 1; ++s) bb[s] = row[4 * s + g];
-            const float b6 = row[col6];
-            bb[6] = pad6 ? 0.f : b6;
-            float dxp = 0.f;
-#pragma unroll
-            for (int s = 0; s < S; ++s) dxp = fmaf(bb[s], dqOwn[s], dxp);
-            dxp = qsum(dxp);
+            for (int pp = 0; pp < P; ++pp) dx2 = __builtin_elementwise_fma(bb[rr][pp], dqP[pp], dx2);
+            const float dxp = qsum(fmaf(b6[rr], dq6, dx2.x + dx2.y));
             if (g == 0) xq[25 + r] = dxp;
-            // column-oriented substitution: y_c = b_c / L[c][c] (owner lane), then b_i -= L[i][c] y_c
+        }
+        // column-oriented substitution: y_c = b_c / L[c][c] (owner lane), then b_i -= L[i][c] y_c
 #pragma unroll
-            for (int c = 0; c < N; ++c) {
-                const int sc = c >> 2, gc = c & 3;
-                const float yc = qbcast(bb[sc] * DinvOwn[sc], gc);
+        for (int rr = 0; rr < R; ++rr) {
 #pragma unroll
-                for (int s = sc; s < S; ++s) bb[s] = fmaf(-Ls[s][c], yc, bb[s]);
+            for (int c = 0; c < 24; ++c) {
+                const int sc = c >> 2, gc = c & 3, pc = sc >> 1;
+                const float own = (sc & 1) ? bb[rr][pc].y * DinvP[pc].y : bb[rr][pc].x * DinvP[pc].x;
+                const float ycs = -qbcast(own, gc);
+                const v2f yc = v2f{ycs, ycs};
+#pragma unroll
+                for (int pp = pc; pp < P; ++pp) bb[rr][pp] = __builtin_elementwise_fma(Lp[pp][c], yc, bb[rr][pp]);
+                b6[rr] = fmaf(L6[c], ycs, b6[rr]);
+                asm volatile("" : "+v"(b6[rr]), "+v"(bb[rr][P - 1]));
             }
 #pragma unroll
-            for (int s = 0; s < S; ++s) Yo[r][s] = bb[s] * DinvOwn[s];
+            for (int pp = 0; pp < P; ++pp) Yp[jc * 4 + rr][pp] = bb[rr][pp] * DinvP[pp];
+            Y6[jc * 4 + rr] = b6[rr] * Dinv6;
             __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 
+    IRLOSC_TS(3);
     // ---------------- task-space signal: lane g of the quad handles device g ---------------------------------------
     float kvn = 0.f;
     if (p.cfgflags & IRLOSC_NULLSPACE) kvn = p.null_kv[p.gains_per_instance ? b : 0];
@@ -384,16 +441,17 @@ __global__ __launch_bounds__(64, 1) void osc_group_kernel_f32(const KParams<floa
 #pragma unroll
     for (int r = 0; r < K; ++r) w[r] = wls[r] - kvn * xq[25 + r];
 
+    IRLOSC_TS(4);
     // ---------------- A = Y^T Y (lower), replicated in the quad ---------------------------------------------------
     float A[K][K];
 #pragma unroll
     for (int r = 0; r < K; ++r) {
 #pragma unroll
         for (int s2 = 0; s2 <= r; ++s2) {
-            float a = 0.f;
+            v2f a2 = Yp[r][0] * Yp[s2][0];
 #pragma unroll
-            for (int s = 0; s < S; ++s) a = fmaf(Yo[r][s], Yo[s2][s], a);
-            A[r][s2] = qsum(a);
+            for (int pp = 1; pp < P; ++pp) a2 = __builtin_elementwise_fma(Yp[r][pp], Yp[s2][pp], a2);
+            A[r][s2] = qsum(fmaf(Y6[r], Y6[s2], a2.x + a2.y));
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -412,6 +470,7 @@ __global__ __launch_bounds__(64, 1) void osc_group_kernel_f32(const KParams<floa
         }
     }
 
+    IRLOSC_TS(5);
     // ---------------- k x k (per lane): Cholesky of A in place, cond certificate, t = A^-1 w ------------------
     float nA2 = 0.f;
 #pragma unroll
@@ -480,6 +539,14 @@ __global__ __launch_bounds__(64, 1) void osc_group_kernel_f32(const KParams<floa
         t[i] = s2 * dA[i];
     }
 
+    IRLOSC_TS(6);
+    // Reserve worklist slots for the flagged quads of this wave: ONE atomic per wave on one of NLISTS
+    // sharded counters (a single counter saturates at ~90 atomics/us), issued here so that its round trip
+    // overlaps the torque phase.
+    const unsigned long long fmask = __ballot(!plain && g == 0);
+    int wl_base = 0;
+    const int wl_list = blockIdx.x & (NLISTS - 1);
+    if (fmask != 0ull && lane == 0) wl_base = atomicAdd(workcount + wl_list, __popcll(fmask));
     // ---------------- joint torques for the own rows ------------------------------------------------------------------
     const float* biasv = vec + VEC_BIAS + q * N;
     bool bad = false;
@@ -509,14 +576,13 @@ __global__ __launch_bounds__(64, 1) void osc_group_kernel_f32(const KParams<floa
     }
     flags |= bad ? IRLOSC_FLAG_NONFINITE : 0u;
     flags = grp::qor(flags);
+    if (fmask != 0ull) wl_base = __builtin_amdgcn_readfirstlane(wl_base);
     if (!plain) {
         flags |= IRLOSC_FLAG_EIGEN_PATH;
-        int pos = 0;
-        if (g == 0) {
-            pos = atomicAdd(workcount, 1);
-            worklist[pos] = b;
-        }
-        pos = qbcast_i(pos, 0);
+        // rank of this quad among the wave's flagged quads (bits of fmask below this quad's g==0 lane)
+        const int rank = __popcll(fmask & ((1ull << (lane & ~3)) - 1ull));
+        const int pos = wl_list * list_cap + wl_base + rank;
+        if (g == 0) worklist[pos] = b;
         __builtin_amdgcn_wave_barrier();
         wait_lgkm0();
         // side[e][pos]: A (K(K+1)/2 lower entries, row-major) then w (K)
@@ -527,6 +593,12 @@ __global__ __launch_bounds__(64, 1) void osc_group_kernel_f32(const KParams<floa
             if ((r & 3) == g) side[(size_t)(NA + r) * side_cap + pos] = w[r];
     }
     if (g == 0) p.flags[b] = flags;
+    IRLOSC_TS(7);
+    if (p.dbg && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p.dbg[(size_t)blockIdx.x * 8 + i] = ts[i];
+    }
+#undef IRLOSC_TS
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -546,17 +618,19 @@ __global__ __launch_bounds__(64, 1) void osc_group_kernel_f32(const KParams<floa
 template <int K>
 __global__ __launch_bounds__(64) void osc_group_stage2_f32(const KParams<float> p, const int32_t* __restrict__ worklist,
                                                           const int32_t* __restrict__ workcount,
-                                                          const float* __restrict__ side, int side_cap,
+                                                          const float* __restrict__ side, int side_cap, int list_cap,
                                                           int32_t* __restrict__ worklist2, int32_t* __restrict__ workcount2) {
     using namespace grp;
     constexpr int NA = K * (K + 1) / 2;
     const int lane = threadIdx.x, g = lane & 3, q = lane >> 2;
-    const int count = *workcount;
+    // block -> (list = blockIdx % NLISTS, tile within the list strided by gridDim / NLISTS)
+    const int list = blockIdx.x & (NLISTS - 1);
+    const int count = workcount[list];
     const int ntile = (count + TILE - 1) / TILE;
-    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        const int pos = tile * TILE + q;
-        const bool live = pos < count;
-        const int posc = live ? pos : count - 1;
+    for (int tile = blockIdx.x / NLISTS; tile < ntile; tile += gridDim.x / NLISTS) {
+        const int lpos = tile * TILE + q;
+        const bool live = lpos < count;
+        const int posc = list * list_cap + (live ? lpos : count - 1);
         const int b = worklist[posc];
         float w[K], L[K][K], Ld[K], Li[K];     // factor: strictly-lower L, diagonal Ld, inverse diagonal Li
 #pragma unroll
@@ -768,9 +842,9 @@ inline bool group_kernel_supports(int dtype, int n, int k, int ndev) {
 
 // Device scratch owned by the context for the two-stage group path.
 struct GroupScratch {
-    int32_t* worklist;    // [max_batch] instances flagged by stage 1
+    int32_t* worklist;    // [max_batch + 16 * NLISTS] instances flagged by stage 1, NLISTS sharded lists
     int32_t* worklist2;   // [max_batch] instances stage 2 hands to the generic kernel
-    int32_t* counts;      // [2] lengths of the two lists
+    int32_t* counts;      // [NLISTS + 1] lengths of the sharded stage-1 lists, then of worklist2
     float* side;          // [(K(K+1)/2 + K)][side_cap]: A and w of flagged instances
     int side_cap;
 };
@@ -787,18 +861,21 @@ template <>
 inline int launch_group<float>(const KParams<float>& p, const GroupScratch& gs, hipStream_t st) {
     const int tiles = p.B / grp::TILE;
     const int rem = p.B - tiles * grp::TILE;
-    hipError_t e = hipMemsetAsync(gs.counts, 0, 2 * sizeof(int32_t), st);
+    hipError_t e = hipMemsetAsync(gs.counts, 0, (grp::NLISTS + 1) * sizeof(int32_t), st);
     if (e != hipSuccess) return (int)e;
     int32_t* wc1 = gs.counts;
-    int32_t* wc2 = gs.counts + 1;
+    int32_t* wc2 = gs.counts + grp::NLISTS;
+    // each of the NLISTS lists can hold every instance of the tiles that map to it
+    const int list_cap = ((tiles + grp::NLISTS - 1) / grp::NLISTS) * grp::TILE;
     if (tiles > 0) {
-        const int g2 = tiles < 1024 ? tiles : 1024;
+        int g2 = ((tiles + 3) / 4 + grp::NLISTS - 1) / grp::NLISTS * grp::NLISTS;   // ~1 stage-2 wave per 4 stage-1 waves
+        g2 = g2 < grp::NLISTS ? grp::NLISTS : (g2 > 2048 ? 2048 : g2);
         if (p.k == 13 && p.ndev == 3) {
-            hipLaunchKernelGGL((osc_group_kernel_f32<13, 3>), dim3(tiles), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap);
-            hipLaunchKernelGGL((osc_group_stage2_f32<13>), dim3(g2), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, gs.worklist2, wc2);
+            hipLaunchKernelGGL((osc_group_kernel_f32<13, 3>), dim3(tiles), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, list_cap);
+            hipLaunchKernelGGL((osc_group_stage2_f32<13>), dim3(g2), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, list_cap, gs.worklist2, wc2);
         } else if (p.k == 12 && p.ndev == 2) {
-            hipLaunchKernelGGL((osc_group_kernel_f32<12, 2>), dim3(tiles), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap);
-            hipLaunchKernelGGL((osc_group_stage2_f32<12>), dim3(g2), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, gs.worklist2, wc2);
+            hipLaunchKernelGGL((osc_group_kernel_f32<12, 2>), dim3(tiles), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, list_cap);
+            hipLaunchKernelGGL((osc_group_stage2_f32<12>), dim3(g2), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, list_cap, gs.worklist2, wc2);
         } else return (int)hipErrorNotSupported;
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
