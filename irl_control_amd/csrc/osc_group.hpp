@@ -174,432 +174,9 @@ __device__ __forceinline__ const float* jrow_ptr(const float* ring, const float*
 
 }  // namespace grp
 
-// One wave = 16 instances.  K = stacked task rows, NDEV = target devices (<= 4, one quad lane each).
-template <int K, int NDEV>
-__global__ __launch_bounds__(64, 1) void osc_group_kernel_f32(const KParams<float> p, int32_t* __restrict__ worklist,
-                                                             int32_t* __restrict__ workcount,
-                                                             float* __restrict__ side, int side_cap, int list_cap) {
-    using namespace grp;
-    constexpr int NCHM = 7;                                   // M chunks: 6 x 4 rows + 1 row
-    constexpr int NCHJ = (K + 3) / 4;                         // J chunks of 4 rows; the last may be shorter
-    static_assert(K % 4 == 0 || K % 4 == 1, "the last J chunk must be 4 rows or 1 row");
-    constexpr int VEC_DQ = 0, VEC_BIAS = 512, VEC_EE = 1024, VEC_TGT = 1536, VEC_TV = 2048, VEC_WR = 2560;
-    constexpr int VEC_W = 3072;                               // [16][16] exchange area for the task vector
-    constexpr int VEC_X = 3328;                               // [16][48] per-quad Mdq (25) and dx (K) parking
-    __shared__ __attribute__((aligned(16))) float ring[NBUF * BUF_FLOATS];
-    __shared__ __attribute__((aligned(16))) float vec[3328 + 768];
-    __shared__ __attribute__((aligned(16))) float jtail[448];   // 1-row chunk J[12] (k = 13): 7 x 64 dwords
-    constexpr bool HASJ3 = (K % 4) == 1;
-
-    const int lane = threadIdx.x;
-    const int g = lane & 3, q = lane >> 2;
-    const int tile = blockIdx.x;
-    const int b = tile * TILE + q;
-    const size_t t0 = (size_t)tile * TILE;
-    const bool has_tv = p.tvel != nullptr;
-    const bool has_wr = (p.cfgflags & IRLOSC_ADMITTANCE) && p.wrench != nullptr;
-    unsigned long long ts[8];
-#define IRLOSC_TS(i) ts[i] = p.dbg ? __builtin_readcyclecounter() : 0ull
-    IRLOSC_TS(0);
-
-    // ---------------- prologue: vectors + first chunks in flight -----------------------------------
-    // Issue order (7 DMA instructions per chunk):  vec(12) M0 M1 M2 | M3 | M4 | M5 | M6 [J3] | J0 | J1 | J2
-    // where "| X" means X is issued right after the chunk three places earlier has been consumed.
-    // M chunk c lives in ring slot c % 3 and is recycled; J chunks 0,1,2 land in slots 1,2,0 once
-    // M4,M5,M6 are consumed and then STAY (J is re-read for u -= J^T t); the 1-row chunk J3 (k = 13)
-    // has its own small buffer.  vmcnt retires in order, so "wait until at most n younger DMA
-    // instructions are outstanding" is exact.
-    dma_linear2(p.dq + t0 * N, TILE * N / 4, vec + VEC_DQ, lane);
-    dma_linear2((p.cfgflags & IRLOSC_USE_G) ? p.bias + t0 * N : p.dq + t0 * N, TILE * N / 4, vec + VEC_BIAS, lane);
-    dma_linear2(p.ee + t0 * NDEV * 7, TILE * NDEV * 7 / 4, vec + VEC_EE, lane);
-    dma_linear2(p.tgt + t0 * NDEV * 7, TILE * NDEV * 7 / 4, vec + VEC_TGT, lane);
-    dma_linear2(has_tv ? p.tvel + t0 * NDEV * 6 : p.dq + t0 * N, TILE * NDEV * 6 / 4, vec + VEC_TV, lane);
-    dma_linear2(has_wr ? p.wrench + t0 * NDEV * 6 : p.dq + t0 * N, TILE * NDEV * 6 / 4, vec + VEC_WR, lane);
-    const float* Mt = p.M + t0 * (N * N);
-    const float* Jt = p.J + t0 * (K * N);
-    dma_rows4(Mt, N * N, ring + 0 * BUF_FLOATS, lane);
-    dma_rows4(Mt + 4 * N, N * N, ring + 1 * BUF_FLOATS, lane);
-    dma_rows4(Mt + 8 * N, N * N, ring + 2 * BUF_FLOATS, lane);
-
-    // ---------------- register state ----------------------------------------------------------------
-    // Row slots 0..5 are kept as PAIRS (slots 2p, 2p+1 in one float2) so that the multiply-adds below
-    // are v_pk_fma_f32: a lone wave per SIMD issues one VALU op per quad-cycle, so halving the
-    // instruction count matters more than anything else.  Slot 6 (row 24, real only for g == 0) stays
-    // scalar: pairing it with an all-padding slot 7 cost ~60 registers and pushed L into AGPRs.
-    constexpr int P = 3;
-    v2f Lp[P][24];         // strictly-lower rows of L owned by this lane (slots 0..5); upper/diagonal = 0
-    float L6[24];          // row 24 (g == 0), zeros elsewhere
-    v2f DinvP[P];          // 1 / L[i][i] for the lane's own rows
-    float Dinv6 = 0.f;
-    v2f mdqP[P];           // (M dq)[i] for own rows
-    float mdq6 = 0.f;
-    v2f dqP[P];
-    float dq6;
-    v2f Yp[K][P];          // own rows of Y = L^-1 J^T
-    float Y6[K];
-    uint32_t flags = 0;
-#pragma unroll
-    for (int pp = 0; pp < P; ++pp) { DinvP[pp] = v2f{0.f, 0.f}; mdqP[pp] = v2f{0.f, 0.f}; }
-
-    const bool pad6 = g != 0;            // slot 6 is padding except on quad lane 0
-    const int col6 = pad6 ? 0 : 24;      // safe in-range column for the masked slot
-    float* xq = vec + VEC_X + q * 48;    // per-quad exchange: [0..24] Mdq, [25..37] dx
-
-    // read one 25-float row (quad q): slots 0..5 into 3 pairs, slot 6 into a scalar (padding -> 0)
-    auto load_row = [&](const float* row, v2f (&dst)[P], float& d6) {
-#pragma unroll
-        for (int pp = 0; pp < P; ++pp) dst[pp] = v2f{row[8 * pp + g], row[8 * pp + 4 + g]};
-        const float t6 = row[col6];
-        d6 = pad6 ? 0.f : t6;
-    };
-
-    wait_vm<21>();                        // the 12 vector DMAs have landed (3 chunks = 21 still in flight)
-    IRLOSC_TS(1);
-    load_row(vec + VEC_DQ + q * N, dqP, dq6);
-
-    // ---------------- stream M: Cholesky column by column -----------------------------------------------
-#pragma unroll
-    for (int ch = 0; ch < NCHM; ++ch) {
-        float* buf = ring + (ch % NBUF) * BUF_FLOATS;
-        if (ch <= 3) wait_vm<14>(); else wait_vm<7 * (HASJ3 ? 3 : 2)>();
-        const int R = ch < 6 ? 4 : 1;
-        const int istride = R * N;
-        // all rows of the chunk are read up front (one LDS round trip per chunk instead of per column)
-        v2f mrow[4][P];
-        float mrow6[4], dqj[4];
-#pragma unroll
-        for (int rr = 0; rr < R; ++rr) {
-            load_row(buf + q * istride + rr * N, mrow[rr], mrow6[rr]);
-            dqj[rr] = vec[VEC_DQ + q * N + ch * 4 + rr];
-        }
-#pragma unroll
-        for (int rr = 0; rr < R; ++rr) {
-            const int j = ch * 4 + rr;
-            const int sj = j >> 2, gj = j & 3, pj = sj >> 1;     // row j lives in slot sj of quad lane gj
-            const v2f dq2 = v2f{dqj[rr], dqj[rr]};
-#pragma unroll
-            for (int pp = 0; pp < P; ++pp) mdqP[pp] = __builtin_elementwise_fma(mrow[rr][pp], dq2, mdqP[pp]);   // M symmetric
-            mdq6 = fmaf(mrow6[rr], dqj[rr], mdq6);
-            // left-looking column j: acc = M[j][i] - sum_{c<j} L[i][c] L[j][c] for the rows i >= j
-            v2f acc[P];
-            float acc6 = mrow6[rr];
-#pragma unroll
-            for (int pp = 0; pp < P; ++pp) acc[pp] = mrow[rr][pp];
-#pragma unroll
-            for (int c = 0; c < j; ++c) {
-                const float own = sj == 6 ? L6[c] : ((sj & 1) ? Lp[pj < P ? pj : 0][c].y : Lp[pj < P ? pj : 0][c].x);
-                const float ljs = -qbcast(own, gj);
-                const v2f lj = v2f{ljs, ljs};
-#pragma unroll
-                for (int pp = pj; pp < P; ++pp) acc[pp] = __builtin_elementwise_fma(Lp[pp][c], lj, acc[pp]);
-                acc6 = fmaf(L6[c], ljs, acc6);
-                // keep the scalar slot-6 chain in step with the packed chains: left alone, the scheduler
-                // sinks it to the end of the column and every broadcast value stays live (-> scratch)
-                asm volatile("" : "+v"(acc6), "+v"(acc[P - 1]));
-            }
-            const float dsel = sj == 6 ? acc6 : ((sj & 1) ? acc[pj < P ? pj : 0].y : acc[pj < P ? pj : 0].x);
-            float d = qbcast(dsel, gj);
-            const bool notpd = !(d > 0.f);
-            flags |= notpd ? IRLOSC_FLAG_M_NOT_PD : 0u;
-            const float dfix = (d == d && d != 0.f) ? fabsf(d) : 1.f;
-            d = notpd ? dfix : d;
-            const float dinv = __builtin_amdgcn_rsqf(d);
-            const v2f dinv2 = v2f{dinv, dinv};
-            const bool own_row = (g == gj);
-            const float below = (g > gj) ? 1.f : 0.f;
-            if (j < 24) {
-#pragma unroll
-                for (int pp = pj + 1; pp < P; ++pp) Lp[pp][j] = acc[pp] * dinv2;
-                if (sj < 6) {   // the pair that contains slot sj: rows above / on the diagonal get exact zeros
-                    const v2f sc2 = acc[pj < P ? pj : 0] * dinv2;
-                    if (sj & 1) Lp[pj < P ? pj : 0][j] = v2f{0.f, sc2.y * below};
-                    else Lp[pj < P ? pj : 0][j] = v2f{sc2.x * below, sc2.y};
-                }
-                L6[j] = acc6 * dinv;             // row 24 > j always; padding lanes carry exact zeros
-            }
-            if (sj < 6) {
-                if (sj & 1) DinvP[pj < P ? pj : 0].y = own_row ? dinv : DinvP[pj < P ? pj : 0].y;
-                else DinvP[pj < P ? pj : 0].x = own_row ? dinv : DinvP[pj < P ? pj : 0].x;
-            } else {
-                Dinv6 = own_row ? dinv : 0.f;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // recycle the ring slot just consumed
-        wait_lgkm0();
-        if (ch < 3) dma_rows4(Mt + (ch + 3) * 4 * N, N * N, buf, lane);
-        else if (ch == 3) {
-            dma_rows1(Mt + 24 * N, N * N, buf, lane);
-            if (HASJ3) dma_rows1(Jt + 12 * N, K * N, jtail, lane);
-        } else dma_rows4(Jt + (ch - 4) * 4 * N, K * N, buf, lane);   // J0,J1,J2 -> slots 1,2,0 (resident)
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    IRLOSC_TS(2);
-    // park Mdq in LDS (own rows; rows >= 25 never written)
-#pragma unroll
-    for (int pp = 0; pp < P; ++pp) { xq[8 * pp + g] = mdqP[pp].x; xq[8 * pp + 4 + g] = mdqP[pp].y; }
-    if (!pad6) xq[24] = mdq6;
-
-    // ---------------- J rows: dx and forward substitutions ------------------------------------------------
-    // The R rows of a chunk are substituted together: R independent dependency chains per column step.
-#pragma unroll
-    for (int jc = 0; jc < NCHJ; ++jc) {
-        if (jc == 0) wait_vm<14>(); else if (jc == 1) wait_vm<7>(); else wait_vm<0>();
-        constexpr int RMAX = 4;
-        const int R = jc < 3 ? 4 : 1;
-        v2f bb[RMAX][P];
-        float b6[RMAX];
-#pragma unroll
-        for (int rr = 0; rr < R; ++rr) {
-            const int r = jc * 4 + rr;
-            load_row(jrow_ptr(ring, jtail, jc, q, rr), bb[rr], b6[rr]);
-            v2f dx2 = v2f{0.f, 0.f};
-#pragma unroll
-            for (int pp = 0; pp < P; ++pp) dx2 = __builtin_elementwise_fma(bb[rr][pp], dqP[pp], dx2);
-            const float dxp = qsum(fmaf(b6[rr], dq6, dx2.x + dx2.y));
-            if (g == 0) xq[25 + r] = dxp;
-        }
-        // column-oriented substitution: y_c = b_c / L[c][c] (owner lane), then b_i -= L[i][c] y_c
-#pragma unroll
-        for (int rr = 0; rr < R; ++rr) {
-#pragma unroll
-            for (int c = 0; c < 24; ++c) {
-                const int sc = c >> 2, gc = c & 3, pc = sc >> 1;
-                const float own = (sc & 1) ? bb[rr][pc].y * DinvP[pc].y : bb[rr][pc].x * DinvP[pc].x;
-                const float ycs = -qbcast(own, gc);
-                const v2f yc = v2f{ycs, ycs};
-#pragma unroll
-                for (int pp = pc; pp < P; ++pp) bb[rr][pp] = __builtin_elementwise_fma(Lp[pp][c], yc, bb[rr][pp]);
-                b6[rr] = fmaf(L6[c], ycs, b6[rr]);
-                asm volatile("" : "+v"(b6[rr]), "+v"(bb[rr][P - 1]));
-            }
-#pragma unroll
-            for (int pp = 0; pp < P; ++pp) Yp[jc * 4 + rr][pp] = bb[rr][pp] * DinvP[pp];
-            Y6[jc * 4 + rr] = b6[rr] * Dinv6;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
-    IRLOSC_TS(3);
-    // ---------------- task-space signal: lane g of the quad handles device g ---------------------------------------
-    float kvn = 0.f;
-    if (p.cfgflags & IRLOSC_NULLSPACE) kvn = p.null_kv[p.gains_per_instance ? b : 0];
-    const float* gbase = p.gains + (p.gains_per_instance ? (size_t)b * NDEV * IRLOSC_GAIN_WORDS : 0);
-    float* wls = vec + VEC_W + q * 16;
-    int brA_own = 1;
-    float kv_own = 0.f;
-    __builtin_amdgcn_wave_barrier();
-    if (g < NDEV) {
-        const DevMeta dm = p.dev[g];
-        const float* gg = gbase + g * IRLOSC_GAIN_WORDS;
-        float gl[IRLOSC_GAIN_WORDS];
-#pragma unroll
-        for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) gl[i] = gg[i];
-        kv_own = gl[1];
-        float ee[7], tg[7];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            ee[i] = vec[VEC_EE + (q * NDEV + g) * 7 + i];
-            tg[i] = vec[VEC_TGT + (q * NDEV + g) * 7 + i];
-        }
-        float e[6];
-        task_error6<float>(ee, tg, dm.calc & 1u, dm.calc & 2u, e);
-        apply_gains6<float>(gl, e);
-        float tv[6];
-        bool all_nonzero = has_tv;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            tv[i] = has_tv ? vec[VEC_TV + (q * NDEV + g) * 6 + i] : 0.f;
-            all_nonzero = all_nonzero && (tv[i] != 0.f);
-        }
-        brA_own = all_nonzero ? 0 : 1;
-        if (all_nonzero) {
-            flags |= IRLOSC_FLAG_VEL_BRANCH_B;
-            if (dm.jidx0 + dm.rows > K) flags |= IRLOSC_FLAG_BAD_JIDX;
-        }
-        int cnt = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            if (dm.dofmask & (1u << i)) {
-                float v = e[i];
-                if (all_nonzero) {
-                    const int row = dm.jidx0 + cnt;
-                    const float dxv = xq[25 + (row < K ? row : 0)];
-                    const float damp = (i < 3) ? gl[6 + i] : 1.f;
-                    v += gl[1] * ((row < K ? dxv : 0.f) - tv[i]) * damp;
-                }
-                if (has_wr) v += vec[VEC_WR + (q * NDEV + g) * 6 + i];
-                wls[dm.row0 + cnt] = v;
-                ++cnt;
-            }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    wait_lgkm0();
-    float w[K];
-#pragma unroll
-    for (int r = 0; r < K; ++r) w[r] = wls[r] - kvn * xq[25 + r];
-
-    IRLOSC_TS(4);
-    // ---------------- A = Y^T Y (lower), replicated in the quad ---------------------------------------------------
-    float A[K][K];
-#pragma unroll
-    for (int r = 0; r < K; ++r) {
-#pragma unroll
-        for (int s2 = 0; s2 <= r; ++s2) {
-            v2f a2 = Yp[r][0] * Yp[s2][0];
-#pragma unroll
-            for (int pp = 1; pp < P; ++pp) a2 = __builtin_elementwise_fma(Yp[r][pp], Yp[s2][pp], a2);
-            A[r][s2] = qsum(fmaf(Y6[r], Y6[s2], a2.x + a2.y));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // Park A in LDS (the ee/tgt/tvel/wrench regions are dead by now): lane g stores entries e = g mod 4.
-    // Read back only by flagged quads, which hand A and w to the second stage.
-    float* aq = vec + VEC_EE + q * 96;
-    {
-        int e = 0;
-#pragma unroll
-        for (int r = 0; r < K; ++r) {
-#pragma unroll
-            for (int c2 = 0; c2 <= r; ++c2) {
-                if ((e & 3) == g) aq[e] = A[r][c2];
-                ++e;
-            }
-        }
-    }
-
-    IRLOSC_TS(5);
-    // ---------------- k x k (per lane): Cholesky of A in place, cond certificate, t = A^-1 w ------------------
-    float nA2 = 0.f;
-#pragma unroll
-    for (int r = 0; r < K; ++r) {
-#pragma unroll
-        for (int c = 0; c < r; ++c) nA2 = fmaf(2.f * A[r][c], A[r][c], nA2);
-        nA2 = fmaf(A[r][r], A[r][r], nA2);
-    }
-    bool pdA = true;
-    float detA = 1.f;
-    float dA[K];                       // 1 / L_A[j][j]
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        float d = A[j][j];
-#pragma unroll
-        for (int c = 0; c < j; ++c) d = fmaf(-A[j][c], A[j][c], d);
-        const bool npd = !(d > 0.f);
-        pdA = pdA && !npd;
-        const float dfix = (d == d && d != 0.f) ? fabsf(d) : 1.f;
-        d = npd ? dfix : d;
-        detA *= d;
-        const float di = __builtin_amdgcn_rsqf(d);
-        dA[j] = di;
-#pragma unroll
-        for (int i = j + 1; i < K; ++i) {
-            float a = A[i][j];
-#pragma unroll
-            for (int c = 0; c < j; ++c) a = fmaf(-A[i][c], A[j][c], a);
-            A[i][j] = a * di;
-        }
-    }
-    // ||L_A^-1||_F^2 = trace(A^-1): column j of W = L_A^-1 by forward substitution, used and dropped
-    float nW2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        float wc[K];
-        wc[j] = dA[j];
-        nW2 = fmaf(wc[j], wc[j], nW2);
-#pragma unroll
-        for (int i = j + 1; i < K; ++i) {
-            float s2 = 0.f;
-#pragma unroll
-            for (int c = j; c < i; ++c) s2 = fmaf(A[i][c], wc[c], s2);
-            wc[i] = -dA[i] * s2;
-            nW2 = fmaf(wc[i], wc[i], nW2);
-        }
-    }
-    const bool small_det = !(fabsf(detA) >= 1e-4f);
-    const float cond_bound = sqrtf(nA2) * nW2;        // >= cond_2(A) for SPD A
-    const bool plain = pdA && t_finite(cond_bound) && (!small_det || cond_bound < 0.99e5f);
-    flags |= small_det ? IRLOSC_FLAG_PINV_BRANCH : 0u;
-    float t[K];
-    // forward: z = L_A^-1 w ; backward: t = L_A^-T z
-#pragma unroll
-    for (int i = 0; i < K; ++i) {
-        float s2 = w[i];
-#pragma unroll
-        for (int c = 0; c < i; ++c) s2 = fmaf(-A[i][c], t[c], s2);
-        t[i] = s2 * dA[i];
-    }
-#pragma unroll
-    for (int i = K - 1; i >= 0; --i) {
-        float s2 = t[i];
-#pragma unroll
-        for (int c = i + 1; c < K; ++c) s2 = fmaf(-A[c][i], t[c], s2);
-        t[i] = s2 * dA[i];
-    }
-
-    IRLOSC_TS(6);
-    // Reserve worklist slots for the flagged quads of this wave: ONE atomic per wave on one of NLISTS
-    // sharded counters (a single counter saturates at ~90 atomics/us), issued here so that its round trip
-    // overlaps the torque phase.
-    const unsigned long long fmask = __ballot(!plain && g == 0);
-    int wl_base = 0;
-    const int wl_list = blockIdx.x & (NLISTS - 1);
-    if (fmask != 0ull && lane == 0) wl_base = atomicAdd(workcount + wl_list, __popcll(fmask));
-    // ---------------- joint torques for the own rows ------------------------------------------------------------------
-    const float* biasv = vec + VEC_BIAS + q * N;
-    bool bad = false;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const int i = 4 * s + g;
-        const bool valid = (s < 6) || !pad6;
-        const int icol = valid ? i : 0;
-        const float mdq_i = xq[icol];
-        float uu = 0.f;
-#pragma unroll
-        for (int d = 0; d < NDEV; ++d) {
-            const int brA_d = qbcast_i(brA_own, d);
-            const float kv_d = qbcast(kv_own, d);
-            if (brA_d && (p.dev[d].joint_mask & (1u << i))) uu = -kv_d * mdq_i;
-        }
-        float acc = 0.f;
-#pragma unroll
-        for (int r = 0; r < K; ++r) acc = fmaf(jrow_ptr(ring, jtail, r >> 2, q, r & 3)[icol], t[r], acc);
-        uu -= plain ? acc : 0.f;             // flagged instances keep u_base; stage 2 subtracts J^T t
-        if (p.cfgflags & IRLOSC_USE_G) uu += biasv[icol];
-        uu -= kvn * mdq_i;
-        if (valid) {
-            p.u[(size_t)b * N + i] = uu;
-            bad = bad || !t_finite(uu);
-        }
-    }
-    flags |= bad ? IRLOSC_FLAG_NONFINITE : 0u;
-    flags = grp::qor(flags);
-    if (fmask != 0ull) wl_base = __builtin_amdgcn_readfirstlane(wl_base);
-    if (!plain) {
-        flags |= IRLOSC_FLAG_EIGEN_PATH;
-        // rank of this quad among the wave's flagged quads (bits of fmask below this quad's g==0 lane)
-        const int rank = __popcll(fmask & ((1ull << (lane & ~3)) - 1ull));
-        const int pos = wl_list * list_cap + wl_base + rank;
-        if (g == 0) worklist[pos] = b;
-        __builtin_amdgcn_wave_barrier();
-        wait_lgkm0();
-        // side[e][pos]: A (K(K+1)/2 lower entries, row-major) then w (K)
-        constexpr int NA = K * (K + 1) / 2;
-        for (int e = g; e < NA; e += 4) side[(size_t)e * side_cap + pos] = aq[e];
-#pragma unroll
-        for (int r = 0; r < K; ++r)
-            if ((r & 3) == g) side[(size_t)(NA + r) * side_cap + pos] = w[r];
-    }
-    if (g == 0) p.flags[b] = flags;
-    IRLOSC_TS(7);
-    if (p.dbg && lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) p.dbg[(size_t)blockIdx.x * 8 + i] = ts[i];
-    }
-#undef IRLOSC_TS
-}
+}  // namespace irlosc
+#include "osc_group_stage1.hpp"
+namespace irlosc {
 
 // ---------------------------------------------------------------------------------------------------------
 // Second stage for the group kernel: truncated pseudo-inverse solve t = pinv(A, rcond 1e-5) w for the
@@ -847,6 +424,7 @@ struct GroupScratch {
     int32_t* counts;      // [NLISTS + 1] lengths of the sharded stage-1 lists, then of worklist2
     float* side;          // [(K(K+1)/2 + K)][side_cap]: A and w of flagged instances
     int side_cap;
+    int lanes_per_instance;   // 4 or 8 (stage-1 kernel variant)
 };
 
 template <typename T>
@@ -859,22 +437,26 @@ inline int launch_group<double>(const KParams<double>&, const GroupScratch&, hip
 
 template <>
 inline int launch_group<float>(const KParams<float>& p, const GroupScratch& gs, hipStream_t st) {
-    const int tiles = p.B / grp::TILE;
-    const int rem = p.B - tiles * grp::TILE;
+    const int G = gs.lanes_per_instance == 8 ? 8 : 4;
+    const int TILE1 = 64 / G;
+    const int tiles = p.B / TILE1;
+    const int rem = p.B - tiles * TILE1;
     hipError_t e = hipMemsetAsync(gs.counts, 0, (grp::NLISTS + 1) * sizeof(int32_t), st);
     if (e != hipSuccess) return (int)e;
     int32_t* wc1 = gs.counts;
     int32_t* wc2 = gs.counts + grp::NLISTS;
     // each of the NLISTS lists can hold every instance of the tiles that map to it
-    const int list_cap = ((tiles + grp::NLISTS - 1) / grp::NLISTS) * grp::TILE;
+    const int list_cap = ((tiles + grp::NLISTS - 1) / grp::NLISTS) * TILE1;
     if (tiles > 0) {
-        int g2 = ((tiles + 3) / 4 + grp::NLISTS - 1) / grp::NLISTS * grp::NLISTS;   // ~1 stage-2 wave per 4 stage-1 waves
+        int g2 = ((p.B / 64) + grp::NLISTS - 1) / grp::NLISTS * grp::NLISTS;   // ~1 stage-2 wave per 64 instances
         g2 = g2 < grp::NLISTS ? grp::NLISTS : (g2 > 2048 ? 2048 : g2);
         if (p.k == 13 && p.ndev == 3) {
-            hipLaunchKernelGGL((osc_group_kernel_f32<13, 3>), dim3(tiles), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, list_cap);
+            if (G == 8) hipLaunchKernelGGL((osc_group_kernel_f32<8, 13, 3>), dim3(tiles), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, list_cap);
+            else hipLaunchKernelGGL((osc_group_kernel_f32<4, 13, 3>), dim3(tiles), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, list_cap);
             hipLaunchKernelGGL((osc_group_stage2_f32<13>), dim3(g2), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, list_cap, gs.worklist2, wc2);
         } else if (p.k == 12 && p.ndev == 2) {
-            hipLaunchKernelGGL((osc_group_kernel_f32<12, 2>), dim3(tiles), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, list_cap);
+            if (G == 8) hipLaunchKernelGGL((osc_group_kernel_f32<8, 12, 2>), dim3(tiles), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, list_cap);
+            else hipLaunchKernelGGL((osc_group_kernel_f32<4, 12, 2>), dim3(tiles), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, list_cap);
             hipLaunchKernelGGL((osc_group_stage2_f32<12>), dim3(g2), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, list_cap, gs.worklist2, wc2);
         } else return (int)hipErrorNotSupported;
         e = hipGetLastError();
@@ -884,7 +466,7 @@ inline int launch_group<float>(const KParams<float>& p, const GroupScratch& gs, 
     if (rem > 0) {   // ragged tail (< 16 instances): generic kernel on the last instances
         KParams<float> pt = p;
         pt.index = nullptr;
-        pt.b0 = tiles * grp::TILE;
+        pt.b0 = tiles * TILE1;
         hipLaunchKernelGGL(osc_generic_kernel<float>, dim3(rem), dim3(64), smem, st, pt);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;

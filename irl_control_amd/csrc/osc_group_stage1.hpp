@@ -1,0 +1,603 @@
+// Stage 1 of the group path: G lanes per robot instance (G = 4 or 8), n = 25, fp32.
+// See the header comment of osc_group.hpp for the design; this file is the kernel itself.
+//
+// Lane (q, g) = (lane / G, lane % G) works on instance `tile * (64 / G) + q` and owns the joint rows
+// i = G * s + g.  G = 4: 7 slots (6 paired + scalar slot 6 = row 24, real only for g == 0),
+// 16 instances per wave, ~33 KB LDS, one wave per SIMD.  G = 8: 4 slots = 2 pairs (slot 3 = rows
+// 24..31, real only for g == 0), 8 instances per wave, ~17 KB LDS and < 256 registers, so TWO waves
+// share a SIMD: a lone wave issues at most one VALU op per quad-cycle, two interleave.
+#pragma once
+#include "osc_common.hpp"
+
+namespace irlosc {
+namespace grp {
+
+template <int G> struct Geo {
+    static constexpr int TILE = 64 / G;               // instances per wave
+    static constexpr int NS = (N + G - 1) / G;        // row slots per lane
+    static constexpr int P = NS / 2;                  // slot pairs (float2)
+    static constexpr bool ODD = (NS & 1) != 0;        // a scalar last slot
+    static constexpr int LS = NS - 1;                 // the slot that holds row 24 (= G * LS)
+    static constexpr int PSTR = (G == 4) ? 25 : 26;   // 16-byte pieces per instance in a 4-row chunk image
+    static constexpr int STR4 = PSTR * 4;             // float stride between instances (100 / 104)
+    static constexpr int CI = (TILE * PSTR + 63) / 64;   // DMA instructions per 4-row chunk (7 / 4)
+    static constexpr int C1 = (TILE * N + 63) / 64;      // DMA instructions per 1-row chunk (7 / 4)
+    static constexpr int SLOT = TILE * STR4;             // floats per ring slot
+    static_assert(G * LS == 24, "row 24 must be lane 0 of the last slot");
+    static_assert(CI == C1, "vmcnt bookkeeping assumes equal instruction counts for both chunk kinds");
+};
+
+// broadcast lane gl (0..G-1, compile-time after unrolling) of every G-lane group to the whole group
+template <int G> __device__ __forceinline__ float gbcast(float v, int gl) {
+    float t = qbcast(v, gl & 3);
+    if (G == 8) {
+        // the value now sits in all 4 lanes of the owner's quad of every octet; copy it to the other quad:
+        // row_shr:4 (lane i <- lane i-4) into the upper quads (banks 1,3), or row_shl:4 into the lower (0,2)
+        const int ti = __builtin_bit_cast(int, t);
+        if ((gl & 4) == 0) t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ti, ti, 0x114, 0xf, 0xA, false));
+        else t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ti, ti, 0x104, 0xf, 0x5, false));
+    }
+    return t;
+}
+template <int G> __device__ __forceinline__ int gbcast_i(int v, int gl) {
+    int t = qbcast_i(v, gl & 3);
+    if (G == 8) {
+        if ((gl & 4) == 0) t = __builtin_amdgcn_update_dpp(t, t, 0x114, 0xf, 0xA, false);
+        else t = __builtin_amdgcn_update_dpp(t, t, 0x104, 0xf, 0x5, false);
+    }
+    return t;
+}
+// sum over the G lanes of a group (result in every lane)
+template <int G> __device__ __forceinline__ float gsum(float v) {
+    v = qsum(v);
+    if (G == 8) v += dpp_f<0x141>(v);     // row_half_mirror: the two quads of an octet swap
+    return v;
+}
+template <int G> __device__ __forceinline__ uint32_t gor(uint32_t v) {
+    v = qor(v);
+    if (G == 8) v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true);
+    return v;
+}
+
+// ---- LDS-DMA, one instruction per statement (hand-counted; see osc_group.hpp) ------------------------------
+// `active` lanes fetch size bytes from base + off into LDS at lds + lane * size.
+__device__ __forceinline__ void glds16(const float* base, uint32_t off, uint32_t lds) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %[o], %[base]\n\ts_mov_b32 m0, %[keep]"
+                 : [keep] "=&s"(keep) : [o] "v"(off), [base] "s"(base), [lds] "s"(lds) : "memory");
+}
+__device__ __forceinline__ void glds4(const float* base, uint32_t off, uint32_t lds) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"
+                 "global_load_lds_dword %[o], %[base]\n\ts_mov_b32 m0, %[keep]"
+                 : [keep] "=&s"(keep) : [o] "v"(off), [base] "s"(base), [lds] "s"(lds) : "memory");
+}
+// Every DMA helper issues EXACTLY its nominal number of instructions (inactive tail lanes are clamped to a
+// valid piece and land in the slack of the destination), so the vmcnt arithmetic stays static.
+template <int G> __device__ __forceinline__ void dma4rows(const float* src, int stride, float* buf, int lane) {
+    using GE = Geo<G>;
+    const uint32_t lds = lds_addr(buf);
+#pragma unroll
+    for (int j = 0; j < GE::CI; ++j) {
+        int x = j * 64 + lane;                         // piece slot in the LDS image (PSTR per instance)
+        x = x < GE::TILE * GE::PSTR ? x : GE::TILE * GE::PSTR - 1;
+        const int inst = x / GE::PSTR;
+        int pc = x - inst * GE::PSTR;
+        pc = pc > 24 ? 24 : pc;                        // pad piece (G = 8): re-fetch the last real one
+        glds16(src, (uint32_t)(inst * stride + pc * 4) * 4u, lds + j * 1024);
+    }
+}
+template <int G> __device__ __forceinline__ void dma1row(const float* src, int stride, float* buf, int lane) {
+    using GE = Geo<G>;
+    const uint32_t lds = lds_addr(buf);
+#pragma unroll
+    for (int j = 0; j < GE::C1; ++j) {
+        int x = j * 64 + lane;
+        x = x < GE::TILE * N ? x : GE::TILE * N - 1;
+        const int inst = x / N;
+        const int e = x - inst * N;
+        glds4(src, (uint32_t)(inst * stride + e) * 4u, lds + j * 256);
+    }
+}
+// contiguous block of `pieces` 16-byte pieces with NI instructions
+template <int NI> __device__ __forceinline__ void dmalinear(const float* src, int pieces, float* buf, int lane) {
+    const uint32_t lds = lds_addr(buf);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        int x = j * 64 + lane;
+        x = x < pieces ? x : pieces - 1;
+        glds16(src, (uint32_t)x * 16u, lds + j * 1024);
+    }
+}
+
+}  // namespace grp
+
+template <int G, int K, int NDEV>
+__global__ __launch_bounds__(64, (G == 8 ? 2 : 1)) void osc_group_kernel_f32(
+    const KParams<float> p, int32_t* __restrict__ worklist, int32_t* __restrict__ workcount,
+    float* __restrict__ side, int side_cap, int list_cap) {
+    using namespace grp;
+    using GE = Geo<G>;
+    constexpr int TILE = GE::TILE, P = GE::P, NS = GE::NS, LS = GE::LS, CI = GE::CI;
+    constexpr bool ODD = GE::ODD;
+    constexpr bool HASJ3 = (K % 4) == 1;
+    static_assert(K % 4 == 0 || K % 4 == 1, "the last J chunk must be 4 rows or 1 row");
+    constexpr int NCHM = 7;                          // M chunks: 6 x 4 rows + 1 row
+    constexpr int NCHJ = (K + 3) / 4;
+    constexpr int NA = K * (K + 1) / 2;
+    constexpr int NVI = (TILE * N / 4 + 63) / 64;    // DMA instructions per vector array (2 / 1)
+    constexpr int RND = NVI * 256;                   // floats reserved per vector array (DMA slack included)
+    // LDS map (floats).  The A/w hand-off area `aq` overlays dq..W, all dead by then.
+    constexpr int VEC_DQ = 0, VEC_EE = RND, VEC_TGT = 2 * RND, VEC_TV = 3 * RND, VEC_WR = 4 * RND;
+    constexpr int VEC_W = 5 * RND, VEC_BIAS = VEC_W + TILE * 16, VEC_X = VEC_BIAS + RND, VEC_END = VEC_X + TILE * 40;
+    static_assert(TILE * 92 <= VEC_BIAS, "A park area must fit in the dead dq..W regions");
+    constexpr int RSLOT = CI * 256;                  // ring slot incl. the slack the clamped tail lanes write
+    __shared__ __attribute__((aligned(16))) float ring[3 * RSLOT];
+    __shared__ __attribute__((aligned(16))) float jtail[GE::C1 * 64];
+    __shared__ __attribute__((aligned(16))) float vec[VEC_END];
+
+    const int lane = threadIdx.x;
+    const int g = lane % G, q = lane / G;
+    const int tile = blockIdx.x;
+    const int b = tile * TILE + q;
+    const size_t t0 = (size_t)tile * TILE;
+    const bool has_tv = p.tvel != nullptr;
+    const bool has_wr = (p.cfgflags & IRLOSC_ADMITTANCE) && p.wrench != nullptr;
+    unsigned long long ts[8];
+#define IRLOSC_TS(i) ts[i] = p.dbg ? __builtin_readcyclecounter() : 0ull
+    IRLOSC_TS(0);
+
+    // ---------------- prologue: vectors + first three M chunks in flight ------------------------------------
+    // Issue order (CI instructions per chunk):  vec(6 NVI) M0 M1 M2 | M3 | M4 | M5 | M6 [J3] | J0 | J1 | J2,
+    // "| X" = issued right after the chunk three places earlier has been consumed.  M chunk c lives in ring
+    // slot c % 3; J chunks 0,1,2 land in slots 1,2,0 once M4,M5,M6 are consumed and STAY (re-read for
+    // u -= J^T t); the 1-row chunk J3 (k = 13) has its own buffer.  vmcnt retires in order.
+    dmalinear<NVI>(p.dq + t0 * N, TILE * N / 4, vec + VEC_DQ, lane);
+    dmalinear<NVI>((p.cfgflags & IRLOSC_USE_G) ? p.bias + t0 * N : p.dq + t0 * N, TILE * N / 4, vec + VEC_BIAS, lane);
+    dmalinear<NVI>(p.ee + t0 * NDEV * 7, TILE * NDEV * 7 / 4, vec + VEC_EE, lane);
+    dmalinear<NVI>(p.tgt + t0 * NDEV * 7, TILE * NDEV * 7 / 4, vec + VEC_TGT, lane);
+    dmalinear<NVI>(has_tv ? p.tvel + t0 * NDEV * 6 : p.dq + t0 * N, TILE * NDEV * 6 / 4, vec + VEC_TV, lane);
+    dmalinear<NVI>(has_wr ? p.wrench + t0 * NDEV * 6 : p.dq + t0 * N, TILE * NDEV * 6 / 4, vec + VEC_WR, lane);
+    const float* Mt = p.M + t0 * (N * N);
+    const float* Jt = p.J + t0 * (K * N);
+    dma4rows<G>(Mt, N * N, ring + 0 * RSLOT, lane);
+    dma4rows<G>(Mt + 4 * N, N * N, ring + 1 * RSLOT, lane);
+    dma4rows<G>(Mt + 8 * N, N * N, ring + 2 * RSLOT, lane);
+
+    // ---------------- register state -----------------------------------------------------------------------
+    // Row slots are kept as PAIRS (slots 2p, 2p+1 in one float2) so the multiply-adds are v_pk_fma_f32.
+    struct Row { v2f p[P]; float o; };       // `o` = the scalar odd slot (G = 4: slot 6), unused for G = 8
+    v2f Lp[P][24];         // strictly-lower rows of L owned by this lane; upper/diagonal entries are 0
+    float Lo[24];          // odd slot (row 24 on g == 0, zeros elsewhere)
+    Row dinv, mdq, dqo;    // 1/L[i][i], (M dq)[i], dq[i] for the lane's own rows
+    Row Y[K];              // own rows of Y = L^-1 J^T
+    uint32_t flags = 0;
+#pragma unroll
+    for (int pp = 0; pp < P; ++pp) { dinv.p[pp] = v2f{0.f, 0.f}; mdq.p[pp] = v2f{0.f, 0.f}; }
+    dinv.o = 0.f; mdq.o = 0.f;
+
+    const bool lastpad = g != 0;                 // the last slot (row 24 + padding) is real only on lane g == 0
+    const int lastcol = lastpad ? 0 : 24;        // safe in-range column for the masked slot
+    float* xq = vec + VEC_X + q * 40;            // per-instance exchange: [0..24] Mdq, [25..37] dx
+
+    // slot accessors (s is a compile-time constant wherever these are used)
+    auto sget = [&](const Row& r, int s) -> float {
+        if (ODD && s == LS) return r.o;
+        return (s & 1) ? r.p[s >> 1].y : r.p[s >> 1].x;
+    };
+    // read one 25-float row of this instance: real slots into pairs (+ scalar), padding -> 0
+    auto load_row = [&](const float* row, Row& d) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            float v;
+            if (s == LS) { const float t = row[lastcol]; v = lastpad ? 0.f : t; }
+            else v = row[G * s + g];
+            if (ODD && s == LS) d.o = v;
+            else if (s & 1) d.p[s >> 1].y = v;
+            else d.p[s >> 1].x = v;
+        }
+        if (!ODD) { /* all slots are in pairs */ } else { /* d.o set above */ }
+    };
+
+    wait_vm<3 * CI>();                    // the vector DMAs have landed (3 chunks still in flight)
+    IRLOSC_TS(1);
+    load_row(vec + VEC_DQ + q * N, dqo);
+
+    // ---------------- stream M: Cholesky column by column -------------------------------------------------
+#pragma unroll
+    for (int ch = 0; ch < NCHM; ++ch) {
+        float* buf = ring + (ch % 3) * RSLOT;
+        if (ch <= 3) wait_vm<2 * CI>(); else wait_vm<CI * (HASJ3 ? 3 : 2)>();
+        const int R = ch < 6 ? 4 : 1;
+        const int istride = ch < 6 ? GE::STR4 : N;
+        Row mrow[4];
+        float dqj[4];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {    // all rows of the chunk up front: one LDS round trip per chunk
+            load_row(buf + q * istride + rr * N, mrow[rr]);
+            dqj[rr] = vec[VEC_DQ + q * N + ch * 4 + rr];
+        }
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int j = ch * 4 + rr;
+            const int sj = j / G, gj = j % G;                    // row j lives in slot sj of group lane gj
+            const int pj = sj >> 1;
+            const bool sj_odd_slot = ODD && sj == LS;            // the pivot row sits in the scalar slot
+            const v2f dq2 = v2f{dqj[rr], dqj[rr]};
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) mdq.p[pp] = __builtin_elementwise_fma(mrow[rr].p[pp], dq2, mdq.p[pp]);   // M symmetric
+            if (ODD) mdq.o = fmaf(mrow[rr].o, dqj[rr], mdq.o);
+            // Order fence (no instructions): instruction selection linearises this one huge basic block as it
+            // likes and, left alone, hoists the row-j broadcasts of later columns and sinks the Mdq chain, which
+            // keeps hundreds of values live.  Passing the operands through an empty volatile asm pins them.
+#pragma unroll
+            for (int c = 0; c < j; ++c) {
+                if (sj_odd_slot) asm volatile("" : "+v"(Lo[c]));
+                else asm volatile("" : "+v"(Lp[pj < P ? pj : 0][c]));
+            }
+            // left-looking column j: acc = M[j][i] - sum_{c<j} L[i][c] L[j][c] for the rows i >= j
+            Row acc = mrow[rr];
+#pragma unroll
+            for (int c = 0; c < j; ++c) {
+                const float own = sj_odd_slot ? Lo[c] : ((sj & 1) ? Lp[pj < P ? pj : 0][c].y : Lp[pj < P ? pj : 0][c].x);
+                const float ljs = -gbcast<G>(own, gj);
+                const v2f lj = v2f{ljs, ljs};
+#pragma unroll
+                for (int pp = (pj < P ? pj : P); pp < P; ++pp) acc.p[pp] = __builtin_elementwise_fma(Lp[pp][c], lj, acc.p[pp]);
+                if (ODD) {
+                    acc.o = fmaf(Lo[c], ljs, acc.o);
+                    // keep the scalar chain in step with the packed ones: left alone the scheduler sinks it to
+                    // the end of the column and every broadcast value stays live (-> scratch)
+                    asm volatile("" : "+v"(acc.o), "+v"(acc.p[P - 1]));
+                }
+            }
+            float d = gbcast<G>(sget(acc, sj), gj);
+            const bool notpd = !(d > 0.f);
+            flags |= notpd ? IRLOSC_FLAG_M_NOT_PD : 0u;
+            const float dfix = (d == d && d != 0.f) ? fabsf(d) : 1.f;
+            d = notpd ? dfix : d;
+            const float di = __builtin_amdgcn_rsqf(d);
+            const v2f di2 = v2f{di, di};
+            const bool own_row = (g == gj);
+            const float below = (g > gj) ? 1.f : 0.f;
+            if (j < 24) {
+#pragma unroll
+                for (int pp = pj + 1; pp < P; ++pp) Lp[pp][j] = acc.p[pp] * di2;
+                if (!sj_odd_slot && pj < P) {   // the pair holding slot sj: rows above / on the diagonal get exact zeros
+                    const v2f sc2 = acc.p[pj] * di2;
+                    if (sj & 1) Lp[pj][j] = v2f{0.f, sc2.y * below};
+                    else Lp[pj][j] = v2f{sc2.x * below, sc2.y};
+                }
+                if (ODD) Lo[j] = acc.o * di;    // row 24 > j always; padding lanes carry exact zeros
+            }
+            if (sj_odd_slot) dinv.o = own_row ? di : 0.f;
+            else if (sj & 1) dinv.p[pj < P ? pj : 0].y = own_row ? di : dinv.p[pj < P ? pj : 0].y;
+            else dinv.p[pj < P ? pj : 0].x = own_row ? di : dinv.p[pj < P ? pj : 0].x;
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) asm volatile("" : "+v"(mdq.p[pp]));
+            if (ODD) asm volatile("" : "+v"(mdq.o));
+            if (j < 24) {
+#pragma unroll
+                for (int pp = (pj < P ? pj : P); pp < P; ++pp) asm volatile("" : "+v"(Lp[pp][j]));
+                if (ODD) asm volatile("" : "+v"(Lo[j]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // recycle the ring slot just consumed
+        wait_lgkm0();
+        if (ch < 3) dma4rows<G>(Mt + (ch + 3) * 4 * N, N * N, buf, lane);
+        else if (ch == 3) {
+            dma1row<G>(Mt + 24 * N, N * N, buf, lane);
+            if (HASJ3) dma1row<G>(Jt + 12 * N, K * N, jtail, lane);
+        } else dma4rows<G>(Jt + (ch - 4) * 4 * N, K * N, buf, lane);   // J0,J1,J2 -> slots 1,2,0 (resident)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#if defined(IRLOSC_CUT) && IRLOSC_CUT == 1
+    { v2f h = v2f{0.f,0.f};
+      for (int pp = 0; pp < P; ++pp) for (int c = 0; c < 24; ++c) if (pp >= ((c / G) >> 1)) h += Lp[pp][c];
+      for (int pp = 0; pp < P; ++pp) h += dinv.p[pp] + mdq.p[pp];
+      p.u[(size_t)b * N + g] = h.x + h.y + (ODD ? Lo[3] + dinv.o : 0.f); return; }
+#endif
+    IRLOSC_TS(2);
+    // park Mdq in LDS (own real rows)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s == LS) { if (!lastpad) xq[24] = sget(mdq, s); }
+        else xq[G * s + g] = sget(mdq, s);
+    }
+
+    // row rr of J chunk jc for this instance (chunks 0,1,2: ring slots 1,2,0, stride STR4; chunk 3: jtail)
+    auto jrow = [&](int jc, int rr) -> const float* {
+        if (jc < 3) return ring + ((jc + 1) % 3) * RSLOT + q * GE::STR4 + rr * N;
+        return jtail + q * N;
+    };
+
+    // ---------------- J rows: dx and forward substitutions ----------------------------------------------------
+#pragma unroll
+    for (int jc = 0; jc < NCHJ; ++jc) {
+        if (jc == 0) wait_vm<2 * CI>(); else if (jc == 1) wait_vm<CI>(); else wait_vm<0>();
+        const int R = jc < 3 ? 4 : 1;
+        Row bb[4];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            load_row(jrow(jc, rr), bb[rr]);
+            v2f dx2 = v2f{0.f, 0.f};
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) dx2 = __builtin_elementwise_fma(bb[rr].p[pp], dqo.p[pp], dx2);
+            float dxs = dx2.x + dx2.y;
+            if (ODD) dxs = fmaf(bb[rr].o, dqo.o, dxs);
+            dxs = gsum<G>(dxs);
+            if (g == 0) xq[25 + jc * 4 + rr] = dxs;
+        }
+        // column-oriented substitution: y_c = b_c / L[c][c] (owner lane), then b_i -= L[i][c] y_c
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+#pragma unroll
+            for (int c = 0; c < 24; ++c) {
+                const int sc = c / G, gc = c % G, pc = sc >> 1;
+                const float own = sget(bb[rr], sc) * sget(dinv, sc);
+                const float ycs = -gbcast<G>(own, gc);
+                const v2f yc = v2f{ycs, ycs};
+#pragma unroll
+                for (int pp = pc; pp < P; ++pp) bb[rr].p[pp] = __builtin_elementwise_fma(Lp[pp][c], yc, bb[rr].p[pp]);
+                if (ODD) {
+                    bb[rr].o = fmaf(Lo[c], ycs, bb[rr].o);
+                    asm volatile("" : "+v"(bb[rr].o), "+v"(bb[rr].p[P - 1]));
+                }
+            }
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) Y[jc * 4 + rr].p[pp] = bb[rr].p[pp] * dinv.p[pp];
+            Y[jc * 4 + rr].o = ODD ? bb[rr].o * dinv.o : 0.f;
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) asm volatile("" : "+v"(Y[jc * 4 + rr].p[pp]));
+            if (ODD) asm volatile("" : "+v"(Y[jc * 4 + rr].o));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+#if defined(IRLOSC_CUT) && IRLOSC_CUT == 2
+    { v2f h = v2f{0.f,0.f};
+      for (int r = 0; r < K; ++r) for (int pp = 0; pp < P; ++pp) h += Y[r].p[pp];
+      p.u[(size_t)b * N + g] = h.x + h.y; return; }
+#endif
+    IRLOSC_TS(3);
+    // ---------------- task-space signal: lane d of the group handles device d -----------------------------------
+    float kvn = 0.f;
+    if (p.cfgflags & IRLOSC_NULLSPACE) kvn = p.null_kv[p.gains_per_instance ? b : 0];
+    const float* gbase = p.gains + (p.gains_per_instance ? (size_t)b * NDEV * IRLOSC_GAIN_WORDS : 0);
+    float* wls = vec + VEC_W + q * 16;
+    int brA_own = 1;
+    float kv_own = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    if (g < NDEV) {
+        const DevMeta dm = p.dev[g];
+        const float* gg = gbase + g * IRLOSC_GAIN_WORDS;
+        float gl[IRLOSC_GAIN_WORDS];
+#pragma unroll
+        for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) gl[i] = gg[i];
+        kv_own = gl[1];
+        float ee[7], tg[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            ee[i] = vec[VEC_EE + (q * NDEV + g) * 7 + i];
+            tg[i] = vec[VEC_TGT + (q * NDEV + g) * 7 + i];
+        }
+        float e[6];
+        task_error6<float>(ee, tg, dm.calc & 1u, dm.calc & 2u, e);
+        apply_gains6<float>(gl, e);
+        float tv[6];
+        bool all_nonzero = has_tv;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            tv[i] = has_tv ? vec[VEC_TV + (q * NDEV + g) * 6 + i] : 0.f;
+            all_nonzero = all_nonzero && (tv[i] != 0.f);
+        }
+        brA_own = all_nonzero ? 0 : 1;
+        if (all_nonzero) {
+            flags |= IRLOSC_FLAG_VEL_BRANCH_B;
+            if (dm.jidx0 + dm.rows > K) flags |= IRLOSC_FLAG_BAD_JIDX;
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (dm.dofmask & (1u << i)) {
+                float v = e[i];
+                if (all_nonzero) {
+                    const int row = dm.jidx0 + cnt;
+                    const float dxv = xq[25 + (row < K ? row : 0)];
+                    const float damp = (i < 3) ? gl[6 + i] : 1.f;
+                    v += gl[1] * ((row < K ? dxv : 0.f) - tv[i]) * damp;
+                }
+                if (has_wr) v += vec[VEC_WR + (q * NDEV + g) * 6 + i];
+                wls[dm.row0 + cnt] = v;
+                ++cnt;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    wait_lgkm0();
+    float w[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) w[r] = wls[r] - kvn * xq[25 + r];
+
+    IRLOSC_TS(4);
+    // ---------------- A = Y^T Y (lower), replicated in the group -----------------------------------------------
+    float A[K][K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+#pragma unroll
+        for (int s2 = 0; s2 <= r; ++s2) {
+            v2f a2 = Y[r].p[0] * Y[s2].p[0];
+#pragma unroll
+            for (int pp = 1; pp < P; ++pp) a2 = __builtin_elementwise_fma(Y[r].p[pp], Y[s2].p[pp], a2);
+            float a = a2.x + a2.y;
+            if (ODD) a = fmaf(Y[r].o, Y[s2].o, a);
+            A[r][s2] = gsum<G>(a);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 <= r; ++s2) asm volatile("" : "+v"(A[r][s2]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // Park A in LDS (dq..W regions are dead by now): lane g stores entries e = g mod G.  Read back only by
+    // flagged instances, which hand A and w to the second stage.
+    float* aq = vec + q * 92;
+    {
+        int e = 0;
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+#pragma unroll
+            for (int c2 = 0; c2 <= r; ++c2) {
+                aq[e] = A[r][c2];     // every lane of the group holds the same value: plain broadcast store
+                ++e;
+            }
+        }
+    }
+
+#if defined(IRLOSC_CUT) && IRLOSC_CUT == 3
+    { float h = 0.f;
+      for (int r = 0; r < K; ++r) for (int c = 0; c <= r; ++c) h += A[r][c];
+      for (int r = 0; r < K; ++r) h += w[r];
+      p.u[(size_t)b * N + g] = h; return; }
+#endif
+    IRLOSC_TS(5);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- k x k (per lane): Cholesky of A in place, cond certificate ----------------------------------
+    float nA2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+#pragma unroll
+        for (int c = 0; c < r; ++c) nA2 = fmaf(2.f * A[r][c], A[r][c], nA2);
+        nA2 = fmaf(A[r][r], A[r][r], nA2);
+    }
+    asm volatile("" : "+v"(nA2));     // finish ||A||_F^2 before A is overwritten (else both copies stay live)
+    __builtin_amdgcn_sched_barrier(0);
+    bool pdA = true;
+    float detA = 1.f;
+    float dA[K];                       // 1 / L_A[j][j]
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        float d = A[j][j];
+#pragma unroll
+        for (int c = 0; c < j; ++c) d = fmaf(-A[j][c], A[j][c], d);
+        const bool npd = !(d > 0.f);
+        pdA = pdA && !npd;
+        const float dfix = (d == d && d != 0.f) ? fabsf(d) : 1.f;
+        d = npd ? dfix : d;
+        detA *= d;
+        const float di = __builtin_amdgcn_rsqf(d);
+        dA[j] = di;
+#pragma unroll
+        for (int i = j + 1; i < K; ++i) {
+            float a = A[i][j];
+#pragma unroll
+            for (int c = 0; c < j; ++c) a = fmaf(-A[i][c], A[j][c], a);
+            A[i][j] = a * di;
+        }
+#pragma unroll
+        for (int i = j + 1; i < K; ++i) asm volatile("" : "+v"(A[i][j]));
+        asm volatile("" : "+v"(dA[j]), "+v"(detA));
+    }
+    // ||L_A^-1||_F^2 = trace(A^-1): column j of W = L_A^-1 by forward substitution, used and dropped
+    float nW2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        float wc[K];
+        wc[j] = dA[j];
+        nW2 = fmaf(wc[j], wc[j], nW2);
+#pragma unroll
+        for (int i = j + 1; i < K; ++i) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int c = j; c < i; ++c) s2 = fmaf(A[i][c], wc[c], s2);
+            wc[i] = -dA[i] * s2;
+            nW2 = fmaf(wc[i], wc[i], nW2);
+        }
+        asm volatile("" : "+v"(nW2));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bool small_det = !(fabsf(detA) >= 1e-4f);
+    const float cond_bound = sqrtf(nA2) * nW2;        // >= cond_2(A) for SPD A
+    const bool plain = pdA && t_finite(cond_bound) && (!small_det || cond_bound < 0.99e5f);
+    flags |= small_det ? IRLOSC_FLAG_PINV_BRANCH : 0u;
+    // Reserve worklist slots for the flagged instances of this wave: ONE atomic per wave on one of NLISTS
+    // sharded counters, issued before the solves so that its round trip overlaps them.
+    const unsigned long long fmask = __ballot(!plain && g == 0);
+    int wl_base = 0;
+    const int wl_list = blockIdx.x & (NLISTS - 1);
+    if (fmask != 0ull && lane == 0) wl_base = atomicAdd(workcount + wl_list, __popcll(fmask));
+    float t[K];
+    // forward: z = L_A^-1 w ; backward: t = L_A^-T z
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        float s2 = w[i];
+#pragma unroll
+        for (int c = 0; c < i; ++c) s2 = fmaf(-A[i][c], t[c], s2);
+        t[i] = s2 * dA[i];
+    }
+#pragma unroll
+    for (int i = K - 1; i >= 0; --i) {
+        float s2 = t[i];
+#pragma unroll
+        for (int c = i + 1; c < K; ++c) s2 = fmaf(-A[c][i], t[c], s2);
+        t[i] = s2 * dA[i];
+    }
+
+    IRLOSC_TS(6);
+    // keep the scheduler from hoisting the ~120 LDS reads of the torque phase above the k x k work
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- joint torques for the own rows -----------------------------------------------------------------
+    const float* biasv = vec + VEC_BIAS + q * N;
+    bool bad = false;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int i = G * s + g;
+        const bool valid = (s < LS) || !lastpad;
+        const int icol = valid ? i : 0;
+        const float mdq_i = xq[icol];
+        float uu = 0.f;
+#pragma unroll
+        for (int d = 0; d < NDEV; ++d) {
+            const int brA_d = gbcast_i<G>(brA_own, d);
+            const float kv_d = gbcast<G>(kv_own, d);
+            if (brA_d && (p.dev[d].joint_mask & (1u << (i & 31)))) uu = -kv_d * mdq_i;
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < K; ++r) acc = fmaf(jrow(r >> 2, r & 3)[icol], t[r], acc);
+        uu -= plain ? acc : 0.f;             // flagged instances keep u_base; stage 2 subtracts J^T t
+        if (p.cfgflags & IRLOSC_USE_G) uu += biasv[icol];
+        uu -= kvn * mdq_i;
+        if (valid) {
+            p.u[(size_t)b * N + i] = uu;
+            bad = bad || !t_finite(uu);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    flags |= bad ? IRLOSC_FLAG_NONFINITE : 0u;
+    flags = gor<G>(flags);
+    if (fmask != 0ull) wl_base = __builtin_amdgcn_readfirstlane(wl_base);
+    if (!plain) {
+        flags |= IRLOSC_FLAG_EIGEN_PATH;
+        // rank of this instance among the wave's flagged ones (bits of fmask below this group's lane 0)
+        const int rank = __popcll(fmask & ((1ull << (lane - g)) - 1ull));
+        const int pos = wl_list * list_cap + wl_base + rank;
+        if (g == 0) worklist[pos] = b;
+        __builtin_amdgcn_wave_barrier();
+        wait_lgkm0();
+        // side[e][pos]: A (K(K+1)/2 lower entries, row-major) then w (K)
+        for (int e = g; e < NA; e += G) side[(size_t)e * side_cap + pos] = aq[e];
+#pragma unroll
+        for (int r = 0; r < K; ++r)
+            if ((r % G) == g) side[(size_t)(NA + r) * side_cap + pos] = w[r];
+    }
+    if (g == 0) p.flags[b] = flags;
+    IRLOSC_TS(7);
+    if (p.dbg && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p.dbg[(size_t)blockIdx.x * 8 + i] = ts[i];
+    }
+#undef IRLOSC_TS
+}
+
+}  // namespace irlosc
