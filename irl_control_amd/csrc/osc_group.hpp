@@ -195,20 +195,18 @@ namespace irlosc {
 template <int K>
 __global__ __launch_bounds__(64) void osc_group_stage2_f32(const KParams<float> p, const int32_t* __restrict__ worklist,
                                                           const int32_t* __restrict__ workcount,
-                                                          const float* __restrict__ side, int side_cap, int list_cap,
+                                                          const float* __restrict__ side, int side_cap,
                                                           int32_t* __restrict__ worklist2, int32_t* __restrict__ workcount2) {
     using namespace grp;
     constexpr int NA = K * (K + 1) / 2;
     const int lane = threadIdx.x, g = lane & 3, q = lane >> 2;
-    // block -> (list = blockIdx % NLISTS, tile within the list strided by gridDim / NLISTS)
-    const int list = blockIdx.x & (NLISTS - 1);
-    const int count = workcount[list];
+    const int count = *workcount;
     const int ntile = (count + TILE - 1) / TILE;
-    for (int tile = blockIdx.x / NLISTS; tile < ntile; tile += gridDim.x / NLISTS) {
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const int lpos = tile * TILE + q;
         const bool live = lpos < count;
-        const int posc = list * list_cap + (live ? lpos : count - 1);
-        const int b = worklist[posc];
+        const int b = worklist[live ? lpos : count - 1];
+        const int posc = b;                  // the side buffer is indexed by instance
         float w[K], L[K][K], Ld[K], Li[K];     // factor: strictly-lower L, diagonal Ld, inverse diagonal Li
 #pragma unroll
         for (int r = 0; r < K; ++r) w[r] = side[(size_t)(NA + r) * side_cap + posc];
@@ -417,12 +415,46 @@ inline bool group_kernel_supports(int dtype, int n, int k, int ndev) {
     return dtype == IRLOSC_F32 && n == 25 && ((k == 13 && ndev == 3) || (k == 12 && ndev == 2));
 }
 
+// Build the stage-2 worklist from the flag words stage 1 wrote: one block scans 1024 instances and reserves
+// its output range with ONE atomic (64 atomics for 65 536 instances; order inside the list is irrelevant).
+__global__ __launch_bounds__(256) void osc_group_compact(const uint32_t* __restrict__ flags, int n,
+                                                         int32_t* __restrict__ worklist, int32_t* __restrict__ count) {
+    __shared__ int wave_off[4];
+    __shared__ int block_base;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int idx[4];
+    unsigned long long mk[4];
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        idx[k] = blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        const bool f = idx[k] < n && (flags[idx[k]] & IRLOSC_FLAG_EIGEN_PATH);
+        mk[k] = __ballot(f);
+        mine += __popcll(mk[k]);
+    }
+    if (lane == 0) wave_off[wv] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < 4; ++w) { const int c = wave_off[w]; wave_off[w] = tot; tot += c; }
+        block_base = tot ? atomicAdd(count, tot) : 0;
+    }
+    __syncthreads();
+    int off = block_base + wave_off[wv];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long below = mk[k] & ((1ull << lane) - 1ull);
+        if (mk[k] & (1ull << lane)) worklist[off + __popcll(below)] = idx[k];
+        off += __popcll(mk[k]);
+    }
+}
+
 // Device scratch owned by the context for the two-stage group path.
 struct GroupScratch {
-    int32_t* worklist;    // [max_batch + 16 * NLISTS] instances flagged by stage 1, NLISTS sharded lists
+    int32_t* worklist;    // [max_batch] instances flagged by stage 1 (built by osc_group_compact)
     int32_t* worklist2;   // [max_batch] instances stage 2 hands to the generic kernel
-    int32_t* counts;      // [NLISTS + 1] lengths of the sharded stage-1 lists, then of worklist2
-    float* side;          // [(K(K+1)/2 + K)][side_cap]: A and w of flagged instances
+    int32_t* counts;      // [2] lengths of worklist and worklist2
+    float* side;          // [(K(K+1)/2 + K)][side_cap]: A and w of flagged instances, indexed by instance
     int side_cap;
     int lanes_per_instance;   // 4 or 8 (stage-1 kernel variant)
 };
@@ -440,33 +472,34 @@ inline int launch_group<float>(const KParams<float>& p, const GroupScratch& gs, 
     const int G = gs.lanes_per_instance == 8 ? 8 : 4;
     const int TILE1 = 64 / G;
     const int tiles = p.B / TILE1;
-    const int rem = p.B - tiles * TILE1;
-    hipError_t e = hipMemsetAsync(gs.counts, 0, (grp::NLISTS + 1) * sizeof(int32_t), st);
+    const int nfast = tiles * TILE1;
+    const int rem = p.B - nfast;
+    hipError_t e = hipMemsetAsync(gs.counts, 0, 2 * sizeof(int32_t), st);
     if (e != hipSuccess) return (int)e;
     int32_t* wc1 = gs.counts;
-    int32_t* wc2 = gs.counts + grp::NLISTS;
-    // each of the NLISTS lists can hold every instance of the tiles that map to it
-    const int list_cap = ((tiles + grp::NLISTS - 1) / grp::NLISTS) * TILE1;
+    int32_t* wc2 = gs.counts + 1;
     if (tiles > 0) {
-        int g2 = ((p.B / 64) + grp::NLISTS - 1) / grp::NLISTS * grp::NLISTS;   // ~1 stage-2 wave per 64 instances
-        g2 = g2 < grp::NLISTS ? grp::NLISTS : (g2 > 2048 ? 2048 : g2);
+        int g2 = p.B / 64;                               // ~1 stage-2 wave per 64 instances, grid-strided
+        g2 = g2 < 1 ? 1 : (g2 > 2048 ? 2048 : g2);
         if (p.k == 13 && p.ndev == 3) {
-            if (G == 8) hipLaunchKernelGGL((osc_group_kernel_f32<8, 13, 3>), dim3(tiles), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, list_cap);
-            else hipLaunchKernelGGL((osc_group_kernel_f32<4, 13, 3>), dim3(tiles), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, list_cap);
-            hipLaunchKernelGGL((osc_group_stage2_f32<13>), dim3(g2), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, list_cap, gs.worklist2, wc2);
+            if (G == 8) hipLaunchKernelGGL((osc_group_kernel_f32<8, 13, 3>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap);
+            else hipLaunchKernelGGL((osc_group_kernel_f32<4, 13, 3>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap);
+            hipLaunchKernelGGL(osc_group_compact, dim3((nfast + 1023) / 1024), dim3(256), 0, st, p.flags, nfast, gs.worklist, wc1);
+            hipLaunchKernelGGL((osc_group_stage2_f32<13>), dim3(g2), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, gs.worklist2, wc2);
         } else if (p.k == 12 && p.ndev == 2) {
-            if (G == 8) hipLaunchKernelGGL((osc_group_kernel_f32<8, 12, 2>), dim3(tiles), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, list_cap);
-            else hipLaunchKernelGGL((osc_group_kernel_f32<4, 12, 2>), dim3(tiles), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, list_cap);
-            hipLaunchKernelGGL((osc_group_stage2_f32<12>), dim3(g2), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, list_cap, gs.worklist2, wc2);
+            if (G == 8) hipLaunchKernelGGL((osc_group_kernel_f32<8, 12, 2>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap);
+            else hipLaunchKernelGGL((osc_group_kernel_f32<4, 12, 2>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap);
+            hipLaunchKernelGGL(osc_group_compact, dim3((nfast + 1023) / 1024), dim3(256), 0, st, p.flags, nfast, gs.worklist, wc1);
+            hipLaunchKernelGGL((osc_group_stage2_f32<12>), dim3(g2), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, gs.worklist2, wc2);
         } else return (int)hipErrorNotSupported;
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
     const size_t smem = generic_smem_bytes<float>(p.n, p.k, p.ndev);
-    if (rem > 0) {   // ragged tail (< 16 instances): generic kernel on the last instances
+    if (rem > 0) {   // ragged tail (< TILE instances): generic kernel on the last instances
         KParams<float> pt = p;
         pt.index = nullptr;
-        pt.b0 = tiles * TILE1;
+        pt.b0 = nfast;
         hipLaunchKernelGGL(osc_generic_kernel<float>, dim3(rem), dim3(64), smem, st, pt);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;

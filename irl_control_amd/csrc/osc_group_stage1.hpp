@@ -73,19 +73,19 @@ __device__ __forceinline__ void glds4(const float* base, uint32_t off, uint32_t 
                  "global_load_lds_dword %[o], %[base]\n\ts_mov_b32 m0, %[keep]"
                  : [keep] "=&s"(keep) : [o] "v"(off), [base] "s"(base), [lds] "s"(lds) : "memory");
 }
-// Every DMA helper issues EXACTLY its nominal number of instructions (inactive tail lanes are clamped to a
-// valid piece and land in the slack of the destination), so the vmcnt arithmetic stays static.
+// DMA helpers.  Tail lanes are switched off with EXEC (no LDS overrun, so ring slots can be adjacent);
+// every helper still issues a compile-time number of instructions (each has >= 1 active lane), which keeps
+// the vmcnt arithmetic static.
 template <int G> __device__ __forceinline__ void dma4rows(const float* src, int stride, float* buf, int lane) {
     using GE = Geo<G>;
     const uint32_t lds = lds_addr(buf);
 #pragma unroll
     for (int j = 0; j < GE::CI; ++j) {
-        int x = j * 64 + lane;                         // piece slot in the LDS image (PSTR per instance)
-        x = x < GE::TILE * GE::PSTR ? x : GE::TILE * GE::PSTR - 1;
+        const int x = j * 64 + lane;                   // piece slot in the LDS image (PSTR per instance)
         const int inst = x / GE::PSTR;
         int pc = x - inst * GE::PSTR;
         pc = pc > 24 ? 24 : pc;                        // pad piece (G = 8): re-fetch the last real one
-        glds16(src, (uint32_t)(inst * stride + pc * 4) * 4u, lds + j * 1024);
+        if (x < GE::TILE * GE::PSTR) glds16(src, (uint32_t)(inst * stride + pc * 4) * 4u, lds + j * 1024);
     }
 }
 template <int G> __device__ __forceinline__ void dma1row(const float* src, int stride, float* buf, int lane) {
@@ -93,30 +93,26 @@ template <int G> __device__ __forceinline__ void dma1row(const float* src, int s
     const uint32_t lds = lds_addr(buf);
 #pragma unroll
     for (int j = 0; j < GE::C1; ++j) {
-        int x = j * 64 + lane;
-        x = x < GE::TILE * N ? x : GE::TILE * N - 1;
+        const int x = j * 64 + lane;
         const int inst = x / N;
         const int e = x - inst * N;
-        glds4(src, (uint32_t)(inst * stride + e) * 4u, lds + j * 256);
+        if (x < GE::TILE * N) glds4(src, (uint32_t)(inst * stride + e) * 4u, lds + j * 256);
     }
 }
-// contiguous block of `pieces` 16-byte pieces with NI instructions
-template <int NI> __device__ __forceinline__ void dmalinear(const float* src, int pieces, float* buf, int lane) {
+// contiguous block of PIECES 16-byte pieces: (PIECES + 63) / 64 instructions
+template <int PIECES> __device__ __forceinline__ void dmalinear(const float* src, float* buf, int lane) {
     const uint32_t lds = lds_addr(buf);
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        int x = j * 64 + lane;
-        x = x < pieces ? x : pieces - 1;
-        glds16(src, (uint32_t)x * 16u, lds + j * 1024);
+    for (int j = 0; j < (PIECES + 63) / 64; ++j) {
+        const int x = j * 64 + lane;
+        if (x < PIECES) glds16(src, (uint32_t)x * 16u, lds + j * 1024);
     }
 }
 
 }  // namespace grp
 
 template <int G, int K, int NDEV>
-__global__ __launch_bounds__(64, (G == 8 ? 2 : 1)) void osc_group_kernel_f32(
-    const KParams<float> p, int32_t* __restrict__ worklist, int32_t* __restrict__ workcount,
-    float* __restrict__ side, int side_cap, int list_cap) {
+__global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<float> p, float* __restrict__ side, int side_cap) {
     using namespace grp;
     using GE = Geo<G>;
     constexpr int TILE = GE::TILE, P = GE::P, NS = GE::NS, LS = GE::LS, CI = GE::CI;
@@ -124,17 +120,18 @@ __global__ __launch_bounds__(64, (G == 8 ? 2 : 1)) void osc_group_kernel_f32(
     constexpr bool HASJ3 = (K % 4) == 1;
     static_assert(K % 4 == 0 || K % 4 == 1, "the last J chunk must be 4 rows or 1 row");
     constexpr int NCHM = 7;                          // M chunks: 6 x 4 rows + 1 row
-    constexpr int NCHJ = (K + 3) / 4;
+    constexpr int NCHJ = (K + 3) / 4;                // J chunks: 4-row ones (+ a 1-row tail when k = 13)
+    constexpr int NCH1 = NCHM + NCHJ;                // chunks of the first pass (M then J)
     constexpr int NA = K * (K + 1) / 2;
-    constexpr int NVI = (TILE * N / 4 + 63) / 64;    // DMA instructions per vector array (2 / 1)
-    constexpr int RND = NVI * 256;                   // floats reserved per vector array (DMA slack included)
-    // LDS map (floats).  The A/w hand-off area `aq` overlays dq..W, all dead by then.
-    constexpr int VEC_DQ = 0, VEC_EE = RND, VEC_TGT = 2 * RND, VEC_TV = 3 * RND, VEC_WR = 4 * RND;
-    constexpr int VEC_W = 5 * RND, VEC_BIAS = VEC_W + TILE * 16, VEC_X = VEC_BIAS + RND, VEC_END = VEC_X + TILE * 40;
-    static_assert(TILE * 92 <= VEC_BIAS, "A park area must fit in the dead dq..W regions");
-    constexpr int RSLOT = CI * 256;                  // ring slot incl. the slack the clamped tail lanes write
-    __shared__ __attribute__((aligned(16))) float ring[3 * RSLOT];
-    __shared__ __attribute__((aligned(16))) float jtail[GE::C1 * 64];
+    constexpr int PDQ = TILE * N / 4, PEE = TILE * NDEV * 7 / 4;      // 16-byte pieces of the vector arrays
+    constexpr int NVEC = (PDQ + 63) / 64 + 2 * ((PEE + 63) / 64);     // their DMA instruction count
+    // LDS map (floats): two ring slots, then dq | ee | tgt | W (task vector exchange) | X (Mdq, dx parking).
+    // Kept under 20 KB so that two waves fit per SIMD: a lone wave issues at most one VALU op per quad-cycle.
+    constexpr int SLOT = GE::SLOT;
+    constexpr int VEC_DQ = 0, VEC_EE = VEC_DQ + TILE * N, VEC_TGT = VEC_EE + TILE * NDEV * 7;
+    constexpr int VEC_W = VEC_TGT + TILE * NDEV * 7, VEC_X = VEC_W + TILE * K, VEC_END = VEC_X + TILE * (N + K);
+    static_assert(TILE * NA <= SLOT, "the A hand-off area must fit in one ring slot");
+    __shared__ __attribute__((aligned(16))) float ring[2 * SLOT];
     __shared__ __attribute__((aligned(16))) float vec[VEC_END];
 
     const int lane = threadIdx.x;
@@ -148,22 +145,33 @@ __global__ __launch_bounds__(64, (G == 8 ? 2 : 1)) void osc_group_kernel_f32(
 #define IRLOSC_TS(i) ts[i] = p.dbg ? __builtin_readcyclecounter() : 0ull
     IRLOSC_TS(0);
 
-    // ---------------- prologue: vectors + first three M chunks in flight ------------------------------------
-    // Issue order (CI instructions per chunk):  vec(6 NVI) M0 M1 M2 | M3 | M4 | M5 | M6 [J3] | J0 | J1 | J2,
-    // "| X" = issued right after the chunk three places earlier has been consumed.  M chunk c lives in ring
-    // slot c % 3; J chunks 0,1,2 land in slots 1,2,0 once M4,M5,M6 are consumed and STAY (re-read for
-    // u -= J^T t); the 1-row chunk J3 (k = 13) has its own buffer.  vmcnt retires in order.
-    dmalinear<NVI>(p.dq + t0 * N, TILE * N / 4, vec + VEC_DQ, lane);
-    dmalinear<NVI>((p.cfgflags & IRLOSC_USE_G) ? p.bias + t0 * N : p.dq + t0 * N, TILE * N / 4, vec + VEC_BIAS, lane);
-    dmalinear<NVI>(p.ee + t0 * NDEV * 7, TILE * NDEV * 7 / 4, vec + VEC_EE, lane);
-    dmalinear<NVI>(p.tgt + t0 * NDEV * 7, TILE * NDEV * 7 / 4, vec + VEC_TGT, lane);
-    dmalinear<NVI>(has_tv ? p.tvel + t0 * NDEV * 6 : p.dq + t0 * N, TILE * NDEV * 6 / 4, vec + VEC_TV, lane);
-    dmalinear<NVI>(has_wr ? p.wrench + t0 * NDEV * 6 : p.dq + t0 * N, TILE * NDEV * 6 / 4, vec + VEC_WR, lane);
+    // ---------------- prologue --------------------------------------------------------------------------------
+    // DMA issue order (CI instructions per chunk, retired in order):
+    //   vec(NVEC) C0 C1 | C2 | C3 | ... first pass: C0..C6 = M (6 x 4 rows + row 24), then the J chunks;
+    //   "| Cn" = issued right after chunk n-2 has been consumed, into the slot (n % 2) that chunk vacated.
+    //   Second pass over J (for u -= J^T t; keeping J resident would cost 21 KB of LDS and the second wave
+    //   per SIMD): J0' is issued when the last-but-one first-pass chunk is consumed, J1' after the A hand-off
+    //   area (which borrows the other slot) has been read, J2'/J3' as their slots drain.
+    dmalinear<PDQ>(p.dq + t0 * N, vec + VEC_DQ, lane);
+    dmalinear<PEE>(p.ee + t0 * NDEV * 7, vec + VEC_EE, lane);
+    dmalinear<PEE>(p.tgt + t0 * NDEV * 7, vec + VEC_TGT, lane);
     const float* Mt = p.M + t0 * (N * N);
     const float* Jt = p.J + t0 * (K * N);
-    dma4rows<G>(Mt, N * N, ring + 0 * RSLOT, lane);
-    dma4rows<G>(Mt + 4 * N, N * N, ring + 1 * RSLOT, lane);
-    dma4rows<G>(Mt + 8 * N, N * N, ring + 2 * RSLOT, lane);
+    // chunk n of the first pass / chunk jc of the second pass -> DMA
+    auto issue_first = [&](int n) {
+        float* dst = ring + (n % 2) * SLOT;
+        if (n < 6) dma4rows<G>(Mt + n * 4 * N, N * N, dst, lane);
+        else if (n == 6) dma1row<G>(Mt + 24 * N, N * N, dst, lane);
+        else if (n - NCHM < 3) dma4rows<G>(Jt + (n - NCHM) * 4 * N, K * N, dst, lane);
+        else dma1row<G>(Jt + 12 * N, K * N, dst, lane);
+    };
+    auto issue_second = [&](int jc) {
+        float* dst = ring + ((NCH1 + jc) % 2) * SLOT;
+        if (jc < 3) dma4rows<G>(Jt + jc * 4 * N, K * N, dst, lane);
+        else dma1row<G>(Jt + 12 * N, K * N, dst, lane);
+    };
+    issue_first(0);
+    issue_first(1);
 
     // ---------------- register state -----------------------------------------------------------------------
     // Row slots are kept as PAIRS (slots 2p, 2p+1 in one float2) so the multiply-adds are v_pk_fma_f32.
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(64, (G == 8 ? 2 : 1)) void osc_group_kernel_f32(
 
     const bool lastpad = g != 0;                 // the last slot (row 24 + padding) is real only on lane g == 0
     const int lastcol = lastpad ? 0 : 24;        // safe in-range column for the masked slot
-    float* xq = vec + VEC_X + q * 40;            // per-instance exchange: [0..24] Mdq, [25..37] dx
+    float* xq = vec + VEC_X + q * (N + K);       // per-instance exchange: [0..24] Mdq, [25..25+K) dx
 
     // slot accessors (s is a compile-time constant wherever these are used)
     auto sget = [&](const Row& r, int s) -> float {
@@ -200,15 +208,15 @@ __global__ __launch_bounds__(64, (G == 8 ? 2 : 1)) void osc_group_kernel_f32(
         if (!ODD) { /* all slots are in pairs */ } else { /* d.o set above */ }
     };
 
-    wait_vm<3 * CI>();                    // the vector DMAs have landed (3 chunks still in flight)
+    wait_vm<2 * CI>();                    // the vector DMAs have landed (2 chunks still in flight)
     IRLOSC_TS(1);
     load_row(vec + VEC_DQ + q * N, dqo);
 
     // ---------------- stream M: Cholesky column by column -------------------------------------------------
 #pragma unroll
     for (int ch = 0; ch < NCHM; ++ch) {
-        float* buf = ring + (ch % 3) * RSLOT;
-        if (ch <= 3) wait_vm<2 * CI>(); else wait_vm<CI * (HASJ3 ? 3 : 2)>();
+        float* buf = ring + (ch % 2) * SLOT;
+        wait_vm<CI>();                    // chunk ch has landed; chunk ch + 1 may still be in flight
         const int R = ch < 6 ? 4 : 1;
         const int istride = ch < 6 ? GE::STR4 : N;
         Row mrow[4];
@@ -286,19 +294,9 @@ __global__ __launch_bounds__(64, (G == 8 ? 2 : 1)) void osc_group_kernel_f32(
         }
         // recycle the ring slot just consumed
         wait_lgkm0();
-        if (ch < 3) dma4rows<G>(Mt + (ch + 3) * 4 * N, N * N, buf, lane);
-        else if (ch == 3) {
-            dma1row<G>(Mt + 24 * N, N * N, buf, lane);
-            if (HASJ3) dma1row<G>(Jt + 12 * N, K * N, jtail, lane);
-        } else dma4rows<G>(Jt + (ch - 4) * 4 * N, K * N, buf, lane);   // J0,J1,J2 -> slots 1,2,0 (resident)
+        issue_first(ch + 2);
         __builtin_amdgcn_sched_barrier(0);
     }
-#if defined(IRLOSC_CUT) && IRLOSC_CUT == 1
-    { v2f h = v2f{0.f,0.f};
-      for (int pp = 0; pp < P; ++pp) for (int c = 0; c < 24; ++c) if (pp >= ((c / G) >> 1)) h += Lp[pp][c];
-      for (int pp = 0; pp < P; ++pp) h += dinv.p[pp] + mdq.p[pp];
-      p.u[(size_t)b * N + g] = h.x + h.y + (ODD ? Lo[3] + dinv.o : 0.f); return; }
-#endif
     IRLOSC_TS(2);
     // park Mdq in LDS (own real rows)
 #pragma unroll
@@ -307,21 +305,18 @@ __global__ __launch_bounds__(64, (G == 8 ? 2 : 1)) void osc_group_kernel_f32(
         else xq[G * s + g] = sget(mdq, s);
     }
 
-    // row rr of J chunk jc for this instance (chunks 0,1,2: ring slots 1,2,0, stride STR4; chunk 3: jtail)
-    auto jrow = [&](int jc, int rr) -> const float* {
-        if (jc < 3) return ring + ((jc + 1) % 3) * RSLOT + q * GE::STR4 + rr * N;
-        return jtail + q * N;
-    };
-
     // ---------------- J rows: dx and forward substitutions ----------------------------------------------------
 #pragma unroll
     for (int jc = 0; jc < NCHJ; ++jc) {
-        if (jc == 0) wait_vm<2 * CI>(); else if (jc == 1) wait_vm<CI>(); else wait_vm<0>();
+        const int n = NCHM + jc;
+        float* buf = ring + (n % 2) * SLOT;
+        if (n + 1 < NCH1) wait_vm<CI>(); else wait_vm<CI>();   // the next first-pass chunk, or J0', is in flight
+        const int jstride = jc < 3 ? GE::STR4 : N;
         const int R = jc < 3 ? 4 : 1;
         Row bb[4];
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
-            load_row(jrow(jc, rr), bb[rr]);
+            load_row(buf + q * jstride + rr * N, bb[rr]);
             v2f dx2 = v2f{0.f, 0.f};
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) dx2 = __builtin_elementwise_fma(bb[rr].p[pp], dqo.p[pp], dx2);
@@ -354,6 +349,10 @@ __global__ __launch_bounds__(64, (G == 8 ? 2 : 1)) void osc_group_kernel_f32(
             if (ODD) asm volatile("" : "+v"(Y[jc * 4 + rr].o));
             __builtin_amdgcn_sched_barrier(0);
         }
+        wait_lgkm0();
+        if (n + 2 < NCH1) issue_first(n + 2);
+        else if (n + 2 == NCH1) issue_second(0);      // J0' into the slot just vacated; the last slot stays free for A
+        __builtin_amdgcn_sched_barrier(0);
     }
 
 #if defined(IRLOSC_CUT) && IRLOSC_CUT == 2
@@ -366,7 +365,7 @@ __global__ __launch_bounds__(64, (G == 8 ? 2 : 1)) void osc_group_kernel_f32(
     float kvn = 0.f;
     if (p.cfgflags & IRLOSC_NULLSPACE) kvn = p.null_kv[p.gains_per_instance ? b : 0];
     const float* gbase = p.gains + (p.gains_per_instance ? (size_t)b * NDEV * IRLOSC_GAIN_WORDS : 0);
-    float* wls = vec + VEC_W + q * 16;
+    float* wls = vec + VEC_W + q * K;
     int brA_own = 1;
     float kv_own = 0.f;
     __builtin_amdgcn_wave_barrier();
@@ -390,7 +389,7 @@ __global__ __launch_bounds__(64, (G == 8 ? 2 : 1)) void osc_group_kernel_f32(
         bool all_nonzero = has_tv;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            tv[i] = has_tv ? vec[VEC_TV + (q * NDEV + g) * 6 + i] : 0.f;
+            tv[i] = has_tv ? p.tvel[((size_t)b * NDEV + g) * 6 + i] : 0.f;
             all_nonzero = all_nonzero && (tv[i] != 0.f);
         }
         brA_own = all_nonzero ? 0 : 1;
@@ -409,7 +408,7 @@ __global__ __launch_bounds__(64, (G == 8 ? 2 : 1)) void osc_group_kernel_f32(
                     const float damp = (i < 3) ? gl[6 + i] : 1.f;
                     v += gl[1] * ((row < K ? dxv : 0.f) - tv[i]) * damp;
                 }
-                if (has_wr) v += vec[VEC_WR + (q * NDEV + g) * 6 + i];
+                if (has_wr) v += p.wrench[((size_t)b * NDEV + g) * 6 + i];
                 wls[dm.row0 + cnt] = v;
                 ++cnt;
             }
@@ -439,9 +438,9 @@ __global__ __launch_bounds__(64, (G == 8 ? 2 : 1)) void osc_group_kernel_f32(
         for (int s2 = 0; s2 <= r; ++s2) asm volatile("" : "+v"(A[r][s2]));
         __builtin_amdgcn_sched_barrier(0);
     }
-    // Park A in LDS (dq..W regions are dead by now): lane g stores entries e = g mod G.  Read back only by
-    // flagged instances, which hand A and w to the second stage.
-    float* aq = vec + q * 92;
+    // Park A in the ring slot that the second J pass has not claimed yet (J0' went to the other one).  It is
+    // read back only by flagged instances, which hand A and w to the second stage.
+    float* aq = ring + ((NCH1 + 1) % 2) * SLOT + q * NA;
     {
         int e = 0;
 #pragma unroll
@@ -520,12 +519,19 @@ __global__ __launch_bounds__(64, (G == 8 ? 2 : 1)) void osc_group_kernel_f32(
     const float cond_bound = sqrtf(nA2) * nW2;        // >= cond_2(A) for SPD A
     const bool plain = pdA && t_finite(cond_bound) && (!small_det || cond_bound < 0.99e5f);
     flags |= small_det ? IRLOSC_FLAG_PINV_BRANCH : 0u;
-    // Reserve worklist slots for the flagged instances of this wave: ONE atomic per wave on one of NLISTS
-    // sharded counters, issued before the solves so that its round trip overlaps them.
-    const unsigned long long fmask = __ballot(!plain && g == 0);
-    int wl_base = 0;
-    const int wl_list = blockIdx.x & (NLISTS - 1);
-    if (fmask != 0ull && lane == 0) wl_base = atomicAdd(workcount + wl_list, __popcll(fmask));
+    // Flagged instances hand A and w to the second stage now (side[e][b], indexed by instance: no atomics; a
+    // compaction kernel builds the worklist from the flag words), which frees the slot for J1'.
+    if (!plain) {
+        flags |= IRLOSC_FLAG_EIGEN_PATH;
+        for (int e = g; e < NA; e += G) side[(size_t)e * side_cap + b] = aq[e];
+#pragma unroll
+        for (int r = 0; r < K; ++r)
+            if ((r % G) == g) side[(size_t)(NA + r) * side_cap + b] = w[r];
+    }
+    wait_lgkm0();
+    __builtin_amdgcn_wave_barrier();
+    if (NCHJ > 1) issue_second(1);
+    __builtin_amdgcn_sched_barrier(0);
     float t[K];
     // forward: z = L_A^-1 w ; backward: t = L_A^-T z
 #pragma unroll
@@ -546,8 +552,34 @@ __global__ __launch_bounds__(64, (G == 8 ? 2 : 1)) void osc_group_kernel_f32(
     IRLOSC_TS(6);
     // keep the scheduler from hoisting the ~120 LDS reads of the torque phase above the k x k work
     __builtin_amdgcn_sched_barrier(0);
-    // ---------------- joint torques for the own rows -----------------------------------------------------------------
-    const float* biasv = vec + VEC_BIAS + q * N;
+    // ---------------- joint torques for the own rows: u = u0 + bias - kvn*Mdq - J^T t ----------------------------
+    // NOTE on vmcnt: the side-buffer stores above are VMEM too and retire in order with the DMAs, so waiting
+    // for "at most CI younger" still guarantees J0' has landed (it only waits longer when stores are pending).
+    Row jt;                                   // (J^T t) for the own rows, accumulated chunk by chunk
+#pragma unroll
+    for (int pp = 0; pp < P; ++pp) jt.p[pp] = v2f{0.f, 0.f};
+    jt.o = 0.f;
+#pragma unroll
+    for (int jc = 0; jc < NCHJ; ++jc) {
+        const int n = NCH1 + jc;
+        const float* buf = ring + (n % 2) * SLOT;
+        if (jc + 1 < NCHJ) wait_vm<CI>(); else wait_vm<0>();
+        const int R = jc < 3 ? 4 : 1;
+        const int jstride = jc < 3 ? GE::STR4 : N;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            Row jr;
+            load_row(buf + q * jstride + rr * N, jr);
+            const float tr = t[jc * 4 + rr];
+            const v2f t2 = v2f{tr, tr};
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) jt.p[pp] = __builtin_elementwise_fma(jr.p[pp], t2, jt.p[pp]);
+            if (ODD) jt.o = fmaf(jr.o, tr, jt.o);
+        }
+        wait_lgkm0();
+        if (jc + 2 < NCHJ) issue_second(jc + 2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     bool bad = false;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -562,35 +594,16 @@ __global__ __launch_bounds__(64, (G == 8 ? 2 : 1)) void osc_group_kernel_f32(
             const float kv_d = gbcast<G>(kv_own, d);
             if (brA_d && (p.dev[d].joint_mask & (1u << (i & 31)))) uu = -kv_d * mdq_i;
         }
-        float acc = 0.f;
-#pragma unroll
-        for (int r = 0; r < K; ++r) acc = fmaf(jrow(r >> 2, r & 3)[icol], t[r], acc);
-        uu -= plain ? acc : 0.f;             // flagged instances keep u_base; stage 2 subtracts J^T t
-        if (p.cfgflags & IRLOSC_USE_G) uu += biasv[icol];
+        uu -= plain ? sget(jt, s) : 0.f;     // flagged instances keep u_base; stage 2 subtracts J^T t
+        if (p.cfgflags & IRLOSC_USE_G) uu += p.bias[(size_t)b * N + icol];
         uu -= kvn * mdq_i;
         if (valid) {
             p.u[(size_t)b * N + i] = uu;
             bad = bad || !t_finite(uu);
         }
-        __builtin_amdgcn_sched_barrier(0);
     }
     flags |= bad ? IRLOSC_FLAG_NONFINITE : 0u;
     flags = gor<G>(flags);
-    if (fmask != 0ull) wl_base = __builtin_amdgcn_readfirstlane(wl_base);
-    if (!plain) {
-        flags |= IRLOSC_FLAG_EIGEN_PATH;
-        // rank of this instance among the wave's flagged ones (bits of fmask below this group's lane 0)
-        const int rank = __popcll(fmask & ((1ull << (lane - g)) - 1ull));
-        const int pos = wl_list * list_cap + wl_base + rank;
-        if (g == 0) worklist[pos] = b;
-        __builtin_amdgcn_wave_barrier();
-        wait_lgkm0();
-        // side[e][pos]: A (K(K+1)/2 lower entries, row-major) then w (K)
-        for (int e = g; e < NA; e += G) side[(size_t)e * side_cap + pos] = aq[e];
-#pragma unroll
-        for (int r = 0; r < K; ++r)
-            if ((r % G) == g) side[(size_t)(NA + r) * side_cap + pos] = w[r];
-    }
     if (g == 0) p.flags[b] = flags;
     IRLOSC_TS(7);
     if (p.dbg && lane == 0) {
