@@ -41,6 +41,7 @@ struct irlosc_ctx {
     float* dside = nullptr;         // [104][max_batch] A and w of flagged instances
     unsigned long long* ddbg = nullptr;  // IRLOSC_PHASE_TIMING=1: 8 cycle stamps per stage-1 wave
     int kernel = IRLOSC_KERNEL_GENERIC;
+    int ring = 2;             // group kernel: LDS ring depth (IRLOSC_GROUP_RING=2|3 overrides)
     int lanes = 4;            // group kernel: lanes per instance (IRLOSC_GROUP_LANES=4|8 overrides)
     std::string kernel_name;
     std::string err;
@@ -201,6 +202,7 @@ extern "C" int irlosc_create(const irlosc_cfg* cfg, irlosc_ctx** out) {
     c->kernel = (cfg->kernel == IRLOSC_KERNEL_GENERIC || !group_supported(c)) ? IRLOSC_KERNEL_GENERIC
                                                                               : IRLOSC_KERNEL_GROUP;
     if (const char* ev = getenv("IRLOSC_GROUP_LANES")) c->lanes = atoi(ev) == 8 ? 8 : 4;
+    if (const char* ev = getenv("IRLOSC_GROUP_RING")) c->ring = atoi(ev) == 3 ? 3 : 2;
     char nm[96];
     snprintf(nm, sizeof nm, "%s_%s_n%d_k%d", c->kernel == IRLOSC_KERNEL_GROUP ? "osc_group" : "osc_generic",
              cfg->dtype == IRLOSC_F64 ? "f64" : "f32", cfg->n, k);
@@ -328,7 +330,7 @@ static int launch_t(irlosc_ctx* c, int B, const void* M, const void* J, const vo
     fill_params<T>(c, p, B, M, J, dq, bias, ee, tgt, tvel, wrench, u, flags);
 #ifndef IRLOSC_NO_GROUP_KERNEL
     if (c->kernel == IRLOSC_KERNEL_GROUP) {
-        GroupScratch gs{c->dworklist, c->dworklist2, c->dworkcount, c->dside, c->cfg.max_batch + 16 * 64, c->lanes};
+        GroupScratch gs{c->dworklist, c->dworklist2, c->dworkcount, c->dside, c->cfg.max_batch + 16 * 64, c->lanes, c->ring};
         int rc = launch_group<T>(p, gs, st);
         if (rc) return fail(c, IRLOSC_ERR_HIP, "group kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         return IRLOSC_OK;

@@ -186,26 +186,35 @@ namespace irlosc {
 //
 // Method (A = J M^-1 J^T is symmetric positive semi-definite, k <= 13):
 //   * factor A + sigma I = L L^T (sigma = 0, raised to ~2e-6 ||A||_F only if a pivot fails in fp32);
-//   * lambda_max by 12 power iterations through the factor (A x = L (L^T x) - sigma x);
+//   * lambda_max by 8 power iterations through the factor (A x = L (L^T x) - sigma x);
 //   * the eigenpairs below the cut 1e-5 lambda_max one at a time by inverse iteration with
 //     deflation (at most 3; typically exactly one: a nearly rank-deficient Jacobian stack);
 //   * t = P (A + sigma I)^-1 P w with P the projector off those eigenvectors (one refinement step
 //     when sigma > 0), which equals sum over the kept eigenpairs of v v^T w / lambda.
 // Instances with more than 3 sub-threshold eigenvalues are handed to the generic kernel (Jacobi).
 template <int K>
-__global__ __launch_bounds__(64) void osc_group_stage2_f32(const KParams<float> p, const int32_t* __restrict__ worklist,
-                                                          const int32_t* __restrict__ workcount,
+__global__ __launch_bounds__(64) void osc_group_stage2_f32(const KParams<float> p, int nfast,
                                                           const float* __restrict__ side, int side_cap,
                                                           int32_t* __restrict__ worklist2, int32_t* __restrict__ workcount2) {
     using namespace grp;
     constexpr int NA = K * (K + 1) / 2;
+    constexpr int SPAN = 64;                      // instances scanned per block (~7 flagged at an 11 % rate, so
+    __shared__ int32_t list[SPAN];                // one round of 16 almost always; the kernel is latency-bound)
     const int lane = threadIdx.x, g = lane & 3, q = lane >> 2;
-    const int count = *workcount;
+    // compaction in the block: no global worklist, no atomics (stage 1 left IRLOSC_FLAG_EIGEN_PATH in flags[])
+    const int base = blockIdx.x * SPAN;
+    const int i0 = base + lane;
+    const bool f0 = i0 < nfast && (p.flags[i0] & IRLOSC_FLAG_EIGEN_PATH);
+    const unsigned long long m0 = __ballot(f0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (f0) list[__popcll(m0 & below)] = i0;
+    const int count = __popcll(m0);
+    __syncthreads();
     const int ntile = (count + TILE - 1) / TILE;
-    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    for (int tile = 0; tile < ntile; ++tile) {
         const int lpos = tile * TILE + q;
         const bool live = lpos < count;
-        const int b = worklist[live ? lpos : count - 1];
+        const int b = list[live ? lpos : count - 1];
         const int posc = b;                  // the side buffer is indexed by instance
         float w[K], L[K][K], Ld[K], Li[K];     // factor: strictly-lower L, diagonal Ld, inverse diagonal Li
 #pragma unroll
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(64) void osc_group_stage2_f32(const KParams<float> 
 #pragma unroll
         for (int i = 0; i < K; ++i) x[i] = 0.2f + 0.05f * (float)((i * 7) % 5);
         float lmax = hi;
-        for (int it = 0; it < 12; ++it) {
+        for (int it = 0; it < 8; ++it) {
             amul(x, y);
             const float n2 = dot(y, y);
             const float rn = __builtin_amdgcn_rsqf(n2 > 0.f ? n2 : 1.f);
@@ -327,6 +336,7 @@ __global__ __launch_bounds__(64) void osc_group_stage2_f32(const KParams<float> 
 #pragma unroll
             for (int i = 0; i < K; ++i) x[i] = 0.3f + 0.1f * (float)(((i + 3 * slot) * 5) % 7) - 0.05f * (float)slot;
             float lam = 0.f;
+            float lam_prev = -1.f;
             for (int it = 0; it < 6; ++it) {
 #pragma unroll
                 for (int s0 = 0; s0 < 3; ++s0) {
@@ -342,6 +352,10 @@ __global__ __launch_bounds__(64) void osc_group_stage2_f32(const KParams<float> 
                 lam = rn - sigma;                          // 1/||(A+sigma)^-1 x|| -> lambda + sigma
 #pragma unroll
                 for (int i = 0; i < K; ++i) x[i] *= rn;
+                // converged for every instance of the wave (or clearly above the cut): stop iterating
+                const bool settled = !active || fabsf(lam - lam_prev) <= 1e-3f * fabsf(lam) || (it >= 2 && lam > 4.f * cutoff);
+                lam_prev = lam;
+                if (it >= 2 && !__any(!settled)) break;
             }
             // final clean-up of the accepted vector against the earlier ones
             const bool below = active && (lam <= cutoff);
@@ -415,48 +429,15 @@ inline bool group_kernel_supports(int dtype, int n, int k, int ndev) {
     return dtype == IRLOSC_F32 && n == 25 && ((k == 13 && ndev == 3) || (k == 12 && ndev == 2));
 }
 
-// Build the stage-2 worklist from the flag words stage 1 wrote: one block scans 1024 instances and reserves
-// its output range with ONE atomic (64 atomics for 65 536 instances; order inside the list is irrelevant).
-__global__ __launch_bounds__(256) void osc_group_compact(const uint32_t* __restrict__ flags, int n,
-                                                         int32_t* __restrict__ worklist, int32_t* __restrict__ count) {
-    __shared__ int wave_off[4];
-    __shared__ int block_base;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int idx[4];
-    unsigned long long mk[4];
-    int mine = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        idx[k] = blockIdx.x * 1024 + k * 256 + threadIdx.x;
-        const bool f = idx[k] < n && (flags[idx[k]] & IRLOSC_FLAG_EIGEN_PATH);
-        mk[k] = __ballot(f);
-        mine += __popcll(mk[k]);
-    }
-    if (lane == 0) wave_off[wv] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int tot = 0;
-        for (int w = 0; w < 4; ++w) { const int c = wave_off[w]; wave_off[w] = tot; tot += c; }
-        block_base = tot ? atomicAdd(count, tot) : 0;
-    }
-    __syncthreads();
-    int off = block_base + wave_off[wv];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const unsigned long long below = mk[k] & ((1ull << lane) - 1ull);
-        if (mk[k] & (1ull << lane)) worklist[off + __popcll(below)] = idx[k];
-        off += __popcll(mk[k]);
-    }
-}
-
 // Device scratch owned by the context for the two-stage group path.
 struct GroupScratch {
-    int32_t* worklist;    // [max_batch] instances flagged by stage 1 (built by osc_group_compact)
+    int32_t* worklist;    // unused (stage 2 compacts inside each block)
     int32_t* worklist2;   // [max_batch] instances stage 2 hands to the generic kernel
-    int32_t* counts;      // [2] lengths of worklist and worklist2
+    int32_t* counts;      // [1] length of worklist2
     float* side;          // [(K(K+1)/2 + K)][side_cap]: A and w of flagged instances, indexed by instance
     int side_cap;
     int lanes_per_instance;   // 4 or 8 (stage-1 kernel variant)
+    int ring_depth;           // 2 or 3 LDS ring slots (G = 4)
 };
 
 template <typename T>
@@ -474,23 +455,20 @@ inline int launch_group<float>(const KParams<float>& p, const GroupScratch& gs, 
     const int tiles = p.B / TILE1;
     const int nfast = tiles * TILE1;
     const int rem = p.B - nfast;
-    hipError_t e = hipMemsetAsync(gs.counts, 0, 2 * sizeof(int32_t), st);
-    if (e != hipSuccess) return (int)e;
-    int32_t* wc1 = gs.counts;
-    int32_t* wc2 = gs.counts + 1;
+    int32_t* wc2 = gs.counts;              // length of worklist2; zeroed by block 0 of stage 1
+    hipError_t e;
     if (tiles > 0) {
-        int g2 = p.B / 64;                               // ~1 stage-2 wave per 64 instances, grid-strided
-        g2 = g2 < 1 ? 1 : (g2 > 2048 ? 2048 : g2);
+        const int g2 = (nfast + 63) / 64;
         if (p.k == 13 && p.ndev == 3) {
-            if (G == 8) hipLaunchKernelGGL((osc_group_kernel_f32<8, 13, 3>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap);
-            else hipLaunchKernelGGL((osc_group_kernel_f32<4, 13, 3>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap);
-            hipLaunchKernelGGL(osc_group_compact, dim3((nfast + 1023) / 1024), dim3(256), 0, st, p.flags, nfast, gs.worklist, wc1);
-            hipLaunchKernelGGL((osc_group_stage2_f32<13>), dim3(g2), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, gs.worklist2, wc2);
+            if (G == 8) hipLaunchKernelGGL((osc_group_kernel_f32<8, 13, 3, 3>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap, wc2);
+            else if (gs.ring_depth == 3) hipLaunchKernelGGL((osc_group_kernel_f32<4, 13, 3, 3>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap, wc2);
+            else hipLaunchKernelGGL((osc_group_kernel_f32<4, 13, 3, 2>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap, wc2);
+            hipLaunchKernelGGL((osc_group_stage2_f32<13>), dim3(g2), dim3(64), 0, st, p, nfast, gs.side, gs.side_cap, gs.worklist2, wc2);
         } else if (p.k == 12 && p.ndev == 2) {
-            if (G == 8) hipLaunchKernelGGL((osc_group_kernel_f32<8, 12, 2>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap);
-            else hipLaunchKernelGGL((osc_group_kernel_f32<4, 12, 2>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap);
-            hipLaunchKernelGGL(osc_group_compact, dim3((nfast + 1023) / 1024), dim3(256), 0, st, p.flags, nfast, gs.worklist, wc1);
-            hipLaunchKernelGGL((osc_group_stage2_f32<12>), dim3(g2), dim3(64), 0, st, p, gs.worklist, wc1, gs.side, gs.side_cap, gs.worklist2, wc2);
+            if (G == 8) hipLaunchKernelGGL((osc_group_kernel_f32<8, 12, 2, 3>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap, wc2);
+            else if (gs.ring_depth == 3) hipLaunchKernelGGL((osc_group_kernel_f32<4, 12, 2, 3>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap, wc2);
+            else hipLaunchKernelGGL((osc_group_kernel_f32<4, 12, 2, 2>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap, wc2);
+            hipLaunchKernelGGL((osc_group_stage2_f32<12>), dim3(g2), dim3(64), 0, st, p, nfast, gs.side, gs.side_cap, gs.worklist2, wc2);
         } else return (int)hipErrorNotSupported;
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
@@ -505,12 +483,13 @@ inline int launch_group<float>(const KParams<float>& p, const GroupScratch& gs, 
         if (e != hipSuccess) return (int)e;
     }
     if (tiles > 0) {
-        // instances stage 2 gave up on (> 3 sub-threshold eigenvalues): generic kernel, grid-strided
+        // instances stage 2 gave up on (> 3 sub-threshold eigenvalues, normally none): generic kernel,
+        // a handful of grid-strided blocks that exit at once when the list is empty
         KParams<float> pw = p;
         pw.index = gs.worklist2;
         pw.index_count = wc2;
         pw.b0 = 0;
-        hipLaunchKernelGGL(osc_generic_kernel<float>, dim3(256), dim3(64), smem, st, pw);
+        hipLaunchKernelGGL(osc_generic_kernel<float>, dim3(16), dim3(64), smem, st, pw);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }

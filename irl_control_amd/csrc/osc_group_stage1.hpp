@@ -73,6 +73,16 @@ __device__ __forceinline__ void glds4(const float* base, uint32_t off, uint32_t 
                  "global_load_lds_dword %[o], %[base]\n\ts_mov_b32 m0, %[keep]"
                  : [keep] "=&s"(keep) : [o] "v"(off), [base] "s"(base), [lds] "s"(lds) : "memory");
 }
+// wait until at most `younger` chunks (CI DMA instructions each) are still in flight; `younger` folds to a
+// constant after unrolling
+template <int CI> __device__ __forceinline__ void wait_chunks(int younger) {
+    switch (younger) {
+        case 0: wait_vm<0>(); break;
+        case 1: wait_vm<CI>(); break;
+        default: wait_vm<2 * CI>(); break;
+    }
+}
+
 // DMA helpers.  Tail lanes are switched off with EXEC (no LDS overrun, so ring slots can be adjacent);
 // every helper still issues a compile-time number of instructions (each has >= 1 active lane), which keeps
 // the vmcnt arithmetic static.
@@ -111,8 +121,9 @@ template <int PIECES> __device__ __forceinline__ void dmalinear(const float* src
 
 }  // namespace grp
 
-template <int G, int K, int NDEV>
-__global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<float> p, float* __restrict__ side, int side_cap) {
+template <int G, int K, int NDEV, int NB>
+__global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<float> p, float* __restrict__ side, int side_cap,
+                                                             int32_t* __restrict__ giveup_count) {
     using namespace grp;
     using GE = Geo<G>;
     constexpr int TILE = GE::TILE, P = GE::P, NS = GE::NS, LS = GE::LS, CI = GE::CI;
@@ -131,7 +142,8 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     constexpr int VEC_DQ = 0, VEC_EE = VEC_DQ + TILE * N, VEC_TGT = VEC_EE + TILE * NDEV * 7;
     constexpr int VEC_W = VEC_TGT + TILE * NDEV * 7, VEC_X = VEC_W + TILE * K, VEC_END = VEC_X + TILE * (N + K);
     static_assert(TILE * NA <= SLOT, "the A hand-off area must fit in one ring slot");
-    __shared__ __attribute__((aligned(16))) float ring[2 * SLOT];
+    constexpr int NT = NCH1 + NCHJ;                  // all chunks: first pass, then the second pass over J
+    __shared__ __attribute__((aligned(16))) float ring[NB * SLOT];
     __shared__ __attribute__((aligned(16))) float vec[VEC_END];
 
     const int lane = threadIdx.x;
@@ -144,6 +156,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     unsigned long long ts[8];
 #define IRLOSC_TS(i) ts[i] = p.dbg ? __builtin_readcyclecounter() : 0ull
     IRLOSC_TS(0);
+    if (blockIdx.x == 0 && lane == 0) *giveup_count = 0;     // consumed by stage 2, which runs after this kernel
 
     // ---------------- prologue --------------------------------------------------------------------------------
     // DMA issue order (CI instructions per chunk, retired in order):
@@ -158,20 +171,23 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     const float* Mt = p.M + t0 * (N * N);
     const float* Jt = p.J + t0 * (K * N);
     // chunk n of the first pass / chunk jc of the second pass -> DMA
-    auto issue_first = [&](int n) {
-        float* dst = ring + (n % 2) * SLOT;
-        if (n < 6) dma4rows<G>(Mt + n * 4 * N, N * N, dst, lane);
-        else if (n == 6) dma1row<G>(Mt + 24 * N, N * N, dst, lane);
-        else if (n - NCHM < 3) dma4rows<G>(Jt + (n - NCHM) * 4 * N, K * N, dst, lane);
-        else dma1row<G>(Jt + 12 * N, K * N, dst, lane);
+    // chunk m lives in ring slot m % NB; m < NCH1: first pass (M then J), else second pass over J
+    auto issue = [&](int m) {
+        if (m >= NT) return;
+        float* dst = ring + (m % NB) * SLOT;
+        if (m < 6) dma4rows<G>(Mt + m * 4 * N, N * N, dst, lane);
+        else if (m == 6) dma1row<G>(Mt + 24 * N, N * N, dst, lane);
+        else {
+            const int jc = (m < NCH1) ? m - NCHM : m - NCH1;
+            if (jc < 3) dma4rows<G>(Jt + jc * 4 * N, K * N, dst, lane);
+            else dma1row<G>(Jt + 12 * N, K * N, dst, lane);
+        }
     };
-    auto issue_second = [&](int jc) {
-        float* dst = ring + ((NCH1 + jc) % 2) * SLOT;
-        if (jc < 3) dma4rows<G>(Jt + jc * 4 * N, K * N, dst, lane);
-        else dma1row<G>(Jt + 12 * N, K * N, dst, lane);
-    };
-    issue_first(0);
-    issue_first(1);
+    // Rule: after chunk m has been consumed, chunk m + NB is issued into the slot it vacated - except that the
+    // successor of the LAST first-pass chunk waits until the A hand-off area, which borrows that slot, has been
+    // read.  Hence "younger DMAs possibly in flight while consuming m" = min(NB - 1, NT - 1 - m) chunks.
+#pragma unroll
+    for (int m = 0; m < NB; ++m) issue(m);
 
     // ---------------- register state -----------------------------------------------------------------------
     // Row slots are kept as PAIRS (slots 2p, 2p+1 in one float2) so the multiply-adds are v_pk_fma_f32.
@@ -208,15 +224,15 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
         if (!ODD) { /* all slots are in pairs */ } else { /* d.o set above */ }
     };
 
-    wait_vm<2 * CI>();                    // the vector DMAs have landed (2 chunks still in flight)
+    wait_vm<NB * CI>();                   // the vector DMAs have landed (NB chunks still in flight)
     IRLOSC_TS(1);
     load_row(vec + VEC_DQ + q * N, dqo);
 
     // ---------------- stream M: Cholesky column by column -------------------------------------------------
 #pragma unroll
     for (int ch = 0; ch < NCHM; ++ch) {
-        float* buf = ring + (ch % 2) * SLOT;
-        wait_vm<CI>();                    // chunk ch has landed; chunk ch + 1 may still be in flight
+        float* buf = ring + (ch % NB) * SLOT;
+        wait_chunks<CI>((NT - 1 - ch) < (NB - 1) ? (NT - 1 - ch) : (NB - 1));   // chunk ch has landed
         const int R = ch < 6 ? 4 : 1;
         const int istride = ch < 6 ? GE::STR4 : N;
         Row mrow[4];
@@ -294,7 +310,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
         }
         // recycle the ring slot just consumed
         wait_lgkm0();
-        issue_first(ch + 2);
+        issue(ch + NB);
         __builtin_amdgcn_sched_barrier(0);
     }
     IRLOSC_TS(2);
@@ -309,8 +325,8 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
 #pragma unroll
     for (int jc = 0; jc < NCHJ; ++jc) {
         const int n = NCHM + jc;
-        float* buf = ring + (n % 2) * SLOT;
-        if (n + 1 < NCH1) wait_vm<CI>(); else wait_vm<CI>();   // the next first-pass chunk, or J0', is in flight
+        float* buf = ring + (n % NB) * SLOT;
+        wait_chunks<CI>((NT - 1 - n) < (NB - 1) ? (NT - 1 - n) : (NB - 1));
         const int jstride = jc < 3 ? GE::STR4 : N;
         const int R = jc < 3 ? 4 : 1;
         Row bb[4];
@@ -350,8 +366,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
             __builtin_amdgcn_sched_barrier(0);
         }
         wait_lgkm0();
-        if (n + 2 < NCH1) issue_first(n + 2);
-        else if (n + 2 == NCH1) issue_second(0);      // J0' into the slot just vacated; the last slot stays free for A
+        if (n != NCH1 - 1) issue(n + NB);             // the last first-pass slot is lent to the A hand-off area first
         __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -440,7 +455,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     }
     // Park A in the ring slot that the second J pass has not claimed yet (J0' went to the other one).  It is
     // read back only by flagged instances, which hand A and w to the second stage.
-    float* aq = ring + ((NCH1 + 1) % 2) * SLOT + q * NA;
+    float* aq = ring + ((NCH1 - 1) % NB) * SLOT + q * NA;
     {
         int e = 0;
 #pragma unroll
@@ -530,7 +545,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     }
     wait_lgkm0();
     __builtin_amdgcn_wave_barrier();
-    if (NCHJ > 1) issue_second(1);
+    issue(NCH1 - 1 + NB);                             // the deferred successor of the last first-pass chunk
     __builtin_amdgcn_sched_barrier(0);
     float t[K];
     // forward: z = L_A^-1 w ; backward: t = L_A^-T z
@@ -562,8 +577,8 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
 #pragma unroll
     for (int jc = 0; jc < NCHJ; ++jc) {
         const int n = NCH1 + jc;
-        const float* buf = ring + (n % 2) * SLOT;
-        if (jc + 1 < NCHJ) wait_vm<CI>(); else wait_vm<0>();
+        const float* buf = ring + (n % NB) * SLOT;
+        wait_chunks<CI>((NT - 1 - n) < (NB - 1) ? (NT - 1 - n) : (NB - 1));
         const int R = jc < 3 ? 4 : 1;
         const int jstride = jc < 3 ? GE::STR4 : N;
 #pragma unroll
@@ -577,7 +592,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
             if (ODD) jt.o = fmaf(jr.o, tr, jt.o);
         }
         wait_lgkm0();
-        if (jc + 2 < NCHJ) issue_second(jc + 2);
+        issue(n + NB);
         __builtin_amdgcn_sched_barrier(0);
     }
     bool bad = false;
