@@ -16,7 +16,7 @@
  *   forces gather u_all[actuator_trnids] (osc.py:203-210)       -> host side, from u[B,n]
  *
  * Record layouts (batch-major, row-major, element type = cfg.dtype: float or double):
- *   M[B][n][n]      joint-space inertia (symmetric positive definite; only the lower triangle is read)
+ *   M[B][n][n]      joint-space inertia, symmetric positive definite (the group kernel reads row j as column j)
  *   J[B][k][n]      stacked task Jacobian, device blocks in TARGETS order, k = sum(dev_rows)
  *   dq[B][n]        joint velocities
  *   bias[B][n]      qfrc_bias (gravity + Coriolis); ignored unless IRLOSC_USE_G
@@ -125,6 +125,12 @@ int irlosc_step(irlosc_ctx* ctx, int32_t slot, int32_t B, void* u_host, uint32_t
  * library's own stream; *ms_kernel_avg the mean per-launch duration. */
 int irlosc_step_resident(irlosc_ctx* ctx, int32_t first_slot, int32_t B, int32_t iters,
                          float* ms_total, float* ms_kernel_avg);
+
+/* Roofline support: time ONLY the dominant kernel of a step (the stage-1 group kernel, or the generic
+ * kernel when that is what irlosc_step launches): `iters` back-to-back launches of it on slot `slot`,
+ * HIP events on the library's stream, *ms_avg = mean duration of one launch.  Results in the output
+ * buffers are those of the dominant kernel alone (incomplete for instances that need stage 2). */
+int irlosc_time_dominant_kernel(irlosc_ctx* ctx, int32_t slot, int32_t B, int32_t iters, float* ms_avg);
 
 int irlosc_download(irlosc_ctx* ctx, int32_t B, void* u_host, uint32_t* flags_host);
 int irlosc_sync(irlosc_ctx* ctx);

@@ -102,6 +102,13 @@ class BatchedOSC:
         self._chk(self.lib.irlosc_step_resident(self._h, first_slot, B, iters, C.byref(t), C.byref(a)))
         return t.value, a.value
 
+    def time_dominant_kernel(self, iters: int, slot: int = 0, B: Optional[int] = None) -> float:
+        """Mean duration (ms) of the dominant kernel alone over `iters` launches (roofline support)."""
+        B = self._B[slot] if B is None else B
+        a = C.c_float()
+        self._chk(self.lib.irlosc_time_dominant_kernel(self._h, slot, B, iters, C.byref(a)))
+        return a.value
+
     def download(self, B: Optional[int] = None):
         B = self._B[0] if B is None else B
         u = np.empty((B, self.layout.n), dtype=self.dtype)

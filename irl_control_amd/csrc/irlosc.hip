@@ -41,6 +41,7 @@ struct irlosc_ctx {
     float* dside = nullptr;         // [104][max_batch] A and w of flagged instances
     unsigned long long* ddbg = nullptr;  // IRLOSC_PHASE_TIMING=1: 8 cycle stamps per stage-1 wave
     int kernel = IRLOSC_KERNEL_GENERIC;
+    bool stage1_only = false; // set only inside irlosc_time_dominant_kernel
     int ring = 2;             // group kernel: LDS ring depth (IRLOSC_GROUP_RING=2|3 overrides)
     int lanes = 4;            // group kernel: lanes per instance (IRLOSC_GROUP_LANES=4|8 overrides)
     std::string kernel_name;
@@ -330,7 +331,7 @@ static int launch_t(irlosc_ctx* c, int B, const void* M, const void* J, const vo
     fill_params<T>(c, p, B, M, J, dq, bias, ee, tgt, tvel, wrench, u, flags);
 #ifndef IRLOSC_NO_GROUP_KERNEL
     if (c->kernel == IRLOSC_KERNEL_GROUP) {
-        GroupScratch gs{c->dworklist, c->dworklist2, c->dworkcount, c->dside, c->cfg.max_batch + 16 * 64, c->lanes, c->ring};
+        GroupScratch gs{c->dworklist, c->dworklist2, c->dworkcount, c->dside, c->cfg.max_batch + 16 * 64, c->lanes, c->ring, c->stage1_only};
         int rc = launch_group<T>(p, gs, st);
         if (rc) return fail(c, IRLOSC_ERR_HIP, "group kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         return IRLOSC_OK;
@@ -410,6 +411,26 @@ extern "C" int irlosc_step_resident(irlosc_ctx* c, int32_t first_slot, int32_t B
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     if (ms_total) *ms_total = ms;
     if (ms_kernel_avg) *ms_kernel_avg = ms / (float)iters;
+    return IRLOSC_OK;
+}
+
+extern "C" int irlosc_time_dominant_kernel(irlosc_ctx* c, int32_t slot, int32_t B, int32_t iters, float* ms_avg) {
+    if (!c) return IRLOSC_ERR_ARG;
+    int rc = check_slot(c, slot, B);
+    if (rc) return rc;
+    if (iters < 1 || !ms_avg) return fail(c, IRLOSC_ERR_ARG, "iters must be >= 1 and ms_avg non-NULL");
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    c->stage1_only = true;
+    rc = launch_slot(c, slot, B);                        // warm-up launch
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < iters && !rc; ++i) rc = launch_slot(c, (slot + i) % c->cfg.n_slots, B);
+    c->stage1_only = false;
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *ms_avg = ms / (float)iters;
     return IRLOSC_OK;
 }
 

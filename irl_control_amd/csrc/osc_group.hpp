@@ -438,6 +438,7 @@ struct GroupScratch {
     int side_cap;
     int lanes_per_instance;   // 4 or 8 (stage-1 kernel variant)
     int ring_depth;           // 2 or 3 LDS ring slots (G = 4)
+    bool stage1_only;         // roofline timing: launch the dominant kernel alone
 };
 
 template <typename T>
@@ -463,16 +464,17 @@ inline int launch_group<float>(const KParams<float>& p, const GroupScratch& gs, 
             if (G == 8) hipLaunchKernelGGL((osc_group_kernel_f32<8, 13, 3, 3>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap, wc2);
             else if (gs.ring_depth == 3) hipLaunchKernelGGL((osc_group_kernel_f32<4, 13, 3, 3>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap, wc2);
             else hipLaunchKernelGGL((osc_group_kernel_f32<4, 13, 3, 2>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap, wc2);
-            hipLaunchKernelGGL((osc_group_stage2_f32<13>), dim3(g2), dim3(64), 0, st, p, nfast, gs.side, gs.side_cap, gs.worklist2, wc2);
+            if (!gs.stage1_only) hipLaunchKernelGGL((osc_group_stage2_f32<13>), dim3(g2), dim3(64), 0, st, p, nfast, gs.side, gs.side_cap, gs.worklist2, wc2);
         } else if (p.k == 12 && p.ndev == 2) {
             if (G == 8) hipLaunchKernelGGL((osc_group_kernel_f32<8, 12, 2, 3>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap, wc2);
             else if (gs.ring_depth == 3) hipLaunchKernelGGL((osc_group_kernel_f32<4, 12, 2, 3>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap, wc2);
             else hipLaunchKernelGGL((osc_group_kernel_f32<4, 12, 2, 2>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap, wc2);
-            hipLaunchKernelGGL((osc_group_stage2_f32<12>), dim3(g2), dim3(64), 0, st, p, nfast, gs.side, gs.side_cap, gs.worklist2, wc2);
+            if (!gs.stage1_only) hipLaunchKernelGGL((osc_group_stage2_f32<12>), dim3(g2), dim3(64), 0, st, p, nfast, gs.side, gs.side_cap, gs.worklist2, wc2);
         } else return (int)hipErrorNotSupported;
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
+    if (gs.stage1_only) return 0;
     const size_t smem = generic_smem_bytes<float>(p.n, p.k, p.ndev);
     if (rem > 0) {   // ragged tail (< TILE instances): generic kernel on the last instances
         KParams<float> pt = p;

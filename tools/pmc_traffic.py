@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, TCC slot limits) into
+profiles/hbm_traffic.json.  Units and gfx950 correction per /opt/skills/guides/MI355X_MICROARCH.md §HBM:
+counters are in KiB; FETCH_SIZE reads exactly half of a wide coalesced stream on gfx950 -> doubled.
+usage: pmc_traffic.py <fetch.db> <write.db> <kernel substring> <json key> <out.json>"""
+import json
+import sqlite3
+import sys
+
+
+def avg(db, counter, sub):
+    con = sqlite3.connect(db)
+    rows = con.execute("select value from counters_collection where counter_name=? and kernel_name like ?",
+                       (counter, f"%{sub}%")).fetchall()
+    vals = [r[0] for r in rows]
+    return sum(vals) / len(vals), len(vals)
+
+
+fetch_db, write_db, sub, key, out = sys.argv[1:6]
+f, nf = avg(fetch_db, "FETCH_SIZE", sub)
+w, nw = avg(write_db, "WRITE_SIZE", sub)
+try:
+    data = json.load(open(out))
+except (OSError, ValueError):
+    data = {}
+data[key] = dict(kernel_filter=sub, fetch_size_kib_raw=f, write_size_kib=w, dispatches=[nf, nw],
+                 correction="FETCH_SIZE x2 (gfx950 wide coalesced reads), WRITE_SIZE as reported",
+                 traffic_bytes_per_launch=(2.0 * f + w) * 1024.0)
+json.dump(data, open(out, "w"), indent=1)
+print(json.dumps(data[key]))
