@@ -228,6 +228,41 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     IRLOSC_TS(1);
     load_row(vec + VEC_DQ + q * N, dqo);
 
+    // ---------------- task-space error of device g (lane g < NDEV of the group), part 1 -------------------------
+    // Done here, while the first M chunk is still in flight: quaternion -> sxyz Euler error, velocity limit and
+    // gains need only ee/tgt/gains.  The rows that depend on dx (branch B) are finished after the J phase.
+    float kvn = 0.f;
+    if (p.cfgflags & IRLOSC_NULLSPACE) kvn = p.null_kv[p.gains_per_instance ? b : 0];
+    const float* gbase = p.gains + (p.gains_per_instance ? (size_t)b * NDEV * IRLOSC_GAIN_WORDS : 0);
+    float e6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float kv_own = 0.f;
+    if (g < NDEV) {
+        const DevMeta dm = p.dev[g];
+        const float* gg = gbase + g * IRLOSC_GAIN_WORDS;
+        float gl[IRLOSC_GAIN_WORDS];
+#pragma unroll
+        for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) gl[i] = gg[i];
+        kv_own = gl[1];
+        float ee[7], tg[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            ee[i] = vec[VEC_EE + (q * NDEV + g) * 7 + i];
+            tg[i] = vec[VEC_TGT + (q * NDEV + g) * 7 + i];
+        }
+        task_error6<float>(ee, tg, dm.calc & 1u, dm.calc & 2u, e6);
+        apply_gains6<float>(gl, e6);
+        // park the controlled rows in the exchange area (LDS) instead of holding six registers through the
+        // register-critical phases; part 2 only touches them on the rare branch-B / admittance paths
+        float* wl0 = vec + VEC_W + q * K;
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (dm.dofmask & (1u << i)) { wl0[dm.row0 + cnt] = e6[i]; ++cnt; }
+        }
+    }
+    asm volatile("" : "+v"(kv_own), "+v"(kvn));
+    __builtin_amdgcn_sched_barrier(0);
+
     // ---------------- stream M: Cholesky column by column -------------------------------------------------
 #pragma unroll
     for (int ch = 0; ch < NCHM; ++ch) {
@@ -298,6 +333,11 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
             if (sj_odd_slot) dinv.o = own_row ? di : 0.f;
             else if (sj & 1) dinv.p[pj < P ? pj : 0].y = own_row ? di : dinv.p[pj < P ? pj : 0].y;
             else dinv.p[pj < P ? pj : 0].x = own_row ? di : dinv.p[pj < P ? pj : 0].x;
+            // pair pj is complete once the last row of its second slot has been the pivot: row-scale it now
+            if (((j % (2 * G)) == 2 * G - 1 || j == 24) && pj < P) {
+#pragma unroll
+                for (int c = 0; c <= j && c < 24; ++c) Lp[pj][c] = Lp[pj][c] * dinv.p[pj];
+            }
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) asm volatile("" : "+v"(mdq.p[pp]));
             if (ODD) asm volatile("" : "+v"(mdq.o));
@@ -312,6 +352,12 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
         wait_lgkm0();
         issue(ch + NB);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    // Row-scale the factor once, L'[i][c] = L[i][c] / L[i][i]: the substitutions below then need no per-column
+    // multiply (y_c is the running b'_c itself) and no final scaling.
+    if (ODD) {
+#pragma unroll
+        for (int c = 0; c < 24; ++c) Lo[c] *= dinv.o;
     }
     IRLOSC_TS(2);
     // park Mdq in LDS (own real rows)
@@ -340,6 +386,9 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
             if (ODD) dxs = fmaf(bb[rr].o, dqo.o, dxs);
             dxs = gsum<G>(dxs);
             if (g == 0) xq[25 + jc * 4 + rr] = dxs;
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) bb[rr].p[pp] = bb[rr].p[pp] * dinv.p[pp];     // b' = D^-1 b
+            if (ODD) bb[rr].o *= dinv.o;
         }
         // column-oriented substitution: y_c = b_c / L[c][c] (owner lane), then b_i -= L[i][c] y_c
 #pragma unroll
@@ -347,8 +396,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
 #pragma unroll
             for (int c = 0; c < 24; ++c) {
                 const int sc = c / G, gc = c % G, pc = sc >> 1;
-                const float own = sget(bb[rr], sc) * sget(dinv, sc);
-                const float ycs = -gbcast<G>(own, gc);
+                const float ycs = -gbcast<G>(sget(bb[rr], sc), gc);      // y_c = b'_c, final once columns < c are done
                 const v2f yc = v2f{ycs, ycs};
 #pragma unroll
                 for (int pp = pc; pp < P; ++pp) bb[rr].p[pp] = __builtin_elementwise_fma(Lp[pp][c], yc, bb[rr].p[pp]);
@@ -358,8 +406,8 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
                 }
             }
 #pragma unroll
-            for (int pp = 0; pp < P; ++pp) Y[jc * 4 + rr].p[pp] = bb[rr].p[pp] * dinv.p[pp];
-            Y[jc * 4 + rr].o = ODD ? bb[rr].o * dinv.o : 0.f;
+            for (int pp = 0; pp < P; ++pp) Y[jc * 4 + rr].p[pp] = bb[rr].p[pp];
+            Y[jc * 4 + rr].o = ODD ? bb[rr].o : 0.f;
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) asm volatile("" : "+v"(Y[jc * 4 + rr].p[pp]));
             if (ODD) asm volatile("" : "+v"(Y[jc * 4 + rr].o));
@@ -376,30 +424,13 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
       p.u[(size_t)b * N + g] = h.x + h.y; return; }
 #endif
     IRLOSC_TS(3);
-    // ---------------- task-space signal: lane d of the group handles device d -----------------------------------
-    float kvn = 0.f;
-    if (p.cfgflags & IRLOSC_NULLSPACE) kvn = p.null_kv[p.gains_per_instance ? b : 0];
-    const float* gbase = p.gains + (p.gains_per_instance ? (size_t)b * NDEV * IRLOSC_GAIN_WORDS : 0);
+    // ---------------- task-space signal, part 2: rows of device g into the exchange area --------------------------
     float* wls = vec + VEC_W + q * K;
     int brA_own = 1;
-    float kv_own = 0.f;
     __builtin_amdgcn_wave_barrier();
     if (g < NDEV) {
         const DevMeta dm = p.dev[g];
         const float* gg = gbase + g * IRLOSC_GAIN_WORDS;
-        float gl[IRLOSC_GAIN_WORDS];
-#pragma unroll
-        for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) gl[i] = gg[i];
-        kv_own = gl[1];
-        float ee[7], tg[7];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            ee[i] = vec[VEC_EE + (q * NDEV + g) * 7 + i];
-            tg[i] = vec[VEC_TGT + (q * NDEV + g) * 7 + i];
-        }
-        float e[6];
-        task_error6<float>(ee, tg, dm.calc & 1u, dm.calc & 2u, e);
-        apply_gains6<float>(gl, e);
         float tv[6];
         bool all_nonzero = has_tv;
 #pragma unroll
@@ -412,20 +443,22 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
             flags |= IRLOSC_FLAG_VEL_BRANCH_B;
             if (dm.jidx0 + dm.rows > K) flags |= IRLOSC_FLAG_BAD_JIDX;
         }
-        int cnt = 0;
+        if (all_nonzero || has_wr) {
+            int cnt = 0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            if (dm.dofmask & (1u << i)) {
-                float v = e[i];
-                if (all_nonzero) {
-                    const int row = dm.jidx0 + cnt;
-                    const float dxv = xq[25 + (row < K ? row : 0)];
-                    const float damp = (i < 3) ? gl[6 + i] : 1.f;
-                    v += gl[1] * ((row < K ? dxv : 0.f) - tv[i]) * damp;
+            for (int i = 0; i < 6; ++i) {
+                if (dm.dofmask & (1u << i)) {
+                    float v = wls[dm.row0 + cnt];
+                    if (all_nonzero) {
+                        const int row = dm.jidx0 + cnt;
+                        const float dxv = xq[25 + (row < K ? row : 0)];
+                        const float damp = (i < 3) ? gg[6 + i] : 1.f;
+                        v += kv_own * ((row < K ? dxv : 0.f) - tv[i]) * damp;
+                    }
+                    if (has_wr) v += p.wrench[((size_t)b * NDEV + g) * 6 + i];
+                    wls[dm.row0 + cnt] = v;
+                    ++cnt;
                 }
-                if (has_wr) v += p.wrench[((size_t)b * NDEV + g) * 6 + i];
-                wls[dm.row0 + cnt] = v;
-                ++cnt;
             }
         }
     }
