@@ -629,6 +629,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
         __builtin_amdgcn_sched_barrier(0);
     }
     bool bad = false;
+    float* ubuf = ring;                       // both ring slots have been drained by now
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int i = G * s + g;
@@ -646,8 +647,21 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
         if (p.cfgflags & IRLOSC_USE_G) uu += p.bias[(size_t)b * N + icol];
         uu -= kvn * mdq_i;
         if (valid) {
-            p.u[(size_t)b * N + i] = uu;
+            ubuf[q * N + i] = uu;
             bad = bad || !t_finite(uu);
+        }
+    }
+    // u leaves through LDS as whole 16-byte pieces of the tile's contiguous [TILE][25] block: per-lane
+    // stores at a 100-byte instance stride were partial-line writes (WRITE_SIZE 3.6x the payload)
+    __builtin_amdgcn_wave_barrier();
+    wait_lgkm0();
+    {
+        const float4* src4 = reinterpret_cast<const float4*>(ubuf);
+        float4* dst4 = reinterpret_cast<float4*>(p.u + t0 * N);
+#pragma unroll
+        for (int j = 0; j < (TILE * N / 4 + 63) / 64; ++j) {
+            const int x = j * 64 + lane;
+            if (x < TILE * N / 4) dst4[x] = src4[x];
         }
     }
     flags |= bad ? IRLOSC_FLAG_NONFINITE : 0u;
