@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libirlosc.so")
+LIB_PATH = os.environ.get("IRLOSC_LIB", os.path.join(_HERE, "libirlosc.so"))   # override: A/B builds only
 
 MAX_DEV, MAX_N, MAX_K, GAIN_WORDS = 4, 32, 16, 12
 F32, F64 = 0, 1

@@ -101,6 +101,9 @@ template <int G> __device__ __forceinline__ void dma4rows(const float* src, int 
 template <int G> __device__ __forceinline__ void dma1row(const float* src, int stride, float* buf, int lane) {
     using GE = Geo<G>;
     const uint32_t lds = lds_addr(buf);
+    // used only three times per wave: recompute the offsets from an opaque copy of the lane id instead of letting
+    // the compiler keep 7 more address registers alive through the register-critical phases
+    asm volatile("" : "+v"(lane));
 #pragma unroll
     for (int j = 0; j < GE::C1; ++j) {
         const int x = j * 64 + lane;
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     struct Row { v2f p[P]; float o; };       // `o` = the scalar odd slot (G = 4: slot 6), unused for G = 8
     v2f Lp[P][24];         // strictly-lower rows of L owned by this lane; upper/diagonal entries are 0
     float Lo[24];          // odd slot (row 24 on g == 0, zeros elsewhere)
-    Row dinv, mdq, dqo;    // 1/L[i][i], (M dq)[i], dq[i] for the lane's own rows
+    Row dinv, mdq;         // 1/L[i][i], (M dq)[i] for the lane's own rows
     Row Y[K];              // own rows of Y = L^-1 J^T
     uint32_t flags = 0;
 #pragma unroll
@@ -226,23 +229,21 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
 
     wait_vm<NB * CI>();                   // the vector DMAs have landed (NB chunks still in flight)
     IRLOSC_TS(1);
-    load_row(vec + VEC_DQ + q * N, dqo);
 
     // ---------------- task-space error of device g (lane g < NDEV of the group), part 1 -------------------------
     // Done here, while the first M chunk is still in flight: quaternion -> sxyz Euler error, velocity limit and
     // gains need only ee/tgt/gains.  The rows that depend on dx (branch B) are finished after the J phase.
-    float kvn = 0.f;
-    if (p.cfgflags & IRLOSC_NULLSPACE) kvn = p.null_kv[p.gains_per_instance ? b : 0];
-    const float* gbase = p.gains + (p.gains_per_instance ? (size_t)b * NDEV * IRLOSC_GAIN_WORDS : 0);
+    // (gains pointer and null-space gain are re-derived where they are used: carrying them through the
+    //  register-critical phases spilled them to scratch)
+    auto gains_ptr = [&]() { return p.gains + (p.gains_per_instance ? (size_t)b * NDEV * IRLOSC_GAIN_WORDS : 0); };
     float e6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float kv_own = 0.f;
     if (g < NDEV) {
         const DevMeta dm = p.dev[g];
-        const float* gg = gbase + g * IRLOSC_GAIN_WORDS;
+        const float* gg = gains_ptr() + g * IRLOSC_GAIN_WORDS;
         float gl[IRLOSC_GAIN_WORDS];
 #pragma unroll
         for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) gl[i] = gg[i];
-        kv_own = gl[1];
         float ee[7], tg[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
@@ -260,7 +261,6 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
             if (dm.dofmask & (1u << i)) { wl0[dm.row0 + cnt] = e6[i]; ++cnt; }
         }
     }
-    asm volatile("" : "+v"(kv_own), "+v"(kvn));
     __builtin_amdgcn_sched_barrier(0);
 
     // ---------------- stream M: Cholesky column by column -------------------------------------------------
@@ -312,10 +312,8 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
                 }
             }
             float d = gbcast<G>(sget(acc, sj), gj);
-            const bool notpd = !(d > 0.f);
-            flags |= notpd ? IRLOSC_FLAG_M_NOT_PD : 0u;
-            const float dfix = (d == d && d != 0.f) ? fabsf(d) : 1.f;
-            d = notpd ? dfix : d;
+            flags |= !(d > 0.f) ? IRLOSC_FLAG_M_NOT_PD : 0u;   // also catches NaN
+            d = fmaxf(d, 1e-30f);                               // keeps the factorisation finite; the flag tells
             const float di = __builtin_amdgcn_rsqf(d);
             const v2f di2 = v2f{di, di};
             const bool own_row = (g == gj);
@@ -355,9 +353,20 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     }
     // Row-scale the factor once, L'[i][c] = L[i][c] / L[i][i]: the substitutions below then need no per-column
     // multiply (y_c is the running b'_c itself) and no final scaling.
+    // Row 24 (the scalar slot, real only on lane 0): its row-scaled entries are handed out over the group,
+    // lane g keeping L'[24][G m + g].  In the substitutions lane g then multiplies them with ITS OWN y values
+    // (slot m of its b'), one FMA per G columns and no broadcast, instead of 24 FMAs on 24 registers per lane.
+    float Lq[24 / G];
     if (ODD) {
+        const float d24 = gbcast<G>(dinv.o, 0);
 #pragma unroll
-        for (int c = 0; c < 24; ++c) Lo[c] *= dinv.o;
+        for (int c = 0; c < 24; ++c) {
+            const float v = gbcast<G>(Lo[c], 0) * d24;
+            if (c % G == 0) Lq[c / G] = 0.f;
+            Lq[c / G] = (g == c % G) ? v : Lq[c / G];
+        }
+#pragma unroll
+        for (int m = 0; m < 24 / G; ++m) asm volatile("" : "+v"(Lq[m]));
     }
     IRLOSC_TS(2);
     // park Mdq in LDS (own real rows)
@@ -374,6 +383,8 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
         float* buf = ring + (n % NB) * SLOT;
         wait_chunks<CI>((NT - 1 - n) < (NB - 1) ? (NT - 1 - n) : (NB - 1));
         const int jstride = jc < 3 ? GE::STR4 : N;
+        Row dqc;                                   // dq of the own rows: re-read per chunk (7 registers saved)
+        load_row(vec + VEC_DQ + q * N, dqc);
         const int R = jc < 3 ? 4 : 1;
         Row bb[4];
 #pragma unroll
@@ -381,9 +392,9 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
             load_row(buf + q * jstride + rr * N, bb[rr]);
             v2f dx2 = v2f{0.f, 0.f};
 #pragma unroll
-            for (int pp = 0; pp < P; ++pp) dx2 = __builtin_elementwise_fma(bb[rr].p[pp], dqo.p[pp], dx2);
+            for (int pp = 0; pp < P; ++pp) dx2 = __builtin_elementwise_fma(bb[rr].p[pp], dqc.p[pp], dx2);
             float dxs = dx2.x + dx2.y;
-            if (ODD) dxs = fmaf(bb[rr].o, dqo.o, dxs);
+            if (ODD) dxs = fmaf(bb[rr].o, dqc.o, dxs);
             dxs = gsum<G>(dxs);
             if (g == 0) xq[25 + jc * 4 + rr] = dxs;
 #pragma unroll
@@ -393,6 +404,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
         // column-oriented substitution: y_c = b_c / L[c][c] (owner lane), then b_i -= L[i][c] y_c
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
+            float part24 = 0.f;                  // this lane's share of sum_c L'[24][c] y_c
 #pragma unroll
             for (int c = 0; c < 24; ++c) {
                 const int sc = c / G, gc = c % G, pc = sc >> 1;
@@ -400,10 +412,14 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
                 const v2f yc = v2f{ycs, ycs};
 #pragma unroll
                 for (int pp = pc; pp < P; ++pp) bb[rr].p[pp] = __builtin_elementwise_fma(Lp[pp][c], yc, bb[rr].p[pp]);
-                if (ODD) {
-                    bb[rr].o = fmaf(Lo[c], ycs, bb[rr].o);
-                    asm volatile("" : "+v"(bb[rr].o), "+v"(bb[rr].p[P - 1]));
+                if (ODD && gc == G - 1) {        // slot sc is final in every lane of the group now
+                    part24 = fmaf(Lq[sc], sget(bb[rr], sc), part24);
+                    asm volatile("" : "+v"(part24), "+v"(bb[rr].p[P - 1]));
                 }
+            }
+            if (ODD) {
+                const float y24 = bb[rr].o - gsum<G>(part24);            // b'_24 sits on lane 0 only
+                bb[rr].o = lastpad ? 0.f : y24;
             }
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) Y[jc * 4 + rr].p[pp] = bb[rr].p[pp];
@@ -428,9 +444,12 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     float* wls = vec + VEC_W + q * K;
     int brA_own = 1;
     __builtin_amdgcn_wave_barrier();
+    float kvn = 0.f;
+    if (p.cfgflags & IRLOSC_NULLSPACE) kvn = p.null_kv[p.gains_per_instance ? b : 0];
     if (g < NDEV) {
         const DevMeta dm = p.dev[g];
-        const float* gg = gbase + g * IRLOSC_GAIN_WORDS;
+        const float* gg = gains_ptr() + g * IRLOSC_GAIN_WORDS;
+        kv_own = gg[1];
         float tv[6];
         bool all_nonzero = has_tv;
 #pragma unroll
@@ -471,6 +490,8 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     IRLOSC_TS(4);
     // ---------------- A = Y^T Y (lower), replicated in the group -----------------------------------------------
     float A[K][K];
+    // row by row: first all partial dots of the row, then the butterfly steps over the whole row, so that a
+    // DPP add never has to wait on the instruction right before it (rows 0..2 are too short to hide it)
 #pragma unroll
     for (int r = 0; r < K; ++r) {
 #pragma unroll
@@ -480,7 +501,21 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
             for (int pp = 1; pp < P; ++pp) a2 = __builtin_elementwise_fma(Y[r].p[pp], Y[s2].p[pp], a2);
             float a = a2.x + a2.y;
             if (ODD) a = fmaf(Y[r].o, Y[s2].o, a);
-            A[r][s2] = gsum<G>(a);
+            A[r][s2] = a;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 <= r; ++s2) asm volatile("" : "+v"(A[r][s2]));
+#pragma unroll
+        for (int s2 = 0; s2 <= r; ++s2) A[r][s2] += dpp_f<0xB1>(A[r][s2]);      // quad_perm [1,0,3,2]
+#pragma unroll
+        for (int s2 = 0; s2 <= r; ++s2) asm volatile("" : "+v"(A[r][s2]));
+#pragma unroll
+        for (int s2 = 0; s2 <= r; ++s2) A[r][s2] += dpp_f<0x4E>(A[r][s2]);      // quad_perm [2,3,0,1]
+        if (G == 8) {
+#pragma unroll
+            for (int s2 = 0; s2 <= r; ++s2) asm volatile("" : "+v"(A[r][s2]));
+#pragma unroll
+            for (int s2 = 0; s2 <= r; ++s2) A[r][s2] += dpp_f<0x141>(A[r][s2]); // row_half_mirror
         }
 #pragma unroll
         for (int s2 = 0; s2 <= r; ++s2) asm volatile("" : "+v"(A[r][s2]));
