@@ -30,15 +30,24 @@ struct irlosc_ctx {
     // resident inputs, one set per slot
     std::vector<void*> dM, dJ, ddq, dbias, dee, dwrench, dtgt, dtvel;
     std::vector<int> has_wrench, has_tvel, uploaded, targeted;
-    void* du = nullptr;
-    uint32_t* dflags = nullptr;
+    // Outputs and the stage-2 hand-off buffers exist twice: irlosc_step_resident pipelines consecutive steps on
+    // the group path (stage 2 of step i rides in the stage-1 launch of step i+1), alternating the two sets.
+    void* du2[2] = {nullptr, nullptr};
+    uint32_t* dflags2[2] = {nullptr, nullptr};
+    float* dside2[2] = {nullptr, nullptr};
+    int32_t* dwl2[2] = {nullptr, nullptr};
+    int32_t* dwc2[2] = {nullptr, nullptr};
+    int cur = 0;                       // output set written by the most recent step
+    bool pending = false;              // a deferred stage 2 (of the step that wrote set `pending_set`) is outstanding
+    bool defer_next = false;           // set by irlosc_step_resident around its launches
+    int pending_nfast = 0;
+    int pending_set = 0;
+    KParams<float> pending_p{};
+    void* du = nullptr;                // = du2[cur]
+    uint32_t* dflags = nullptr;        // = dflags2[cur]
     void* dgains = nullptr;   // [nb][ndev][12] in dtype
     void* dnullkv = nullptr;  // [nb]
     int gains_nb = 0;
-    int32_t* dworklist = nullptr;   // [max_batch] instances flagged by the group kernel's first stage
-    int32_t* dworklist2 = nullptr;  // [max_batch] instances its second stage hands to the generic kernel
-    int32_t* dworkcount = nullptr;  // [2]
-    float* dside = nullptr;         // [104][max_batch] A and w of flagged instances
     unsigned long long* ddbg = nullptr;  // IRLOSC_PHASE_TIMING=1: 8 cycle stamps per stage-1 wave
     int kernel = IRLOSC_KERNEL_GENERIC;
     bool stage1_only = false; // set only inside irlosc_time_dominant_kernel
@@ -115,15 +124,16 @@ static int validate(const irlosc_cfg* c, int* k_out) {
 static void free_all(irlosc_ctx* c) {
     auto fr = [](std::vector<void*>& v) { for (void* p : v) if (p) (void)hipFree(p); v.clear(); };
     fr(c->dM); fr(c->dJ); fr(c->ddq); fr(c->dbias); fr(c->dee); fr(c->dwrench); fr(c->dtgt); fr(c->dtvel);
-    if (c->du) (void)hipFree(c->du);
-    if (c->dflags) (void)hipFree(c->dflags);
+    for (int k = 0; k < 2; ++k) {
+        if (c->du2[k]) (void)hipFree(c->du2[k]);
+        if (c->dflags2[k]) (void)hipFree(c->dflags2[k]);
+        if (c->dside2[k]) (void)hipFree(c->dside2[k]);
+        if (c->dwl2[k]) (void)hipFree(c->dwl2[k]);
+        if (c->dwc2[k]) (void)hipFree(c->dwc2[k]);
+    }
     if (c->dgains) (void)hipFree(c->dgains);
     if (c->dnullkv) (void)hipFree(c->dnullkv);
-    if (c->dworklist) (void)hipFree(c->dworklist);
-    if (c->dworklist2) (void)hipFree(c->dworklist2);
-    if (c->dside) (void)hipFree(c->dside);
     if (c->ddbg) (void)hipFree(c->ddbg);
-    if (c->dworkcount) (void)hipFree(c->dworkcount);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -156,17 +166,22 @@ static int create_impl(irlosc_ctx* c) {
     c->has_tvel.assign(g.n_slots, 0);
     c->uploaded.assign(g.n_slots, 0);
     c->targeted.assign(g.n_slots, 0);
-    HIPCHK(nullptr, hipMalloc(&c->du, B * n * e));
-    HIPCHK(nullptr, hipMalloc((void**)&c->dflags, B * sizeof(uint32_t)));
+    for (int k2 = 0; k2 < 2; ++k2) {
+        HIPCHK(nullptr, hipMalloc(&c->du2[k2], B * n * e));
+        HIPCHK(nullptr, hipMalloc((void**)&c->dflags2[k2], B * sizeof(uint32_t)));
+        HIPCHK(nullptr, hipMalloc((void**)&c->dwl2[k2], B * sizeof(int32_t)));
+        HIPCHK(nullptr, hipMalloc((void**)&c->dwc2[k2], 64 * sizeof(int32_t)));
+        if (c->kernel == IRLOSC_KERNEL_GROUP)
+            HIPCHK(nullptr, hipMalloc((void**)&c->dside2[k2], (B + 16 * 64) * 104 * sizeof(float)));
+        HIPCHK(nullptr, hipMemsetAsync(c->dflags2[k2], 0, B * sizeof(uint32_t), c->stream));
+        HIPCHK(nullptr, hipMemsetAsync(c->dwc2[k2], 0, 64 * sizeof(int32_t), c->stream));
+    }
+    c->du = c->du2[0];
+    c->dflags = c->dflags2[0];
     HIPCHK(nullptr, hipMalloc(&c->dgains, B * nd * IRLOSC_GAIN_WORDS * e));
     HIPCHK(nullptr, hipMalloc(&c->dnullkv, B * e));
-    HIPCHK(nullptr, hipMalloc((void**)&c->dworklist, (B + 16 * 64) * sizeof(int32_t)));
-    HIPCHK(nullptr, hipMalloc((void**)&c->dworklist2, B * sizeof(int32_t)));
-    HIPCHK(nullptr, hipMalloc((void**)&c->dworkcount, 64 * sizeof(int32_t)));
-    if (c->kernel == IRLOSC_KERNEL_GROUP) HIPCHK(nullptr, hipMalloc((void**)&c->dside, (B + 16 * 64) * 104 * sizeof(float)));
     if (c->kernel == IRLOSC_KERNEL_GROUP && getenv("IRLOSC_PHASE_TIMING"))
         HIPCHK(nullptr, hipMalloc((void**)&c->ddbg, (B / 16 + 1) * 8 * sizeof(unsigned long long)));
-    HIPCHK(nullptr, hipMemsetAsync(c->dflags, 0, B * sizeof(uint32_t), c->stream));
     HIPCHK(nullptr, hipStreamSynchronize(c->stream));
     return IRLOSC_OK;
 }
@@ -323,6 +338,31 @@ static void fill_params(const irlosc_ctx* c, KParams<T>& p, int B, const void* M
     }
 }
 
+#ifndef IRLOSC_NO_GROUP_KERNEL
+static GroupScratch scratch_for(const irlosc_ctx* c, int set) {
+    GroupScratch gs{};
+    gs.worklist2 = c->dwl2[set];
+    gs.counts = c->dwc2[set];
+    gs.side = c->dside2[set];
+    gs.side_cap = c->cfg.max_batch + 16 * 64;
+    gs.lanes_per_instance = c->lanes;
+    gs.ring_depth = c->ring;
+    return gs;
+}
+
+// Run the stage 2 that a pipelined irlosc_step_resident left outstanding (no-op otherwise).
+static int flush_pending(irlosc_ctx* c, hipStream_t st) {
+    if (!c->pending) return IRLOSC_OK;
+    c->pending = false;
+    const GroupScratch gs = scratch_for(c, c->pending_set);
+    int rc = launch_group_stage2<float>(c->pending_p, make_s2(c->pending_p, c->pending_nfast, gs), st);
+    if (rc) return fail(c, IRLOSC_ERR_HIP, "stage-2 launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return IRLOSC_OK;
+}
+#else
+static int flush_pending(irlosc_ctx*, hipStream_t) { return IRLOSC_OK; }
+#endif
+
 template <typename T>
 static int launch_t(irlosc_ctx* c, int B, const void* M, const void* J, const void* dq, const void* bias,
                     const void* ee, const void* tgt, const void* tvel, const void* wrench, void* u,
@@ -331,10 +371,35 @@ static int launch_t(irlosc_ctx* c, int B, const void* M, const void* J, const vo
     fill_params<T>(c, p, B, M, J, dq, bias, ee, tgt, tvel, wrench, u, flags);
 #ifndef IRLOSC_NO_GROUP_KERNEL
     if (c->kernel == IRLOSC_KERNEL_GROUP) {
-        GroupScratch gs{c->dworklist, c->dworklist2, c->dworkcount, c->dside, c->cfg.max_batch + 16 * 64, c->lanes, c->ring, c->stage1_only};
-        int rc = launch_group<T>(p, gs, st);
-        if (rc) return fail(c, IRLOSC_ERR_HIP, "group kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-        return IRLOSC_OK;
+        if constexpr (sizeof(T) == 4) {
+            // which output set does `u` belong to?  (caller-owned buffers of irlosc_step_device use set `cur`)
+            const int set = (u == c->du2[1]) ? 1 : (u == c->du2[0] ? 0 : c->cur);
+            GroupScratch gs = scratch_for(c, set);
+            gs.stage1_only = c->stage1_only;
+            gs.defer_stage2 = c->defer_next && !c->stage1_only;
+            if (c->pending && c->pending_set != set && !c->stage1_only) {      // previous step's stage 2 rides along
+                const GroupScratch gp = scratch_for(c, c->pending_set);
+                gs.have_prev = true;
+                gs.prev = make_s2(c->pending_p, c->pending_nfast, gp);
+                gs.prev_p = c->pending_p;
+                c->pending = false;
+            } else if (c->pending && !c->stage1_only) {
+                int rc0 = flush_pending(c, st);                              // same set: must finish first
+                if (rc0) return rc0;
+            }
+            int rc = launch_group<float>(p, gs, st);
+            if (rc) return fail(c, IRLOSC_ERR_HIP, "group kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+            if (gs.defer_stage2) {
+                const int tile1 = 64 / (c->lanes == 8 ? 8 : 4);
+                c->pending = true;
+                c->pending_set = set;
+                c->pending_nfast = (B / tile1) * tile1;
+                c->pending_p = p;
+            }
+            return IRLOSC_OK;
+        } else {
+            return fail(c, IRLOSC_ERR_ARG, "no fp64 group kernel");
+        }
     }
 #endif
     size_t smem = generic_smem_bytes<T>(p.n, p.k, p.ndev);
@@ -400,11 +465,23 @@ extern "C" int irlosc_step_resident(irlosc_ctx* c, int32_t first_slot, int32_t B
     if (rc) return rc;
     if (iters < 1) return fail(c, IRLOSC_ERR_ARG, "iters must be >= 1");
     HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    // Group path: consecutive steps are pipelined - step i writes output set i % 2 and its stage 2 rides in the
+    // stage-1 launch of step i + 1 (the last one is flushed below), all on one stream.
+    const bool pipe = c->kernel == IRLOSC_KERNEL_GROUP && !getenv("IRLOSC_NO_PIPELINE");
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     for (int i = 0; i < iters; ++i) {
+        if (pipe) {
+            c->cur ^= 1;
+            c->du = c->du2[c->cur];
+            c->dflags = c->dflags2[c->cur];
+        }
+        c->defer_next = pipe;
         rc = launch_slot(c, (first_slot + i) % c->cfg.n_slots, B);
+        c->defer_next = false;
         if (rc) return rc;
     }
+    rc = flush_pending(c, c->stream);
+    if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));
     float ms = 0.f;

@@ -174,10 +174,6 @@ __device__ __forceinline__ const float* jrow_ptr(const float* ring, const float*
 
 }  // namespace grp
 
-}  // namespace irlosc
-#include "osc_group_stage1.hpp"
-namespace irlosc {
-
 // ---------------------------------------------------------------------------------------------------------
 // Second stage for the group kernel: truncated pseudo-inverse solve t = pinv(A, rcond 1e-5) w for the
 // instances the first stage could not certify (osc.py:51-55 when |det A| < 1e-4 and cond(A) may exceed
@@ -192,19 +188,32 @@ namespace irlosc {
 //   * t = P (A + sigma I)^-1 P w with P the projector off those eigenvectors (one refinement step
 //     when sigma > 0), which equals sum over the kept eigenpairs of v v^T w / lambda.
 // Instances with more than 3 sub-threshold eigenvalues are handed to the generic kernel (Jacobi).
+// What stage 2 needs of a step: its J, its outputs and its hand-off buffers.
+struct S2Args {
+    const float* J;
+    float* u;
+    uint32_t* flags;
+    int nfast;                 // instances handled by stage 1 (multiple of its tile); 0 = nothing pending
+    const float* side;
+    int side_cap;
+    int32_t* worklist2;
+    int32_t* workcount2;
+};
+
+// Body of stage 2 for block `blk` (64 instances scanned); `list` = 64 ints of LDS.
 template <int K>
-__global__ __launch_bounds__(64) void osc_group_stage2_f32(const KParams<float> p, int nfast,
-                                                          const float* __restrict__ side, int side_cap,
-                                                          int32_t* __restrict__ worklist2, int32_t* __restrict__ workcount2) {
+__device__ __forceinline__ void stage2_body(const S2Args a, int blk, int32_t* list) {
     using namespace grp;
     constexpr int NA = K * (K + 1) / 2;
     constexpr int SPAN = 64;                      // instances scanned per block (~7 flagged at an 11 % rate, so
-    __shared__ int32_t list[SPAN];                // one round of 16 almost always; the kernel is latency-bound)
+                                                  // one round of 16 almost always; the work is latency-bound)
+    const float* __restrict__ side = a.side;
+    const int side_cap = a.side_cap;
     const int lane = threadIdx.x, g = lane & 3, q = lane >> 2;
     // compaction in the block: no global worklist, no atomics (stage 1 left IRLOSC_FLAG_EIGEN_PATH in flags[])
-    const int base = blockIdx.x * SPAN;
+    const int base = blk * SPAN;
     const int i0 = base + lane;
-    const bool f0 = i0 < nfast && (p.flags[i0] & IRLOSC_FLAG_EIGEN_PATH);
+    const bool f0 = i0 < a.nfast && (a.flags[i0] & IRLOSC_FLAG_EIGEN_PATH);
     const unsigned long long m0 = __ballot(f0);
     const unsigned long long below = (1ull << lane) - 1ull;
     if (f0) list[__popcll(m0 & below)] = i0;
@@ -402,7 +411,7 @@ __global__ __launch_bounds__(64) void osc_group_stage2_f32(const KParams<float> 
         uint32_t fl = (m > 0 ? IRLOSC_FLAG_TRUNCATED : 0u);
         bool bad = false;
         if (live) {
-            const float* Jb = p.J + (size_t)b * K * N;
+            const float* Jb = a.J + (size_t)b * K * N;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const int i = 4 * s + g;
@@ -410,8 +419,8 @@ __global__ __launch_bounds__(64) void osc_group_stage2_f32(const KParams<float> 
                     float acc = 0.f;
 #pragma unroll
                     for (int r = 0; r < K; ++r) acc = fmaf(Jb[r * N + i], t[r], acc);
-                    const float uu = p.u[(size_t)b * N + i] - acc;
-                    p.u[(size_t)b * N + i] = uu;
+                    const float uu = a.u[(size_t)b * N + i] - acc;
+                    a.u[(size_t)b * N + i] = uu;
                     bad = bad || !t_finite(uu);
                 }
             }
@@ -419,19 +428,28 @@ __global__ __launch_bounds__(64) void osc_group_stage2_f32(const KParams<float> 
         fl |= bad ? IRLOSC_FLAG_NONFINITE : 0u;
         fl = qor(fl);
         if (live && g == 0) {
-            p.flags[b] |= fl;
-            if (giveup) worklist2[atomicAdd(workcount2, 1)] = b;
+            a.flags[b] |= fl;
+            if (giveup) a.worklist2[atomicAdd(a.workcount2, 1)] = b;
         }
     }
 }
+
+template <int K>
+__global__ __launch_bounds__(64) void osc_group_stage2_f32(const S2Args a) {
+    __shared__ int32_t list[64];
+    stage2_body<K>(a, blockIdx.x, list);
+}
+
+}  // namespace irlosc
+#include "osc_group_stage1.hpp"
+namespace irlosc {
 
 inline bool group_kernel_supports(int dtype, int n, int k, int ndev) {
     return dtype == IRLOSC_F32 && n == 25 && ((k == 13 && ndev == 3) || (k == 12 && ndev == 2));
 }
 
-// Device scratch owned by the context for the two-stage group path.
+// Device scratch owned by the context for the two-stage group path (one set per output buffer set).
 struct GroupScratch {
-    int32_t* worklist;    // unused (stage 2 compacts inside each block)
     int32_t* worklist2;   // [max_batch] instances stage 2 hands to the generic kernel
     int32_t* counts;      // [1] length of worklist2
     float* side;          // [(K(K+1)/2 + K)][side_cap]: A and w of flagged instances, indexed by instance
@@ -439,14 +457,45 @@ struct GroupScratch {
     int lanes_per_instance;   // 4 or 8 (stage-1 kernel variant)
     int ring_depth;           // 2 or 3 LDS ring slots (G = 4)
     bool stage1_only;         // roofline timing: launch the dominant kernel alone
+    bool defer_stage2;        // pipelined steps: leave this step's stage 2 to the next launch (or to a flush)
+    bool have_prev;           // a previous step's stage 2 is pending and rides in this launch
+    S2Args prev;              // ... its arguments
+    KParams<float> prev_p;    // ... and its full parameters (for the give-up list -> generic kernel)
 };
+
+inline S2Args make_s2(const KParams<float>& p, int nfast, const GroupScratch& gs) {
+    return S2Args{p.J, p.u, p.flags, nfast, gs.side, gs.side_cap, gs.worklist2, gs.counts};
+}
 
 template <typename T>
 int launch_group(const KParams<T>& p, const GroupScratch& gs, hipStream_t st);
+template <typename T>
+int launch_group_stage2(const KParams<T>& p, const S2Args& a, hipStream_t st);
 
 template <>
 inline int launch_group<double>(const KParams<double>&, const GroupScratch&, hipStream_t) {
     return (int)hipErrorNotSupported;
+}
+template <>
+inline int launch_group_stage2<double>(const KParams<double>&, const S2Args&, hipStream_t) {
+    return (int)hipErrorNotSupported;
+}
+
+// Standalone stage 2 (+ the generic kernel over its give-up list) for the step described by (p, a).
+template <>
+inline int launch_group_stage2<float>(const KParams<float>& p, const S2Args& a, hipStream_t st) {
+    if (a.nfast <= 0) return 0;
+    const int g2 = (a.nfast + 63) / 64;
+    if (p.k == 13) hipLaunchKernelGGL((osc_group_stage2_f32<13>), dim3(g2), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((osc_group_stage2_f32<12>), dim3(g2), dim3(64), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    KParams<float> pw = p;                 // instances stage 2 gave up on (> 3 sub-threshold eigenvalues,
+    pw.index = a.worklist2;                // normally none): a handful of grid-strided generic blocks
+    pw.index_count = a.workcount2;
+    pw.b0 = 0;
+    hipLaunchKernelGGL(osc_generic_kernel<float>, dim3(16), dim3(64), generic_smem_bytes<float>(p.n, p.k, p.ndev), st, pw);
+    return (int)hipGetLastError();
 }
 
 template <>
@@ -456,26 +505,41 @@ inline int launch_group<float>(const KParams<float>& p, const GroupScratch& gs, 
     const int tiles = p.B / TILE1;
     const int nfast = tiles * TILE1;
     const int rem = p.B - nfast;
-    int32_t* wc2 = gs.counts;              // length of worklist2; zeroed by block 0 of stage 1
+    int32_t* wc2 = gs.counts;              // length of worklist2; zeroed by the first stage-1 block
     hipError_t e;
+    const bool ride = gs.have_prev && gs.prev.nfast > 0 && !gs.stage1_only;
+    const int n2 = ride ? (gs.prev.nfast + 63) / 64 : 0;
     if (tiles > 0) {
-        const int g2 = (nfast + 63) / 64;
+        const dim3 grid(tiles + n2);
+#define IRLOSC_LAUNCH1(GG, KK, ND, NBB) \
+        hipLaunchKernelGGL((osc_group_kernel_f32<GG, KK, ND, NBB>), grid, dim3(64), 0, st, p, gs.side, gs.side_cap, wc2, gs.prev, n2)
         if (p.k == 13 && p.ndev == 3) {
-            if (G == 8) hipLaunchKernelGGL((osc_group_kernel_f32<8, 13, 3, 3>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap, wc2);
-            else if (gs.ring_depth == 3) hipLaunchKernelGGL((osc_group_kernel_f32<4, 13, 3, 3>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap, wc2);
-            else hipLaunchKernelGGL((osc_group_kernel_f32<4, 13, 3, 2>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap, wc2);
-            if (!gs.stage1_only) hipLaunchKernelGGL((osc_group_stage2_f32<13>), dim3(g2), dim3(64), 0, st, p, nfast, gs.side, gs.side_cap, gs.worklist2, wc2);
+            if (G == 8) IRLOSC_LAUNCH1(8, 13, 3, 3);
+            else if (gs.ring_depth == 3) IRLOSC_LAUNCH1(4, 13, 3, 3);
+            else IRLOSC_LAUNCH1(4, 13, 3, 2);
         } else if (p.k == 12 && p.ndev == 2) {
-            if (G == 8) hipLaunchKernelGGL((osc_group_kernel_f32<8, 12, 2, 3>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap, wc2);
-            else if (gs.ring_depth == 3) hipLaunchKernelGGL((osc_group_kernel_f32<4, 12, 2, 3>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap, wc2);
-            else hipLaunchKernelGGL((osc_group_kernel_f32<4, 12, 2, 2>), dim3(tiles), dim3(64), 0, st, p, gs.side, gs.side_cap, wc2);
-            if (!gs.stage1_only) hipLaunchKernelGGL((osc_group_stage2_f32<12>), dim3(g2), dim3(64), 0, st, p, nfast, gs.side, gs.side_cap, gs.worklist2, wc2);
+            if (G == 8) IRLOSC_LAUNCH1(8, 12, 2, 3);
+            else if (gs.ring_depth == 3) IRLOSC_LAUNCH1(4, 12, 2, 3);
+            else IRLOSC_LAUNCH1(4, 12, 2, 2);
         } else return (int)hipErrorNotSupported;
+#undef IRLOSC_LAUNCH1
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
+    } else if (ride) {
+        int rc = launch_group_stage2<float>(gs.prev_p, gs.prev, st);
+        if (rc) return rc;
     }
     if (gs.stage1_only) return 0;
     const size_t smem = generic_smem_bytes<float>(p.n, p.k, p.ndev);
+    if (ride && tiles > 0) {               // give-up list of the previous step (its stage 2 just ran in the fused launch)
+        KParams<float> pw = gs.prev_p;
+        pw.index = gs.prev.worklist2;
+        pw.index_count = gs.prev.workcount2;
+        pw.b0 = 0;
+        hipLaunchKernelGGL(osc_generic_kernel<float>, dim3(16), dim3(64), smem, st, pw);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
     if (rem > 0) {   // ragged tail (< TILE instances): generic kernel on the last instances
         KParams<float> pt = p;
         pt.index = nullptr;
@@ -484,17 +548,7 @@ inline int launch_group<float>(const KParams<float>& p, const GroupScratch& gs, 
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
-    if (tiles > 0) {
-        // instances stage 2 gave up on (> 3 sub-threshold eigenvalues, normally none): generic kernel,
-        // a handful of grid-strided blocks that exit at once when the list is empty
-        KParams<float> pw = p;
-        pw.index = gs.worklist2;
-        pw.index_count = wc2;
-        pw.b0 = 0;
-        hipLaunchKernelGGL(osc_generic_kernel<float>, dim3(16), dim3(64), smem, st, pw);
-        e = hipGetLastError();
-        if (e != hipSuccess) return (int)e;
-    }
+    if (!gs.defer_stage2 && tiles > 0) return launch_group_stage2<float>(p, make_s2(p, nfast, gs), st);
     return 0;
 }
 

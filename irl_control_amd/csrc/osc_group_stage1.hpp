@@ -10,6 +10,10 @@
 #include "osc_common.hpp"
 
 namespace irlosc {
+
+struct S2Args;
+template <int K> __device__ __forceinline__ void stage2_body(const S2Args a, int blk, int32_t* list);
+
 namespace grp {
 
 template <int G> struct Geo {
@@ -126,7 +130,8 @@ template <int PIECES> __device__ __forceinline__ void dmalinear(const float* src
 
 template <int G, int K, int NDEV, int NB>
 __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<float> p, float* __restrict__ side, int side_cap,
-                                                             int32_t* __restrict__ giveup_count) {
+                                                             int32_t* __restrict__ giveup_count,
+                                                             const S2Args prev, int n2) {
     using namespace grp;
     using GE = Geo<G>;
     constexpr int TILE = GE::TILE, P = GE::P, NS = GE::NS, LS = GE::LS, CI = GE::CI;
@@ -149,9 +154,16 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     __shared__ __attribute__((aligned(16))) float ring[NB * SLOT];
     __shared__ __attribute__((aligned(16))) float vec[VEC_END];
 
+    // Fused launch: the first n2 blocks run STAGE 2 OF THE PREVIOUS STEP (its own output set), the rest stage 1
+    // of this step.  Stage 2 alone keeps one latency-bound wave per SIMD busy for ~28 us with the other slot
+    // idle; inside this launch its waves share the SIMDs with stage-1 waves instead.
+    if ((int)blockIdx.x < n2) {
+        stage2_body<K>(prev, blockIdx.x, reinterpret_cast<int32_t*>(ring));
+        return;
+    }
     const int lane = threadIdx.x;
     const int g = lane % G, q = lane / G;
-    const int tile = blockIdx.x;
+    const int tile = (int)blockIdx.x - n2;
     const int b = tile * TILE + q;
     const size_t t0 = (size_t)tile * TILE;
     const bool has_tv = p.tvel != nullptr;
@@ -159,7 +171,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     unsigned long long ts[8];
 #define IRLOSC_TS(i) ts[i] = p.dbg ? __builtin_readcyclecounter() : 0ull
     IRLOSC_TS(0);
-    if (blockIdx.x == 0 && lane == 0) *giveup_count = 0;     // consumed by stage 2, which runs after this kernel
+    if (tile == 0 && lane == 0) *giveup_count = 0;           // consumed by this step's stage 2, which runs later
 
     // ---------------- prologue --------------------------------------------------------------------------------
     // DMA issue order (CI instructions per chunk, retired in order):
@@ -705,7 +717,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     IRLOSC_TS(7);
     if (p.dbg && lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) p.dbg[(size_t)blockIdx.x * 8 + i] = ts[i];
+        for (int i = 0; i < 8; ++i) p.dbg[(size_t)tile * 8 + i] = ts[i];
     }
 #undef IRLOSC_TS
 }
