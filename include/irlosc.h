@@ -126,10 +126,10 @@ int irlosc_step(irlosc_ctx* ctx, int32_t slot, int32_t B, void* u_host, uint32_t
 int irlosc_step_resident(irlosc_ctx* ctx, int32_t first_slot, int32_t B, int32_t iters,
                          float* ms_total, float* ms_kernel_avg);
 
-/* Roofline support: time ONLY the dominant kernel of a step (the stage-1 group kernel, or the generic
- * kernel when that is what irlosc_step launches): `iters` back-to-back launches of it on slot `slot`,
- * HIP events on the library's stream, *ms_avg = mean duration of one launch.  Results in the output
- * buffers are those of the dominant kernel alone (incomplete for instances that need stage 2). */
+/* Roofline support: mean duration of the DOMINANT kernel launch of a step, measured live with one HIP event
+ * pair per launch on the library's stream, over `iters` (<= 256) steps run exactly like
+ * irlosc_step_resident.  Group path: the fused launch (stage 1 of step i + the riding stage 2 of step i-1);
+ * generic path: the generic kernel.  Outputs are complete, as after irlosc_step_resident. */
 int irlosc_time_dominant_kernel(irlosc_ctx* ctx, int32_t slot, int32_t B, int32_t iters, float* ms_avg);
 
 int irlosc_download(irlosc_ctx* ctx, int32_t B, void* u_host, uint32_t* flags_host);

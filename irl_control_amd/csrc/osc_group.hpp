@@ -461,6 +461,7 @@ struct GroupScratch {
     bool have_prev;           // a previous step's stage 2 is pending and rides in this launch
     S2Args prev;              // ... its arguments
     KParams<float> prev_p;    // ... and its full parameters (for the give-up list -> generic kernel)
+    hipEvent_t ev_begin, ev_end;   // optional: recorded right before / after the dominant (stage-1 / fused) launch
 };
 
 inline S2Args make_s2(const KParams<float>& p, int nfast, const GroupScratch& gs) {
@@ -511,6 +512,7 @@ inline int launch_group<float>(const KParams<float>& p, const GroupScratch& gs, 
     const int n2 = ride ? (gs.prev.nfast + 63) / 64 : 0;
     if (tiles > 0) {
         const dim3 grid(tiles + n2);
+        if (gs.ev_begin && (e = hipEventRecord(gs.ev_begin, st)) != hipSuccess) return (int)e;
 #define IRLOSC_LAUNCH1(GG, KK, ND, NBB) \
         hipLaunchKernelGGL((osc_group_kernel_f32<GG, KK, ND, NBB>), grid, dim3(64), 0, st, p, gs.side, gs.side_cap, wc2, gs.prev, n2)
         if (p.k == 13 && p.ndev == 3) {
@@ -525,6 +527,7 @@ inline int launch_group<float>(const KParams<float>& p, const GroupScratch& gs, 
 #undef IRLOSC_LAUNCH1
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
+        if (gs.ev_end && (e = hipEventRecord(gs.ev_end, st)) != hipSuccess) return (int)e;
     } else if (ride) {
         int rc = launch_group_stage2<float>(gs.prev_p, gs.prev, st);
         if (rc) return rc;
