@@ -1,30 +1,22 @@
-// Throughput OSC kernel for the Dual-UR5 shapes (n = 25): FOUR LANES PER ROBOT INSTANCE.
+// Throughput OSC path for the Dual-UR5 shapes (n = 25): FOUR LANES PER ROBOT INSTANCE.
 //
 // Why not one wavefront per instance: with n = 25 and k <= 13 a 64-lane wave is 60-80 % idle in
 // every phase and every operand has to be broadcast, so the VALU issue rate — not HBM — bounds
 // the generic kernel at ~5e7 steps/s.  Here a wave carries 16 instances; the 4 lanes of a quad own
 // the joint rows i = 4s + g (slot s = 0..6, g = lane & 3; rows 25..27 are zero padding) and keep
-// their rows of the Cholesky factor L, of Y = L^-1 J^T and of J in VGPRs with COMPILE-TIME indices
-// (everything below is fully unrolled).  The only cross-lane traffic is quad-local DPP
-// (quad_perm broadcasts / butterflies), which costs no LDS and no extra issue slot when fused.
+// their rows of the Cholesky factor L and of Y = L^-1 J^T in VGPRs with COMPILE-TIME indices
+// (everything is fully unrolled).  The only cross-lane traffic is quad-local DPP.
 //
-// Data movement: inputs stay in the caller's batch-major AoS layout (include/irlosc.h).  Each
-// wave streams its 16-instance tile HBM -> LDS with the asynchronous LDS-DMA path
-// (global_load_lds_dwordx4, 4-row chunks of M and J = 16 x 400 B segments; single rows with
-// global_load_lds_dword) through a 3-deep ring, with counted s_waitcnt vmcnt(N) so that two
-// chunks (12.5 KB) are always in flight per wave while the current one is consumed.  The LDS image
-// of a chunk is instance-major with a 100-dword stride: quad q reads dwords 100q + 4s + g, which
-// spreads a 32-lane ds_read_b32 group over all 32 banks.
+// This file: shared helpers (namespace grp), STAGE 2 (stage2_body: the instances whose k x k solve
+// is not certifiably the reference's np.linalg.inv branch — deflated inverse iteration applies the
+// pinv cut of osc.py:55) and the host-side launch logic.  STAGE 1 (all instances; streaming,
+// Cholesky of M, Y, A, certificate, solve, u) is osc_group_stage1.hpp.
 //
-// Math per instance (same algebra as osc_generic.hpp; osc.py:41-200):
-//   column-by-column (left-looking) Cholesky of M while its rows stream in, Mdq accumulated from
-//   the same reads; per Jacobian row r: y_r = L^-1 J_r^T by column-oriented substitution, dx_r;
-//   A = Y^T Y by quad-reduced partial dot products; then per lane (replicated in the quad):
-//   Cholesky of A, W = L_A^-1, the cond(A) certificate, t = W^T W w; finally
-//   u = u0 + bias - kvn*Mdq - J^T t from the register copy of J.
-// Instances whose k x k solve is not certifiably the reference's branch (cond bound >= 1e5 with
-// |det| < 1e-4, or A not positive definite) are appended to a worklist and redone by the generic
-// kernel, which owns the eigen-decomposition.
+// Launch structure (launch_group): one fused launch = [n2 blocks running stage 2 of the PREVIOUS
+// step's flagged instances] + [stage-1 tiles of this step]; flagged instances hand A and w over
+// through `side` (indexed by instance, no worklist); each stage-2 block compacts its own 64-instance
+// span in LDS.  Instances stage 2 cannot finish (more than 3 eigenvalues under the cut) go to a
+// small give-up list handled by the generic kernel (Jacobi).  DESIGN.md section 4.2 has the numbers.
 #pragma once
 #include "osc_common.hpp"
 #include "osc_generic.hpp"
@@ -40,7 +32,6 @@ constexpr int S = 7;         // row slots per lane (4 * 7 = 28 >= 25)
 constexpr int TILE = 16;     // instances per wave
 constexpr int BUF_FLOATS = 1792;   // 7 DMA instructions x 1 KiB
 constexpr int NBUF = 3;
-constexpr int NLISTS = 32;   // sharded worklists (counter l owns worklist[l * list_cap ...))
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {

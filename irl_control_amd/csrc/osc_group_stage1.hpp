@@ -614,8 +614,8 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     const float cond_bound = sqrtf(nA2) * nW2;        // >= cond_2(A) for SPD A
     const bool plain = pdA && t_finite(cond_bound) && (!small_det || cond_bound < 0.99e5f);
     flags |= small_det ? IRLOSC_FLAG_PINV_BRANCH : 0u;
-    // Flagged instances hand A and w to the second stage now (side[e][b], indexed by instance: no atomics; a
-    // compaction kernel builds the worklist from the flag words), which frees the slot for J1'.
+    // Flagged instances hand A and w to the second stage now (side[e][b], indexed by instance: no atomics;
+    // stage-2 blocks compact their span from the flag words), which frees the slot for J1'.
     if (!plain) {
         flags |= IRLOSC_FLAG_EIGEN_PATH;
         for (int e = g; e < NA; e += G) side[(size_t)e * side_cap + b] = aq[e];
