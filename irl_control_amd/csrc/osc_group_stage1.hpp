@@ -495,17 +495,37 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     }
     __builtin_amdgcn_wave_barrier();
     wait_lgkm0();
-    float w[K];
+    // The k x k matrix is REPLICATED in the group (every lane does the same arithmetic), so its throughput is
+    // bought with packed FP32: everything below keeps A column-major in ROW PAIRS, Ac[c][m] = (A[2m][c], A[2m+1][c])
+    // for m >= c/2.  The low half of the first pair of an odd column (row c-1, upper triangle) and row 13 of the
+    // k = 13 padding are don't-care / zero slots that no result ever reads.
+    constexpr int KP = (K + 1) / 2;
+    v2f w2[KP];
 #pragma unroll
-    for (int r = 0; r < K; ++r) w[r] = wls[r] - kvn * xq[25 + r];
+    for (int m = 0; m < KP; ++m) {
+        w2[m].x = wls[2 * m] - kvn * xq[25 + 2 * m];
+        w2[m].y = (2 * m + 1 < K) ? wls[2 * m + 1] - kvn * xq[25 + 2 * m + 1] : 0.f;
+    }
+#define IRLOSC_WE(r) (((r) & 1) ? w2[(r) / 2].y : w2[(r) / 2].x)
 
     IRLOSC_TS(4);
     // ---------------- A = Y^T Y (lower), replicated in the group -----------------------------------------------
-    float A[K][K];
+    v2f Ac[K][KP];
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+#pragma unroll
+        for (int m = 0; m < KP; ++m) Ac[c][m] = v2f{0.f, 0.f};
+    }
+#define IRLOSC_AE(r, c) (((r) & 1) ? Ac[c][(r) / 2].y : Ac[c][(r) / 2].x)
+    // Park A in the ring slot that the second J pass has not claimed yet (J0' went to the other one).  It is
+    // read back only by flagged instances, which hand A and w to the second stage.
+    float* aq = ring + ((NCH1 - 1) % NB) * SLOT + q * NA;
+    float nA2 = 0.f;
     // row by row: first all partial dots of the row, then the butterfly steps over the whole row, so that a
     // DPP add never has to wait on the instruction right before it (rows 0..2 are too short to hide it)
 #pragma unroll
     for (int r = 0; r < K; ++r) {
+        float ar[K];
 #pragma unroll
         for (int s2 = 0; s2 <= r; ++s2) {
             v2f a2 = Y[r].p[0] * Y[s2].p[0];
@@ -513,67 +533,43 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
             for (int pp = 1; pp < P; ++pp) a2 = __builtin_elementwise_fma(Y[r].p[pp], Y[s2].p[pp], a2);
             float a = a2.x + a2.y;
             if (ODD) a = fmaf(Y[r].o, Y[s2].o, a);
-            A[r][s2] = a;
+            ar[s2] = a;
         }
 #pragma unroll
-        for (int s2 = 0; s2 <= r; ++s2) asm volatile("" : "+v"(A[r][s2]));
+        for (int s2 = 0; s2 <= r; ++s2) asm volatile("" : "+v"(ar[s2]));
 #pragma unroll
-        for (int s2 = 0; s2 <= r; ++s2) A[r][s2] += dpp_f<0xB1>(A[r][s2]);      // quad_perm [1,0,3,2]
+        for (int s2 = 0; s2 <= r; ++s2) ar[s2] += dpp_f<0xB1>(ar[s2]);      // quad_perm [1,0,3,2]
 #pragma unroll
-        for (int s2 = 0; s2 <= r; ++s2) asm volatile("" : "+v"(A[r][s2]));
+        for (int s2 = 0; s2 <= r; ++s2) asm volatile("" : "+v"(ar[s2]));
 #pragma unroll
-        for (int s2 = 0; s2 <= r; ++s2) A[r][s2] += dpp_f<0x4E>(A[r][s2]);      // quad_perm [2,3,0,1]
+        for (int s2 = 0; s2 <= r; ++s2) ar[s2] += dpp_f<0x4E>(ar[s2]);      // quad_perm [2,3,0,1]
         if (G == 8) {
 #pragma unroll
-            for (int s2 = 0; s2 <= r; ++s2) asm volatile("" : "+v"(A[r][s2]));
+            for (int s2 = 0; s2 <= r; ++s2) asm volatile("" : "+v"(ar[s2]));
 #pragma unroll
-            for (int s2 = 0; s2 <= r; ++s2) A[r][s2] += dpp_f<0x141>(A[r][s2]); // row_half_mirror
+            for (int s2 = 0; s2 <= r; ++s2) ar[s2] += dpp_f<0x141>(ar[s2]); // row_half_mirror
         }
 #pragma unroll
-        for (int s2 = 0; s2 <= r; ++s2) asm volatile("" : "+v"(A[r][s2]));
+        for (int s2 = 0; s2 <= r; ++s2) asm volatile("" : "+v"(ar[s2]));
+#pragma unroll
+        for (int s2 = 0; s2 <= r; ++s2) {
+            if (r & 1) Ac[s2][r / 2].y = ar[s2]; else Ac[s2][r / 2].x = ar[s2];
+            aq[r * (r + 1) / 2 + s2] = ar[s2];   // every lane of the group holds the same value: plain broadcast store
+            nA2 = fmaf(s2 < r ? 2.f * ar[s2] : ar[s2], ar[s2], nA2);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
-    // Park A in the ring slot that the second J pass has not claimed yet (J0' went to the other one).  It is
-    // read back only by flagged instances, which hand A and w to the second stage.
-    float* aq = ring + ((NCH1 - 1) % NB) * SLOT + q * NA;
-    {
-        int e = 0;
-#pragma unroll
-        for (int r = 0; r < K; ++r) {
-#pragma unroll
-            for (int c2 = 0; c2 <= r; ++c2) {
-                aq[e] = A[r][c2];     // every lane of the group holds the same value: plain broadcast store
-                ++e;
-            }
-        }
-    }
 
-#if defined(IRLOSC_CUT) && IRLOSC_CUT == 3
-    { float h = 0.f;
-      for (int r = 0; r < K; ++r) for (int c = 0; c <= r; ++c) h += A[r][c];
-      for (int r = 0; r < K; ++r) h += w[r];
-      p.u[(size_t)b * N + g] = h; return; }
-#endif
     IRLOSC_TS(5);
+    asm volatile("" : "+v"(nA2));
     __builtin_amdgcn_sched_barrier(0);
-    // ---------------- k x k (per lane): Cholesky of A in place, cond certificate ----------------------------------
-    float nA2 = 0.f;
-#pragma unroll
-    for (int r = 0; r < K; ++r) {
-#pragma unroll
-        for (int c = 0; c < r; ++c) nA2 = fmaf(2.f * A[r][c], A[r][c], nA2);
-        nA2 = fmaf(A[r][r], A[r][r], nA2);
-    }
-    asm volatile("" : "+v"(nA2));     // finish ||A||_F^2 before A is overwritten (else both copies stay live)
-    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- k x k: right-looking Cholesky of A in place (row pairs), cond certificate ---------------------
     bool pdA = true;
     float detA = 1.f;
     float dA[K];                       // 1 / L_A[j][j]
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        float d = A[j][j];
-#pragma unroll
-        for (int c = 0; c < j; ++c) d = fmaf(-A[j][c], A[j][c], d);
+        float d = IRLOSC_AE(j, j);
         const bool npd = !(d > 0.f);
         pdA = pdA && !npd;
         const float dfix = (d == d && d != 0.f) ? fabsf(d) : 1.f;
@@ -581,34 +577,49 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
         detA *= d;
         const float di = __builtin_amdgcn_rsqf(d);
         dA[j] = di;
+        const v2f di2 = v2f{di, di};
 #pragma unroll
-        for (int i = j + 1; i < K; ++i) {
-            float a = A[i][j];
+        for (int m = j / 2; m < KP; ++m) Ac[j][m] = Ac[j][m] * di2;     // the diagonal slot becomes sqrt(d): never read
 #pragma unroll
-            for (int c = 0; c < j; ++c) a = fmaf(-A[i][c], A[j][c], a);
-            A[i][j] = a * di;
+        for (int c2 = j + 1; c2 < K; ++c2) {
+            const float l = IRLOSC_AE(c2, j);
+            const v2f l2 = v2f{l, l};
+#pragma unroll
+            for (int m = c2 / 2; m < KP; ++m) Ac[c2][m] = __builtin_elementwise_fma(-Ac[j][m], l2, Ac[c2][m]);
         }
 #pragma unroll
-        for (int i = j + 1; i < K; ++i) asm volatile("" : "+v"(A[i][j]));
+        for (int m = j / 2; m < KP; ++m) asm volatile("" : "+v"(Ac[j][m]));
         asm volatile("" : "+v"(dA[j]), "+v"(detA));
     }
-    // ||L_A^-1||_F^2 = trace(A^-1): column j of W = L_A^-1 by forward substitution, used and dropped
+    // ||L_A^-1||_F^2 = trace(A^-1).  The columns of W = L_A^-1 are independent forward substitutions with the SAME
+    // matrix, so lane g of the group takes column G*r + g in round r (a different unit right-hand side per lane,
+    // identical instruction stream), and the partial sums are added over the group at the end.
+    float eg[G];
+#pragma unroll
+    for (int m = 0; m < G; ++m) eg[m] = (g == m) ? 1.f : 0.f;
     float nW2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        float wc[K];
-        wc[j] = dA[j];
-        nW2 = fmaf(wc[j], wc[j], nW2);
+    for (int c0 = 0; c0 < K; c0 += G) {
+        v2f wp[KP];
 #pragma unroll
-        for (int i = j + 1; i < K; ++i) {
-            float s2 = 0.f;
+        for (int m = c0 / 2; m < KP; ++m) {
+            wp[m].x = (2 * m - c0 < G && 2 * m < K) ? eg[(2 * m - c0) % G] : 0.f;
+            wp[m].y = (2 * m + 1 - c0 < G && 2 * m + 1 < K) ? eg[(2 * m + 1 - c0) % G] : 0.f;
+        }
 #pragma unroll
-            for (int c = j; c < i; ++c) s2 = fmaf(A[i][c], wc[c], s2);
-            wc[i] = -dA[i] * s2;
-            nW2 = fmaf(wc[i], wc[i], nW2);
+        for (int c = c0; c < K; ++c) {
+            const float wc = ((c & 1) ? wp[c / 2].y : wp[c / 2].x) * dA[c];
+            nW2 = fmaf(wc, wc, nW2);
+            const v2f wc2 = v2f{wc, wc};
+#pragma unroll
+            for (int m = (c + 1) / 2; m < KP; ++m) {
+                const bool has = (2 * m > c && 2 * m < K) || (2 * m + 1 > c && 2 * m + 1 < K);
+                if (has) wp[m] = __builtin_elementwise_fma(-Ac[c][m], wc2, wp[m]);
+            }
         }
         asm volatile("" : "+v"(nW2));
     }
+    nW2 = gsum<G>(nW2);
     __builtin_amdgcn_sched_barrier(0);
     const bool small_det = !(fabsf(detA) >= 1e-4f);
     const float cond_bound = sqrtf(nA2) * nW2;        // >= cond_2(A) for SPD A
@@ -621,28 +632,40 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
         for (int e = g; e < NA; e += G) side[(size_t)e * side_cap + b] = aq[e];
 #pragma unroll
         for (int r = 0; r < K; ++r)
-            if ((r % G) == g) side[(size_t)(NA + r) * side_cap + b] = w[r];
+            if ((r % G) == g) side[(size_t)(NA + r) * side_cap + b] = IRLOSC_WE(r);
     }
     wait_lgkm0();
     __builtin_amdgcn_wave_barrier();
     issue(NCH1 - 1 + NB);                             // the deferred successor of the last first-pass chunk
     __builtin_amdgcn_sched_barrier(0);
     float t[K];
-    // forward: z = L_A^-1 w ; backward: t = L_A^-T z
+    // forward, column-oriented on row pairs: z = L_A^-1 w
 #pragma unroll
-    for (int i = 0; i < K; ++i) {
-        float s2 = w[i];
+    for (int c = 0; c < K; ++c) {
+        t[c] = IRLOSC_WE(c) * dA[c];
+        const v2f t2 = v2f{t[c], t[c]};
 #pragma unroll
-        for (int c = 0; c < i; ++c) s2 = fmaf(-A[i][c], t[c], s2);
-        t[i] = s2 * dA[i];
+        for (int m = (c + 1) / 2; m < KP; ++m) {
+            const bool has = (2 * m > c && 2 * m < K) || (2 * m + 1 > c && 2 * m + 1 < K);
+            if (has) w2[m] = __builtin_elementwise_fma(-Ac[c][m], t2, w2[m]);
+        }
     }
+    // backward, dot form over the row pairs of column i: t = L_A^-T z
+    v2f tp[KP];
+#pragma unroll
+    for (int m = 0; m < KP; ++m) tp[m] = v2f{0.f, 0.f};
 #pragma unroll
     for (int i = K - 1; i >= 0; --i) {
-        float s2 = t[i];
+        v2f acc = v2f{0.f, 0.f};
 #pragma unroll
-        for (int c = i + 1; c < K; ++c) s2 = fmaf(-A[c][i], t[c], s2);
+        for (int m = (i + 2) / 2; m < KP; ++m) acc = __builtin_elementwise_fma(Ac[i][m], tp[m], acc);
+        float s2 = t[i] - (acc.x + acc.y);
+        if (!(i & 1) && i + 1 < K) s2 = fmaf(-IRLOSC_AE(i + 1, i), t[i + 1], s2);
         t[i] = s2 * dA[i];
+        if (i & 1) tp[i / 2].y = t[i]; else tp[i / 2].x = t[i];
     }
+#undef IRLOSC_AE
+#undef IRLOSC_WE
 
     IRLOSC_TS(6);
     // keep the scheduler from hoisting the ~120 LDS reads of the torque phase above the k x k work
