@@ -150,7 +150,9 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     constexpr int VEC_DQ = 0, VEC_EE = VEC_DQ + TILE * N, VEC_TGT = VEC_EE + TILE * NDEV * 7;
     constexpr int VEC_W = VEC_TGT + TILE * NDEV * 7, VEC_X = VEC_W + TILE * K, VEC_END = VEC_X + TILE * (N + K);
     static_assert(TILE * NA <= SLOT, "the A hand-off area must fit in one ring slot");
-    constexpr int NT = NCH1 + NCHJ;                  // all chunks: first pass, then the second pass over J
+    constexpr int NT = NCH1 + 1;                     // ring chunks: first pass, then J rows 0..3 once more (J0')
+    constexpr int RJ0 = K < 4 ? K : 4;               // second pass over J: rows [0, RJ0) from the ring,
+    constexpr int NDL = K - RJ0;                     //   rows [RJ0, K) by plain loads into registers
     __shared__ __attribute__((aligned(16))) float ring[NB * SLOT];
     __shared__ __attribute__((aligned(16))) float vec[VEC_END];
 
@@ -178,8 +180,9 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     //   vec(NVEC) C0 C1 | C2 | C3 | ... first pass: C0..C6 = M (6 x 4 rows + row 24), then the J chunks;
     //   "| Cn" = issued right after chunk n-2 has been consumed, into the slot (n % 2) that chunk vacated.
     //   Second pass over J (for u -= J^T t; keeping J resident would cost 21 KB of LDS and the second wave
-    //   per SIMD): J0' is issued when the last-but-one first-pass chunk is consumed, J1' after the A hand-off
-    //   area (which borrows the other slot) has been read, J2'/J3' as their slots drain.
+    //   per SIMD): J0' (rows 0..3) is issued into the ring when the last-but-one first-pass chunk is consumed;
+    //   the other rows are loaded straight into registers at the start of the k x k phase, when Y has died
+    //   (L2 / Infinity Cache hits), so the torque phase finds everything in place and never waits on a DMA.
     dmalinear<PDQ>(p.dq + t0 * N, vec + VEC_DQ, lane);
     dmalinear<PEE>(p.ee + t0 * NDEV * 7, vec + VEC_EE, lane);
     dmalinear<PEE>(p.tgt + t0 * NDEV * 7, vec + VEC_TGT, lane);
@@ -563,6 +566,30 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     IRLOSC_TS(5);
     asm volatile("" : "+v"(nA2));
     __builtin_amdgcn_sched_barrier(0);
+    // second pass over J, rows RJ0..K-1: own-row elements straight from global memory (the registers Y held are free)
+    // and the bias forces of the own rows.  Raw loads only: nothing here may consume a loaded value, or the wave
+    // would sit out the memory latency right now (the padding slot carries junk that is never stored).
+    Row jd[NDL > 0 ? NDL : 1];
+    Row biasr;
+    {
+        const float* jg = p.J + (size_t)b * (K * N);
+        auto load_row_raw = [&](const float* row, Row& d) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const float v = row[s == LS ? lastcol : G * s + g];
+                if (ODD && s == LS) d.o = v;
+                else if (s & 1) d.p[s >> 1].y = v;
+                else d.p[s >> 1].x = v;
+            }
+        };
+#pragma unroll
+        for (int r = 0; r < NDL; ++r) load_row_raw(jg + (RJ0 + r) * N, jd[r]);
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) biasr.p[pp] = v2f{0.f, 0.f};
+        biasr.o = 0.f;
+        if (p.cfgflags & IRLOSC_USE_G) load_row_raw(p.bias + (size_t)b * N, biasr);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // ---------------- k x k: right-looking Cholesky of A in place (row pairs), cond certificate ---------------------
     bool pdA = true;
     float detA = 1.f;
@@ -634,9 +661,6 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
         for (int r = 0; r < K; ++r)
             if ((r % G) == g) side[(size_t)(NA + r) * side_cap + b] = IRLOSC_WE(r);
     }
-    wait_lgkm0();
-    __builtin_amdgcn_wave_barrier();
-    issue(NCH1 - 1 + NB);                             // the deferred successor of the last first-pass chunk
     __builtin_amdgcn_sched_barrier(0);
     float t[K];
     // forward, column-oriented on row pairs: z = L_A^-1 w
@@ -671,35 +695,34 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     // keep the scheduler from hoisting the ~120 LDS reads of the torque phase above the k x k work
     __builtin_amdgcn_sched_barrier(0);
     // ---------------- joint torques for the own rows: u = u0 + bias - kvn*Mdq - J^T t ----------------------------
-    // NOTE on vmcnt: the side-buffer stores above are VMEM too and retire in order with the DMAs, so waiting
-    // for "at most CI younger" still guarantees J0' has landed (it only waits longer when stores are pending).
-    Row jt;                                   // (J^T t) for the own rows, accumulated chunk by chunk
+    Row jt;                                   // (J^T t) for the own rows
 #pragma unroll
     for (int pp = 0; pp < P; ++pp) jt.p[pp] = v2f{0.f, 0.f};
     jt.o = 0.f;
+    wait_vm<0>();                             // J0' and the register rows were issued a whole k x k phase ago
+    {
+        const float* buf = ring + (NCH1 % NB) * SLOT;
 #pragma unroll
-    for (int jc = 0; jc < NCHJ; ++jc) {
-        const int n = NCH1 + jc;
-        const float* buf = ring + (n % NB) * SLOT;
-        wait_chunks<CI>((NT - 1 - n) < (NB - 1) ? (NT - 1 - n) : (NB - 1));
-        const int R = jc < 3 ? 4 : 1;
-        const int jstride = jc < 3 ? GE::STR4 : N;
-#pragma unroll
-        for (int rr = 0; rr < R; ++rr) {
+        for (int rr = 0; rr < RJ0; ++rr) {
             Row jr;
-            load_row(buf + q * jstride + rr * N, jr);
-            const float tr = t[jc * 4 + rr];
-            const v2f t2 = v2f{tr, tr};
+            load_row(buf + q * GE::STR4 + rr * N, jr);
+            const v2f t2 = v2f{t[rr], t[rr]};
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) jt.p[pp] = __builtin_elementwise_fma(jr.p[pp], t2, jt.p[pp]);
-            if (ODD) jt.o = fmaf(jr.o, tr, jt.o);
+            if (ODD) jt.o = fmaf(jr.o, t[rr], jt.o);
+        }
+#pragma unroll
+        for (int r = 0; r < NDL; ++r) {
+            const v2f t2 = v2f{t[RJ0 + r], t[RJ0 + r]};
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) jt.p[pp] = __builtin_elementwise_fma(jd[r].p[pp], t2, jt.p[pp]);
+            if (ODD) jt.o = fmaf(jd[r].o, t[RJ0 + r], jt.o);      // padding lanes: junk in, never stored
         }
         wait_lgkm0();
-        issue(n + NB);
         __builtin_amdgcn_sched_barrier(0);
     }
     bool bad = false;
-    float* ubuf = ring;                       // both ring slots have been drained by now
+    float* ubuf = ring;                       // both ring slots have been drained by now (LDS ops of a wave are in order)
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int i = G * s + g;
@@ -714,7 +737,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
             if (brA_d && (p.dev[d].joint_mask & (1u << (i & 31)))) uu = -kv_d * mdq_i;
         }
         uu -= plain ? sget(jt, s) : 0.f;     // flagged instances keep u_base; stage 2 subtracts J^T t
-        if (p.cfgflags & IRLOSC_USE_G) uu += p.bias[(size_t)b * N + icol];
+        uu += sget(biasr, s);                // zeros unless IRLOSC_USE_G
         uu -= kvn * mdq_i;
         if (valid) {
             ubuf[q * N + i] = uu;
