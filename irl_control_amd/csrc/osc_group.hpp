@@ -191,28 +191,39 @@ struct S2Args {
     int32_t* workcount2;
 };
 
-// Body of stage 2 for block `blk` (64 instances scanned); `list` = 64 ints of LDS.
+// Body of stage 2 for block `blk`: ONE LANE PER FLAGGED INSTANCE for the k x k work (it is the same serial
+// arithmetic whatever the lane count, so replicating it over a quad only burnt wave slots), then the wave
+// cooperates, four lanes per instance, on u -= J^T t.  A block scans S2_SPAN instances and compacts the flagged
+// ones in LDS: no global worklist, no atomics.  `lds` = S2_LDS_WORDS 32-bit words.
+constexpr int S2_SPAN = 384;     // ~42 flagged per block at the 11 % rate of the synthetic batch: one round of 64
+template <int K> struct S2Lds { static constexpr int WORDS = S2_SPAN + 64 * K + 64; };
+
 template <int K>
-__device__ __forceinline__ void stage2_body(const S2Args a, int blk, int32_t* list) {
+__device__ __forceinline__ void stage2_body(const S2Args a, int blk, int32_t* lds) {
     using namespace grp;
     constexpr int NA = K * (K + 1) / 2;
-    constexpr int SPAN = 64;                      // instances scanned per block (~7 flagged at an 11 % rate, so
-                                                  // one round of 16 almost always; the work is latency-bound)
+    constexpr int SPAN = S2_SPAN;
+    int32_t* list = lds;                                         // [SPAN] flagged instance ids
+    float* tl = reinterpret_cast<float*>(lds + SPAN);            // [64][K] solutions t of the current round
+    uint32_t* fll = reinterpret_cast<uint32_t*>(lds + SPAN + 64 * K);   // [64] their flag bits
     const float* __restrict__ side = a.side;
     const int side_cap = a.side_cap;
     const int lane = threadIdx.x, g = lane & 3, q = lane >> 2;
-    // compaction in the block: no global worklist, no atomics (stage 1 left IRLOSC_FLAG_EIGEN_PATH in flags[])
     const int base = blk * SPAN;
-    const int i0 = base + lane;
-    const bool f0 = i0 < a.nfast && (a.flags[i0] & IRLOSC_FLAG_EIGEN_PATH);
-    const unsigned long long m0 = __ballot(f0);
     const unsigned long long below = (1ull << lane) - 1ull;
-    if (f0) list[__popcll(m0 & below)] = i0;
-    const int count = __popcll(m0);
+    int count = 0;
+#pragma unroll
+    for (int k0 = 0; k0 < SPAN; k0 += 64) {
+        const int i0 = base + k0 + lane;
+        const bool f0 = i0 < a.nfast && (a.flags[i0] & IRLOSC_FLAG_EIGEN_PATH);
+        const unsigned long long m0 = __ballot(f0);
+        if (f0) list[count + __popcll(m0 & below)] = i0;
+        count += __popcll(m0);
+    }
     __syncthreads();
-    const int ntile = (count + TILE - 1) / TILE;
-    for (int tile = 0; tile < ntile; ++tile) {
-        const int lpos = tile * TILE + q;
+    const int nround = (count + 63) / 64;
+    for (int round = 0; round < nround; ++round) {
+        const int lpos = round * 64 + lane;
         const bool live = lpos < count;
         const int b = list[live ? lpos : count - 1];
         const int posc = b;                  // the side buffer is indexed by instance
@@ -337,25 +348,34 @@ __device__ __forceinline__ void stage2_body(const S2Args a, int blk, int32_t* li
             for (int i = 0; i < K; ++i) x[i] = 0.3f + 0.1f * (float)(((i + 3 * slot) * 5) % 7) - 0.05f * (float)slot;
             float lam = 0.f;
             float lam_prev = -1.f;
+            // Every lane carries its own instance, so an instance's result must not depend on its wave-mates
+            // (sharding a batch differently must not change a single bit): a lane FREEZES x and lambda at its own
+            // convergence; the loop merely keeps running until the slowest lane of the wave is done.
+            bool fin = !active;
             for (int it = 0; it < 6; ++it) {
+                float xn[K];
+#pragma unroll
+                for (int i = 0; i < K; ++i) xn[i] = x[i];
 #pragma unroll
                 for (int s0 = 0; s0 < 3; ++s0) {
                     if (s0 < slot) {
-                        const float pr = (s0 < m) ? dot(v[s0], x) : 0.f;
+                        const float pr = (s0 < m) ? dot(v[s0], xn) : 0.f;
 #pragma unroll
-                        for (int i = 0; i < K; ++i) x[i] = fmaf(-pr, v[s0][i], x[i]);
+                        for (int i = 0; i < K; ++i) xn[i] = fmaf(-pr, v[s0][i], xn[i]);
                     }
                 }
-                solve(x);
-                const float n2 = dot(x, x);
+                solve(xn);
+                const float n2 = dot(xn, xn);
                 const float rn = __builtin_amdgcn_rsqf(n2 > 0.f ? n2 : 1.f);
-                lam = rn - sigma;                          // 1/||(A+sigma)^-1 x|| -> lambda + sigma
+                const float lamn = rn - sigma;                 // 1/||(A+sigma)^-1 x|| -> lambda + sigma
+                // converged (or clearly above the cut): this lane stops here
+                const bool settled = fabsf(lamn - lam_prev) <= 1e-3f * fabsf(lamn) || (it >= 2 && lamn > 4.f * cutoff);
 #pragma unroll
-                for (int i = 0; i < K; ++i) x[i] *= rn;
-                // converged for every instance of the wave (or clearly above the cut): stop iterating
-                const bool settled = !active || fabsf(lam - lam_prev) <= 1e-3f * fabsf(lam) || (it >= 2 && lam > 4.f * cutoff);
+                for (int i = 0; i < K; ++i) x[i] = fin ? x[i] : xn[i] * rn;
+                lam = fin ? lam : lamn;
                 lam_prev = lam;
-                if (it >= 2 && !__any(!settled)) break;
+                fin = fin || (it >= 2 && settled);
+                if (!__any(!fin)) break;
             }
             // final clean-up of the accepted vector against the earlier ones
             const bool below = active && (lam <= cutoff);
@@ -398,37 +418,52 @@ __device__ __forceinline__ void stage2_body(const S2Args a, int blk, int32_t* li
                 for (int i = 0; i < K; ++i) t[i] += (sigma > 0.f) ? y[i] : 0.f;
             }
         }
-        // u -= J^T t on the own joint rows; J straight from global (L2-resident: it was just streamed)
-        uint32_t fl = (m > 0 ? IRLOSC_FLAG_TRUNCATED : 0u);
-        bool bad = false;
-        if (live) {
-            const float* Jb = a.J + (size_t)b * K * N;
+        // hand t over to the wave: u -= J^T t is done four lanes per instance (coalesced 16-byte groups of J and u)
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const int i = 4 * s + g;
-                if (i < N) {
-                    float acc = 0.f;
+        for (int r = 0; r < K; ++r) tl[lane * K + r] = t[r];
+        fll[lane] = (m > 0 ? IRLOSC_FLAG_TRUNCATED : 0u) | (giveup ? 0x80000000u : 0u);
+        __syncthreads();
+        const int nlive = (count - round * 64) < 64 ? (count - round * 64) : 64;
+        for (int grp4 = 0; grp4 * TILE < nlive; ++grp4) {
+            const int slot = grp4 * TILE + q;
+            const bool live2 = slot < nlive;
+            const int b2 = list[round * 64 + (live2 ? slot : nlive - 1)];
+            const float* tq = tl + (live2 ? slot : nlive - 1) * K;
+            float t2[K];
 #pragma unroll
-                    for (int r = 0; r < K; ++r) acc = fmaf(Jb[r * N + i], t[r], acc);
-                    const float uu = a.u[(size_t)b * N + i] - acc;
-                    a.u[(size_t)b * N + i] = uu;
-                    bad = bad || !t_finite(uu);
+            for (int r = 0; r < K; ++r) t2[r] = tq[r];
+            uint32_t fl = fll[live2 ? slot : nlive - 1];
+            bool bad = false;
+            if (live2) {
+                const float* Jb = a.J + (size_t)b2 * K * N;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const int i = 4 * s + g;
+                    if (i < N) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int r = 0; r < K; ++r) acc = fmaf(Jb[r * N + i], t2[r], acc);
+                        const float uu = a.u[(size_t)b2 * N + i] - acc;
+                        a.u[(size_t)b2 * N + i] = uu;
+                        bad = bad || !t_finite(uu);
+                    }
                 }
             }
+            fl |= bad ? IRLOSC_FLAG_NONFINITE : 0u;
+            fl = qor(fl);
+            if (live2 && g == 0) {
+                if (fl & 0x7fffffffu) a.flags[b2] |= (fl & 0x7fffffffu);
+                if (fl & 0x80000000u) a.worklist2[atomicAdd(a.workcount2, 1)] = b2;
+            }
         }
-        fl |= bad ? IRLOSC_FLAG_NONFINITE : 0u;
-        fl = qor(fl);
-        if (live && g == 0) {
-            a.flags[b] |= fl;
-            if (giveup) a.worklist2[atomicAdd(a.workcount2, 1)] = b;
-        }
+        __syncthreads();
     }
 }
 
 template <int K>
 __global__ __launch_bounds__(64) void osc_group_stage2_f32(const S2Args a) {
-    __shared__ int32_t list[64];
-    stage2_body<K>(a, blockIdx.x, list);
+    __shared__ int32_t lds[S2Lds<K>::WORDS];
+    stage2_body<K>(a, blockIdx.x, lds);
 }
 
 }  // namespace irlosc
@@ -477,7 +512,7 @@ inline int launch_group_stage2<double>(const KParams<double>&, const S2Args&, hi
 template <>
 inline int launch_group_stage2<float>(const KParams<float>& p, const S2Args& a, hipStream_t st) {
     if (a.nfast <= 0) return 0;
-    const int g2 = (a.nfast + 63) / 64;
+    const int g2 = (a.nfast + S2_SPAN - 1) / S2_SPAN;
     if (p.k == 13) hipLaunchKernelGGL((osc_group_stage2_f32<13>), dim3(g2), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((osc_group_stage2_f32<12>), dim3(g2), dim3(64), 0, st, a);
     hipError_t e = hipGetLastError();
@@ -500,7 +535,7 @@ inline int launch_group<float>(const KParams<float>& p, const GroupScratch& gs, 
     int32_t* wc2 = gs.counts;              // length of worklist2; zeroed by the first stage-1 block
     hipError_t e;
     const bool ride = gs.have_prev && gs.prev.nfast > 0 && !gs.stage1_only;
-    const int n2 = ride ? (gs.prev.nfast + 63) / 64 : 0;
+    const int n2 = ride ? (gs.prev.nfast + S2_SPAN - 1) / S2_SPAN : 0;
     if (tiles > 0) {
         const dim3 grid(tiles + n2);
         if (gs.ev_begin && (e = hipEventRecord(gs.ev_begin, st)) != hipSuccess) return (int)e;

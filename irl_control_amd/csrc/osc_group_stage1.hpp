@@ -159,6 +159,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     // Fused launch: the first n2 blocks run STAGE 2 OF THE PREVIOUS STEP (its own output set), the rest stage 1
     // of this step.  Stage 2 alone keeps one latency-bound wave per SIMD busy for ~28 us with the other slot
     // idle; inside this launch its waves share the SIMDs with stage-1 waves instead.
+    static_assert(S2Lds<K>::WORDS <= NB * SLOT, "stage 2 borrows the ring as its LDS");
     if ((int)blockIdx.x < n2) {
         stage2_body<K>(prev, blockIdx.x, reinterpret_cast<int32_t*>(ring));
         return;
