@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/irlosc.h"
@@ -50,11 +51,9 @@ struct irlosc_ctx {
     void* dgains = nullptr;   // [nb][ndev][12] in dtype
     void* dnullkv = nullptr;  // [nb]
     int gains_nb = 0;
-    unsigned long long* ddbg = nullptr;  // IRLOSC_PHASE_TIMING=1: 8 cycle stamps per stage-1 wave
+    unsigned long long* ddbg = nullptr;  // IRLOSC_PHASE_TIMING=1: 8 cycle stamps + 2 wall-clock stamps per stage-1 wave
     int kernel = IRLOSC_KERNEL_GENERIC;
     bool stage1_only = false; // set only inside irlosc_time_dominant_kernel
-    int ring = 2;             // group kernel: LDS ring depth (IRLOSC_GROUP_RING=2|3 overrides)
-    int lanes = 4;            // group kernel: lanes per instance (IRLOSC_GROUP_LANES=4|8 overrides)
     std::string kernel_name;
     std::string err;
 };
@@ -184,7 +183,7 @@ static int create_impl(irlosc_ctx* c) {
     HIPCHK(nullptr, hipMalloc(&c->dgains, B * nd * IRLOSC_GAIN_WORDS * e));
     HIPCHK(nullptr, hipMalloc(&c->dnullkv, B * e));
     if (c->kernel == IRLOSC_KERNEL_GROUP && getenv("IRLOSC_PHASE_TIMING"))
-        HIPCHK(nullptr, hipMalloc((void**)&c->ddbg, (B / 16 + 1) * 8 * sizeof(unsigned long long)));
+        HIPCHK(nullptr, hipMalloc((void**)&c->ddbg, (B / 16 + 1) * 10 * sizeof(unsigned long long)));
     HIPCHK(nullptr, hipStreamSynchronize(c->stream));
     return IRLOSC_OK;
 }
@@ -220,8 +219,6 @@ extern "C" int irlosc_create(const irlosc_cfg* cfg, irlosc_ctx** out) {
     }
     c->kernel = (cfg->kernel == IRLOSC_KERNEL_GENERIC || !group_supported(c)) ? IRLOSC_KERNEL_GENERIC
                                                                               : IRLOSC_KERNEL_GROUP;
-    if (const char* ev = getenv("IRLOSC_GROUP_LANES")) c->lanes = atoi(ev) == 8 ? 8 : 4;
-    if (const char* ev = getenv("IRLOSC_GROUP_RING")) c->ring = atoi(ev) == 3 ? 3 : 2;
     char nm[96];
     snprintf(nm, sizeof nm, "%s_%s_n%d_k%d", c->kernel == IRLOSC_KERNEL_GROUP ? "osc_group" : "osc_generic",
              cfg->dtype == IRLOSC_F64 ? "f64" : "f32", cfg->n, k);
@@ -348,8 +345,6 @@ static GroupScratch scratch_for(const irlosc_ctx* c, int set) {
     gs.counts = c->dwc2[set];
     gs.side = c->dside2[set];
     gs.side_cap = c->cfg.max_batch + 16 * 64;
-    gs.lanes_per_instance = c->lanes;
-    gs.ring_depth = c->ring;
     return gs;
 }
 
@@ -395,7 +390,7 @@ static int launch_t(irlosc_ctx* c, int B, const void* M, const void* J, const vo
             int rc = launch_group<float>(p, gs, st);
             if (rc) return fail(c, IRLOSC_ERR_HIP, "group kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
             if (gs.defer_stage2) {
-                const int tile1 = 64 / (c->lanes == 8 ? 8 : 4);
+                const int tile1 = 16;
                 c->pending = true;
                 c->pending_set = set;
                 c->pending_nfast = (B / tile1) * tile1;
@@ -439,15 +434,23 @@ extern "C" int irlosc_download(irlosc_ctx* c, int32_t B, void* u_host, uint32_t*
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->ddbg && B >= 16) {   // debug: mean cycles per stage-1 phase over all waves
         const int tiles = B / 16;
-        std::vector<unsigned long long> h((size_t)tiles * 8);
+        std::vector<unsigned long long> h((size_t)tiles * 10);
         HIPCHK(c, hipMemcpy(h.data(), c->ddbg, h.size() * 8, hipMemcpyDeviceToHost));
         static const char* nm[7] = {"vec-wait", "M-stream+Cholesky", "J+fwd-subst", "task-error", "A=YtY", "kxk", "torques+store"};
-        double acc[7] = {0};
-        for (int t = 0; t < tiles; ++t) for (int i = 0; i < 7; ++i) acc[i] += (double)(h[(size_t)t * 8 + i + 1] - h[(size_t)t * 8 + i]);
+        double acc[7] = {0}, rt = 0;
+        unsigned long long rmin = ~0ull, rmax = 0;
+        for (int t = 0; t < tiles; ++t) {
+            for (int i = 0; i < 7; ++i) acc[i] += (double)(h[(size_t)t * 10 + i + 1] - h[(size_t)t * 10 + i]);
+            rt += (double)(h[(size_t)t * 10 + 9] - h[(size_t)t * 10 + 8]);
+            rmin = std::min(rmin, h[(size_t)t * 10 + 8]);
+            rmax = std::max(rmax, h[(size_t)t * 10 + 9]);
+        }
         double tot = 0; for (int i = 0; i < 7; ++i) tot += acc[i];
         fprintf(stderr, "[irlosc phase timing] %d waves, mean cycles/wave %.0f:", tiles, tot / tiles);
         for (int i = 0; i < 7; ++i) fprintf(stderr, " %s=%.0f", nm[i], acc[i] / tiles);
-        fprintf(stderr, "\n");
+        // s_memrealtime ticks at 100 MHz: wave residency in us, the shader clock it implies, first start -> last end
+        fprintf(stderr, " | wave %.2f us => %.0f MHz, launch span %.2f us\n", rt / tiles / 100.0,
+                (tot / tiles) / (rt / tiles / 100.0), (double)(rmax - rmin) / 100.0);
     }
     return IRLOSC_OK;
 }

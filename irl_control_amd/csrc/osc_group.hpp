@@ -227,9 +227,7 @@ __device__ __forceinline__ void stage2_body(const S2Args a, int blk, int32_t* ld
         const bool live = lpos < count;
         const int b = list[live ? lpos : count - 1];
         const int posc = b;                  // the side buffer is indexed by instance
-        float w[K], L[K][K], Ld[K], Li[K];     // factor: strictly-lower L, diagonal Ld, inverse diagonal Li
-#pragma unroll
-        for (int r = 0; r < K; ++r) w[r] = side[(size_t)(NA + r) * side_cap + posc];
+        float L[K][K], Ld[K], Li[K];           // factor: strictly-lower L, diagonal Ld, inverse diagonal Li
         float sigma = 0.f, hi = 0.f, det = 1.f;
         bool ok = false;
         for (int attempt = 0; attempt < 4; ++attempt) {
@@ -239,7 +237,7 @@ __device__ __forceinline__ void stage2_body(const S2Args a, int blk, int32_t* ld
             for (int r = 0; r < K; ++r) {
 #pragma unroll
                 for (int c = 0; c <= r; ++c) {
-                    const float a = side[(size_t)e * side_cap + posc];
+                    const float a = (side + (size_t)e * side_cap)[(uint32_t)posc];   // uniform base + 32-bit lane offset
                     ++e;
                     L[r][c] = a;
                     nA2 = fmaf(c < r ? 2.f * a : a, a, nA2);
@@ -389,9 +387,9 @@ __device__ __forceinline__ void stage2_body(const S2Args a, int blk, int32_t* ld
             active = below;
         }
         // t = P (A + sigma I)^-1 P w  (+ one refinement step against A when sigma > 0)
-        float t[K];
+        float t[K];                            // w is fetched only now: 13 registers less through the iterations
 #pragma unroll
-        for (int i = 0; i < K; ++i) t[i] = w[i];
+        for (int i = 0; i < K; ++i) t[i] = (side + (size_t)(NA + i) * side_cap)[(uint32_t)posc];
         auto project = [&](float (&z)[K]) {
 #pragma unroll
             for (int s0 = 0; s0 < 3; ++s0) {
@@ -480,8 +478,6 @@ struct GroupScratch {
     int32_t* counts;      // [1] length of worklist2
     float* side;          // [(K(K+1)/2 + K)][side_cap]: A and w of flagged instances, indexed by instance
     int side_cap;
-    int lanes_per_instance;   // 4 or 8 (stage-1 kernel variant)
-    int ring_depth;           // 2 or 3 LDS ring slots (G = 4)
     bool stage1_only;         // roofline timing: launch the dominant kernel alone
     bool defer_stage2;        // pipelined steps: leave this step's stage 2 to the next launch (or to a flush)
     bool have_prev;           // a previous step's stage 2 is pending and rides in this launch
@@ -527,7 +523,7 @@ inline int launch_group_stage2<float>(const KParams<float>& p, const S2Args& a, 
 
 template <>
 inline int launch_group<float>(const KParams<float>& p, const GroupScratch& gs, hipStream_t st) {
-    const int G = gs.lanes_per_instance == 8 ? 8 : 4;
+    constexpr int G = 4;
     const int TILE1 = 64 / G;
     const int tiles = p.B / TILE1;
     const int nfast = tiles * TILE1;
@@ -542,13 +538,9 @@ inline int launch_group<float>(const KParams<float>& p, const GroupScratch& gs, 
 #define IRLOSC_LAUNCH1(GG, KK, ND, NBB) \
         hipLaunchKernelGGL((osc_group_kernel_f32<GG, KK, ND, NBB>), grid, dim3(64), 0, st, p, gs.side, gs.side_cap, wc2, gs.prev, n2)
         if (p.k == 13 && p.ndev == 3) {
-            if (G == 8) IRLOSC_LAUNCH1(8, 13, 3, 3);
-            else if (gs.ring_depth == 3) IRLOSC_LAUNCH1(4, 13, 3, 3);
-            else IRLOSC_LAUNCH1(4, 13, 3, 2);
+            IRLOSC_LAUNCH1(4, 13, 3, 2);
         } else if (p.k == 12 && p.ndev == 2) {
-            if (G == 8) IRLOSC_LAUNCH1(8, 12, 2, 3);
-            else if (gs.ring_depth == 3) IRLOSC_LAUNCH1(4, 12, 2, 3);
-            else IRLOSC_LAUNCH1(4, 12, 2, 2);
+            IRLOSC_LAUNCH1(4, 12, 2, 2);
         } else return (int)hipErrorNotSupported;
 #undef IRLOSC_LAUNCH1
         e = hipGetLastError();

@@ -172,6 +172,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     const bool has_tv = p.tvel != nullptr;
     const bool has_wr = (p.cfgflags & IRLOSC_ADMITTANCE) && p.wrench != nullptr;
     unsigned long long ts[8];
+    const unsigned long long rt0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz wall clock
 #define IRLOSC_TS(i) ts[i] = p.dbg ? __builtin_readcyclecounter() : 0ull
     IRLOSC_TS(0);
     if (tile == 0 && lane == 0) *giveup_count = 0;           // consumed by this step's stage 2, which runs later
@@ -211,8 +212,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     // ---------------- register state -----------------------------------------------------------------------
     // Row slots are kept as PAIRS (slots 2p, 2p+1 in one float2) so the multiply-adds are v_pk_fma_f32.
     struct Row { v2f p[P]; float o; };       // `o` = the scalar odd slot (G = 4: slot 6), unused for G = 8
-    v2f Lp[P][24];         // strictly-lower rows of L owned by this lane; upper/diagonal entries are 0
-    float Lo[24];          // odd slot (row 24 on g == 0, zeros elsewhere)
+    v2f Lp[P][24];         // strictly-lower rows 0..23 of L owned by this lane; upper/diagonal entries are 0
     Row dinv, mdq;         // 1/L[i][i], (M dq)[i] for the lane's own rows
     Row Y[K];              // own rows of Y = L^-1 J^T
     uint32_t flags = 0;
@@ -279,87 +279,80 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---------------- stream M: Cholesky column by column -------------------------------------------------
+    // ---------------- stream M: Cholesky of the leading 24 x 24 block, column by column ---------------------------
+    // 24 rows = six full slots on every lane, so this part is packed pairs only.  Row/column 24 is handled after
+    // the loop as one more right-hand side of the forward substitution (L11 y = M[0:24][24] gives row 24 of L).
+    static_assert(G == 4 && ODD && N == 25, "row 24 is treated as the bordering row of a 24 x 24 factor");
+    auto load_row24 = [&](const float* row, Row& d) {          // slots 0..5 only
 #pragma unroll
-    for (int ch = 0; ch < NCHM; ++ch) {
+        for (int s = 0; s < LS; ++s) {
+            const float v = row[G * s + g];
+            if (s & 1) d.p[s >> 1].y = v; else d.p[s >> 1].x = v;
+        }
+    };
+#pragma unroll
+    for (int ch = 0; ch < NCHM - 1; ++ch) {
         float* buf = ring + (ch % NB) * SLOT;
         wait_chunks<CI>((NT - 1 - ch) < (NB - 1) ? (NT - 1 - ch) : (NB - 1));   // chunk ch has landed
-        const int R = ch < 6 ? 4 : 1;
-        const int istride = ch < 6 ? GE::STR4 : N;
         Row mrow[4];
         float dqj[4];
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr) {    // all rows of the chunk up front: one LDS round trip per chunk
-            load_row(buf + q * istride + rr * N, mrow[rr]);
+        for (int rr = 0; rr < 4; ++rr) {    // all rows of the chunk up front: one LDS round trip per chunk
+            load_row24(buf + q * GE::STR4 + rr * N, mrow[rr]);
             dqj[rr] = vec[VEC_DQ + q * N + ch * 4 + rr];
         }
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr) {
+        for (int rr = 0; rr < 4; ++rr) {
             const int j = ch * 4 + rr;
             const int sj = j / G, gj = j % G;                    // row j lives in slot sj of group lane gj
             const int pj = sj >> 1;
-            const bool sj_odd_slot = ODD && sj == LS;            // the pivot row sits in the scalar slot
             const v2f dq2 = v2f{dqj[rr], dqj[rr]};
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) mdq.p[pp] = __builtin_elementwise_fma(mrow[rr].p[pp], dq2, mdq.p[pp]);   // M symmetric
-            if (ODD) mdq.o = fmaf(mrow[rr].o, dqj[rr], mdq.o);
             // Order fence (no instructions): instruction selection linearises this one huge basic block as it
             // likes and, left alone, hoists the row-j broadcasts of later columns and sinks the Mdq chain, which
             // keeps hundreds of values live.  Passing the operands through an empty volatile asm pins them.
 #pragma unroll
-            for (int c = 0; c < j; ++c) {
-                if (sj_odd_slot) asm volatile("" : "+v"(Lo[c]));
-                else asm volatile("" : "+v"(Lp[pj < P ? pj : 0][c]));
-            }
+            for (int c = 0; c < j; ++c) asm volatile("" : "+v"(Lp[pj][c]));
             // left-looking column j: acc = M[j][i] - sum_{c<j} L[i][c] L[j][c] for the rows i >= j
-            Row acc = mrow[rr];
+            v2f acc[P];
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) acc[pp] = mrow[rr].p[pp];
 #pragma unroll
             for (int c = 0; c < j; ++c) {
-                const float own = sj_odd_slot ? Lo[c] : ((sj & 1) ? Lp[pj < P ? pj : 0][c].y : Lp[pj < P ? pj : 0][c].x);
+                const float own = (sj & 1) ? Lp[pj][c].y : Lp[pj][c].x;
                 const float ljs = -gbcast<G>(own, gj);
                 const v2f lj = v2f{ljs, ljs};
 #pragma unroll
-                for (int pp = (pj < P ? pj : P); pp < P; ++pp) acc.p[pp] = __builtin_elementwise_fma(Lp[pp][c], lj, acc.p[pp]);
-                if (ODD) {
-                    acc.o = fmaf(Lo[c], ljs, acc.o);
-                    // keep the scalar chain in step with the packed ones: left alone the scheduler sinks it to
-                    // the end of the column and every broadcast value stays live (-> scratch)
-                    asm volatile("" : "+v"(acc.o), "+v"(acc.p[P - 1]));
-                }
+                for (int pp = pj; pp < P; ++pp) acc[pp] = __builtin_elementwise_fma(Lp[pp][c], lj, acc[pp]);
             }
-            float d = gbcast<G>(sget(acc, sj), gj);
+            float d = gbcast<G>((sj & 1) ? acc[pj].y : acc[pj].x, gj);
             flags |= !(d > 0.f) ? IRLOSC_FLAG_M_NOT_PD : 0u;   // also catches NaN
             d = fmaxf(d, 1e-30f);                               // keeps the factorisation finite; the flag tells
             const float di = __builtin_amdgcn_rsqf(d);
             const v2f di2 = v2f{di, di};
             const bool own_row = (g == gj);
             const float below = (g > gj) ? 1.f : 0.f;
-            if (j < 24) {
 #pragma unroll
-                for (int pp = pj + 1; pp < P; ++pp) Lp[pp][j] = acc.p[pp] * di2;
-                if (!sj_odd_slot && pj < P) {   // the pair holding slot sj: rows above / on the diagonal get exact zeros
-                    const v2f sc2 = acc.p[pj] * di2;
-                    if (sj & 1) Lp[pj][j] = v2f{0.f, sc2.y * below};
-                    else Lp[pj][j] = v2f{sc2.x * below, sc2.y};
-                }
-                if (ODD) Lo[j] = acc.o * di;    // row 24 > j always; padding lanes carry exact zeros
+            for (int pp = pj + 1; pp < P; ++pp) Lp[pp][j] = acc[pp] * di2;
+            {   // the pair holding slot sj: rows above / on the diagonal get exact zeros
+                const v2f sc2 = acc[pj] * di2;
+                if (sj & 1) Lp[pj][j] = v2f{0.f, sc2.y * below};
+                else Lp[pj][j] = v2f{sc2.x * below, sc2.y};
             }
-            if (sj_odd_slot) dinv.o = own_row ? di : 0.f;
-            else if (sj & 1) dinv.p[pj < P ? pj : 0].y = own_row ? di : dinv.p[pj < P ? pj : 0].y;
-            else dinv.p[pj < P ? pj : 0].x = own_row ? di : dinv.p[pj < P ? pj : 0].x;
+            if (sj & 1) dinv.p[pj].y = own_row ? di : dinv.p[pj].y;
+            else dinv.p[pj].x = own_row ? di : dinv.p[pj].x;
             // pair pj is complete once the last row of its second slot has been the pivot: row-scale it now
-            if (((j % (2 * G)) == 2 * G - 1 || j == 24) && pj < P) {
+            // (L'[i][c] = L[i][c] / L[i][i]: the substitutions then need no per-column multiply, y_c is the
+            // running b'_c itself)
+            if ((j % (2 * G)) == 2 * G - 1) {
 #pragma unroll
-                for (int c = 0; c <= j && c < 24; ++c) Lp[pj][c] = Lp[pj][c] * dinv.p[pj];
+                for (int c = 0; c <= j; ++c) Lp[pj][c] = Lp[pj][c] * dinv.p[pj];
             }
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) asm volatile("" : "+v"(mdq.p[pp]));
-            if (ODD) asm volatile("" : "+v"(mdq.o));
-            if (j < 24) {
 #pragma unroll
-                for (int pp = (pj < P ? pj : P); pp < P; ++pp) asm volatile("" : "+v"(Lp[pp][j]));
-                if (ODD) asm volatile("" : "+v"(Lo[j]));
-            }
+            for (int pp = pj; pp < P; ++pp) asm volatile("" : "+v"(Lp[pp][j]));
             __builtin_amdgcn_sched_barrier(0);
         }
         // recycle the ring slot just consumed
@@ -367,22 +360,57 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
         issue(ch + NB);
         __builtin_amdgcn_sched_barrier(0);
     }
-    // Row-scale the factor once, L'[i][c] = L[i][c] / L[i][i]: the substitutions below then need no per-column
-    // multiply (y_c is the running b'_c itself) and no final scaling.
-    // Row 24 (the scalar slot, real only on lane 0): its row-scaled entries are handed out over the group,
-    // lane g keeping L'[24][G m + g].  In the substitutions lane g then multiplies them with ITS OWN y values
-    // (slot m of its b'), one FMA per G columns and no broadcast, instead of 24 FMAs on 24 registers per lane.
-    float Lq[24 / G];
-    if (ODD) {
-        const float d24 = gbcast<G>(dinv.o, 0);
+    // ---------------- row 24: the bordering row -----------------------------------------------------------------
+    // M's row 24 arrives laid out exactly like a right-hand side (lane g, slot s holds M[24][4s+g] = M[4s+g][24]).
+    // y = L11^-1 m is row 24 of L, and it comes out DISTRIBUTED (lane g keeps L[24][4m+g]), which is the form the
+    // J substitutions want: there lane g multiplies L'[24][4m+g] with ITS OWN y values, one packed FMA per pair of
+    // slots and no broadcast.
+    v2f Lq[P];                                  // L'[24][4(2p)+g], L'[24][4(2p+1)+g]
+    {
+        constexpr int ch = NCHM - 1;
+        float* buf = ring + (ch % NB) * SLOT;
+        wait_chunks<CI>((NT - 1 - ch) < (NB - 1) ? (NT - 1 - ch) : (NB - 1));
+        Row m24, dqc;
+        load_row(buf + q * N, m24);             // .o = M[24][24] on lane 0, 0 elsewhere
+        load_row(vec + VEC_DQ + q * N, dqc);    // .o = dq[24] on lane 0
+        const float dq24 = gbcast<G>(dqc.o, 0);
+        const float m2424 = gbcast<G>(m24.o, 0);
+        const v2f dq242 = v2f{dq24, dq24};
+        v2f dt = v2f{0.f, 0.f};
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) {
+            mdq.p[pp] = __builtin_elementwise_fma(m24.p[pp], dq242, mdq.p[pp]);     // column 24 into the rows < 24
+            dt = __builtin_elementwise_fma(m24.p[pp], dqc.p[pp], dt);               // row 24 itself
+        }
+        mdq.o = fmaf(m2424, dq24, gsum<G>(dt.x + dt.y));
+        v2f bq[P];
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) bq[pp] = m24.p[pp] * dinv.p[pp];
 #pragma unroll
         for (int c = 0; c < 24; ++c) {
-            const float v = gbcast<G>(Lo[c], 0) * d24;
-            if (c % G == 0) Lq[c / G] = 0.f;
-            Lq[c / G] = (g == c % G) ? v : Lq[c / G];
-        }
+            const int sc = c / G, gc = c % G, pc = sc >> 1;
+            const float ycs = -gbcast<G>((sc & 1) ? bq[pc].y : bq[pc].x, gc);
+            const v2f yc = v2f{ycs, ycs};
 #pragma unroll
-        for (int m = 0; m < 24 / G; ++m) asm volatile("" : "+v"(Lq[m]));
+            for (int pp = pc; pp < P; ++pp) bq[pp] = __builtin_elementwise_fma(Lp[pp][c], yc, bq[pp]);
+        }
+        v2f n2 = bq[0] * bq[0];
+#pragma unroll
+        for (int pp = 1; pp < P; ++pp) n2 = __builtin_elementwise_fma(bq[pp], bq[pp], n2);
+        float d = m2424 - gsum<G>(n2.x + n2.y);
+        flags |= !(d > 0.f) ? IRLOSC_FLAG_M_NOT_PD : 0u;
+        d = fmaxf(d, 1e-30f);
+        const float di = __builtin_amdgcn_rsqf(d);
+        dinv.o = lastpad ? 0.f : di;
+        const v2f di2 = v2f{di, di};
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) Lq[pp] = bq[pp] * di2;
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) asm volatile("" : "+v"(Lq[pp]), "+v"(mdq.p[pp]));
+        asm volatile("" : "+v"(mdq.o));
+        wait_lgkm0();
+        issue(ch + NB);
+        __builtin_amdgcn_sched_barrier(0);
     }
     IRLOSC_TS(2);
     // park Mdq in LDS (own real rows)
@@ -420,7 +448,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
         // column-oriented substitution: y_c = b_c / L[c][c] (owner lane), then b_i -= L[i][c] y_c
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
-            float part24 = 0.f;                  // this lane's share of sum_c L'[24][c] y_c
+            v2f part24 = v2f{0.f, 0.f};          // this lane's share of sum_c L'[24][c] y_c
 #pragma unroll
             for (int c = 0; c < 24; ++c) {
                 const int sc = c / G, gc = c % G, pc = sc >> 1;
@@ -428,13 +456,13 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
                 const v2f yc = v2f{ycs, ycs};
 #pragma unroll
                 for (int pp = pc; pp < P; ++pp) bb[rr].p[pp] = __builtin_elementwise_fma(Lp[pp][c], yc, bb[rr].p[pp]);
-                if (ODD && gc == G - 1) {        // slot sc is final in every lane of the group now
-                    part24 = fmaf(Lq[sc], sget(bb[rr], sc), part24);
+                if (gc == G - 1 && (sc & 1)) {   // pair pc is final in every lane of the group now
+                    part24 = __builtin_elementwise_fma(Lq[pc], bb[rr].p[pc], part24);
                     asm volatile("" : "+v"(part24), "+v"(bb[rr].p[P - 1]));
                 }
             }
             if (ODD) {
-                const float y24 = bb[rr].o - gsum<G>(part24);            // b'_24 sits on lane 0 only
+                const float y24 = bb[rr].o - gsum<G>(part24.x + part24.y);            // b'_24 sits on lane 0 only
                 bb[rr].o = lastpad ? 0.f : y24;
             }
 #pragma unroll
@@ -764,7 +792,9 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     IRLOSC_TS(7);
     if (p.dbg && lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) p.dbg[(size_t)tile * 8 + i] = ts[i];
+        for (int i = 0; i < 8; ++i) p.dbg[(size_t)tile * 10 + i] = ts[i];
+        p.dbg[(size_t)tile * 10 + 8] = rt0;
+        p.dbg[(size_t)tile * 10 + 9] = __builtin_amdgcn_s_memrealtime();
     }
 #undef IRLOSC_TS
 }
