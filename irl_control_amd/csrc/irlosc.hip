@@ -441,9 +441,21 @@ extern "C" int irlosc_download(irlosc_ctx* c, int32_t B, void* u_host, uint32_t*
         unsigned long long rmin = ~0ull, rmax = 0;
         for (int t = 0; t < tiles; ++t) {
             for (int i = 0; i < 7; ++i) acc[i] += (double)(h[(size_t)t * 10 + i + 1] - h[(size_t)t * 10 + i]);
-            rt += (double)(h[(size_t)t * 10 + 9] - h[(size_t)t * 10 + 8]);
-            rmin = std::min(rmin, h[(size_t)t * 10 + 8]);
+            const unsigned long long r0 = h[(size_t)t * 10 + 8] & 0x0fffffffffffffffull;
+            rt += (double)(h[(size_t)t * 10 + 9] - r0);
+            rmin = std::min(rmin, r0);
             rmax = std::max(rmax, h[(size_t)t * 10 + 9]);
+        }
+        {   // where do blocks land?  XCC of tile t vs t % 8, and vs the XCC of tile t + 2048; start order of the second round
+            int same_mod = 0, same_next = 0, cnt_next = 0;
+            for (int t = 0; t < tiles; ++t) {
+                const int x = (int)(h[(size_t)t * 10 + 8] >> 60);
+                same_mod += (x == (t % 8));
+                if (t + 2048 < tiles) { ++cnt_next; same_next += (x == (int)(h[(size_t)(t + 2048) * 10 + 8] >> 60)); }
+            }
+            fprintf(stderr, "[irlosc placement] xcc==tile%%8: %d/%d, xcc(t)==xcc(t+2048): %d/%d; xcc of tiles 0..15:", same_mod, tiles, same_next, cnt_next);
+            for (int t = 0; t < 16 && t < tiles; ++t) fprintf(stderr, " %d", (int)(h[(size_t)t * 10 + 8] >> 60));
+            fprintf(stderr, "\n");
         }
         double tot = 0; for (int i = 0; i < 7; ++i) tot += acc[i];
         fprintf(stderr, "[irlosc phase timing] %d waves, mean cycles/wave %.0f:", tiles, tot / tiles);

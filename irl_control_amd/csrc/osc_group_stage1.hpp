@@ -14,6 +14,9 @@ namespace irlosc {
 struct S2Args;
 template <int K> __device__ __forceinline__ void stage2_body(const S2Args a, int blk, int32_t* list);
 
+#ifndef IRLOSC_PF_DIST
+#define IRLOSC_PF_DIST 2048
+#endif
 namespace grp {
 
 template <int G> struct Geo {
@@ -24,8 +27,8 @@ template <int G> struct Geo {
     static constexpr int LS = NS - 1;                 // the slot that holds row 24 (= G * LS)
     static constexpr int PSTR = (G == 4) ? 25 : 26;   // 16-byte pieces per instance in a 4-row chunk image
     static constexpr int STR4 = PSTR * 4;             // float stride between instances (100 / 104)
-    static constexpr int CI = (TILE * PSTR + 63) / 64;   // DMA instructions per 4-row chunk (7 / 4)
-    static constexpr int C1 = (TILE * N + 63) / 64;      // DMA instructions per 1-row chunk (7 / 4)
+    static constexpr int CI = TILE / 2;                  // DMA instructions per 4-row chunk: two instances each
+    static constexpr int C1 = TILE / 2;                  // DMA instructions per 1-row chunk
     static constexpr int SLOT = TILE * STR4;             // floats per ring slot
     static_assert(G * LS == 24, "row 24 must be lane 0 of the last slot");
     static_assert(CI == C1, "vmcnt bookkeeping assumes equal instruction counts for both chunk kinds");
@@ -63,20 +66,13 @@ template <int G> __device__ __forceinline__ uint32_t gor(uint32_t v) {
     return v;
 }
 
-// ---- LDS-DMA, one instruction per statement (hand-counted; see osc_group.hpp) ------------------------------
-// `active` lanes fetch size bytes from base + off into LDS at lds + lane * size.
-__device__ __forceinline__ void glds16(const float* base, uint32_t off, uint32_t lds) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %[o], %[base]\n\ts_mov_b32 m0, %[keep]"
-                 : [keep] "=&s"(keep) : [o] "v"(off), [base] "s"(base), [lds] "s"(lds) : "memory");
-}
-__device__ __forceinline__ void glds4(const float* base, uint32_t off, uint32_t lds) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"
-                 "global_load_lds_dword %[o], %[base]\n\ts_mov_b32 m0, %[keep]"
-                 : [keep] "=&s"(keep) : [o] "v"(off), [base] "s"(base), [lds] "s"(lds) : "memory");
-}
+// ---- LDS-DMA (global_load_lds), hand-counted: the compiler neither counts nor waits for these loads --------------
+// Instruction issue is what bounds this kernel, so a chunk is ONE asm block with as little scalar bookkeeping as
+// possible.  LDS destination of a DMA instruction = M0 + immediate offset + lane * size; the immediate offset is also
+// added to the global address.  Every instruction of a chunk moves TWO instances (2 x 25 pieces = 50 lanes): its LDS
+// image advances by 50 pieces (immediate offset), its source by two instance strides (one VALU add on the lane
+// offset), so a single lane-dependent register addresses the whole chunk.  EXEC is narrowed to the 50 lanes inside
+// the block only.
 // wait until at most `younger` chunks (CI DMA instructions each) are still in flight; `younger` folds to a
 // constant after unrolling
 template <int CI> __device__ __forceinline__ void wait_chunks(int younger) {
@@ -86,43 +82,80 @@ template <int CI> __device__ __forceinline__ void wait_chunks(int younger) {
         default: wait_vm<2 * CI>(); break;
     }
 }
-
-// DMA helpers.  Tail lanes are switched off with EXEC (no LDS overrun, so ring slots can be adjacent);
-// every helper still issues a compile-time number of instructions (each has >= 1 active lane), which keeps
-// the vmcnt arithmetic static.
-template <int G> __device__ __forceinline__ void dma4rows(const float* src, int stride, float* buf, int lane) {
-    using GE = Geo<G>;
-    const uint32_t lds = lds_addr(buf);
-#pragma unroll
-    for (int j = 0; j < GE::CI; ++j) {
-        const int x = j * 64 + lane;                   // piece slot in the LDS image (PSTR per instance)
-        const int inst = x / GE::PSTR;
-        int pc = x - inst * GE::PSTR;
-        pc = pc > 24 ? 24 : pc;                        // pad piece (G = 8): re-fetch the last real one
-        if (x < GE::TILE * GE::PSTR) glds16(src, (uint32_t)(inst * stride + pc * 4) * 4u, lds + j * 1024);
-    }
+// lane offset of piece `lane` in a two-instance group: instance lane / 25, piece lane % 25 (lanes >= 50 are masked)
+template <int PIECE_BYTES> __device__ __forceinline__ uint32_t pair_offset(int lane, int stride_bytes) {
+    return (uint32_t)(lane * PIECE_BYTES + (lane >= 25 ? stride_bytes - 25 * PIECE_BYTES : 0));
 }
-template <int G> __device__ __forceinline__ void dma1row(const float* src, int stride, float* buf, int lane) {
-    using GE = Geo<G>;
-    const uint32_t lds = lds_addr(buf);
-    // used only three times per wave: recompute the offsets from an opaque copy of the lane id instead of letting
-    // the compiler keep 7 more address registers alive through the register-critical phases
-    asm volatile("" : "+v"(lane));
-#pragma unroll
-    for (int j = 0; j < GE::C1; ++j) {
-        const int x = j * 64 + lane;
-        const int inst = x / N;
-        const int e = x - inst * N;
-        if (x < GE::TILE * N) glds4(src, (uint32_t)(inst * stride + e) * 4u, lds + j * 256);
-    }
+// 4-row chunk: 16 instances x 25 pieces of 16 B -> 8 instructions.  STRIDE = bytes between instances.
+template <int STRIDE> __device__ __forceinline__ void dma4rows(const float* src, float* buf, int lane) {
+    uint32_t t = pair_offset<16>(lane, STRIDE), km;
+    unsigned long long ke;
+    constexpr int D = 2 * STRIDE - 800;           // source advance per instruction, net of the immediate offset
+    asm volatile(
+        "s_mov_b32 %[km], m0\n\ts_mov_b64 %[ke], exec\n\ts_mov_b32 m0, %[lds]\n\t"
+        "s_mov_b32 exec_lo, -1\n\ts_mov_b32 exec_hi, 0x3ffff\n\t"
+        "global_load_lds_dwordx4 %[t], %[b]\n\tv_add_u32 %[t], %[d], %[t]\n\t"
+        "global_load_lds_dwordx4 %[t], %[b] offset:800\n\tv_add_u32 %[t], %[d], %[t]\n\t"
+        "global_load_lds_dwordx4 %[t], %[b] offset:1600\n\tv_add_u32 %[t], %[d], %[t]\n\t"
+        "global_load_lds_dwordx4 %[t], %[b] offset:2400\n\tv_add_u32 %[t], %[d], %[t]\n\t"
+        "global_load_lds_dwordx4 %[t], %[b] offset:3200\n\tv_add_u32 %[t], %[d], %[t]\n\t"
+        "global_load_lds_dwordx4 %[t], %[b] offset:4000\n\tv_add_u32 %[t], %[d6], %[t]\n\t"
+        "s_add_u32 m0, m0, 0x12c0\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[t], %[b]\n\tv_add_u32 %[t], %[d], %[t]\n\t"
+        "global_load_lds_dwordx4 %[t], %[b] offset:800\n\t"
+        "s_mov_b64 exec, %[ke]\n\ts_mov_b32 m0, %[km]"
+        : [t] "+v"(t), [km] "=&s"(km), [ke] "=&s"(ke)
+        : [b] "s"(src), [lds] "s"(lds_addr(buf)), [d] "i"(D), [d6] "i"(D + 4800)
+        : "memory", "scc");
 }
-// contiguous block of PIECES 16-byte pieces: (PIECES + 63) / 64 instructions
+// 1-row chunk: 16 instances x 25 dwords -> 8 instructions of 4 B per lane
+template <int STRIDE> __device__ __forceinline__ void dma1row(const float* src, float* buf, int lane) {
+    uint32_t t = pair_offset<4>(lane, STRIDE), km;
+    unsigned long long ke;
+    constexpr int D = 2 * STRIDE - 200;
+    asm volatile(
+        "s_mov_b32 %[km], m0\n\ts_mov_b64 %[ke], exec\n\ts_mov_b32 m0, %[lds]\n\t"
+        "s_mov_b32 exec_lo, -1\n\ts_mov_b32 exec_hi, 0x3ffff\n\t"
+        "global_load_lds_dword %[t], %[b]\n\tv_add_u32 %[t], %[d], %[t]\n\t"
+        "global_load_lds_dword %[t], %[b] offset:200\n\tv_add_u32 %[t], %[d], %[t]\n\t"
+        "global_load_lds_dword %[t], %[b] offset:400\n\tv_add_u32 %[t], %[d], %[t]\n\t"
+        "global_load_lds_dword %[t], %[b] offset:600\n\tv_add_u32 %[t], %[d], %[t]\n\t"
+        "global_load_lds_dword %[t], %[b] offset:800\n\tv_add_u32 %[t], %[d], %[t]\n\t"
+        "global_load_lds_dword %[t], %[b] offset:1000\n\tv_add_u32 %[t], %[d], %[t]\n\t"
+        "global_load_lds_dword %[t], %[b] offset:1200\n\tv_add_u32 %[t], %[d], %[t]\n\t"
+        "global_load_lds_dword %[t], %[b] offset:1400\n\t"
+        "s_mov_b64 exec, %[ke]\n\ts_mov_b32 m0, %[km]"
+        : [t] "+v"(t), [km] "=&s"(km), [ke] "=&s"(ke)
+        : [b] "s"(src), [lds] "s"(lds_addr(buf)), [d] "i"(D)
+        : "memory", "scc");
+}
+// contiguous block of PIECES <= 128 16-byte pieces: (PIECES + 63) / 64 instructions, the last one partial
 template <int PIECES> __device__ __forceinline__ void dmalinear(const float* src, float* buf, int lane) {
-    const uint32_t lds = lds_addr(buf);
-#pragma unroll
-    for (int j = 0; j < (PIECES + 63) / 64; ++j) {
-        const int x = j * 64 + lane;
-        if (x < PIECES) glds16(src, (uint32_t)x * 16u, lds + j * 1024);
+    static_assert(PIECES >= 1 && PIECES <= 128, "one or two instructions");
+    const uint32_t t = (uint32_t)lane * 16u;
+    uint32_t km;
+    unsigned long long ke;
+    constexpr int TAIL = PIECES > 64 ? PIECES - 64 : PIECES;                      // active lanes of the last instruction
+    constexpr unsigned long long MASK = TAIL >= 64 ? ~0ull : ((1ull << (TAIL & 63)) - 1ull);
+    if constexpr (PIECES > 64) {
+        asm volatile(
+            "s_mov_b32 %[km], m0\n\ts_mov_b64 %[ke], exec\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %[t], %[b]\n\t"
+            "s_mov_b32 exec_lo, %[mlo]\n\ts_mov_b32 exec_hi, %[mhi]\n\t"
+            "global_load_lds_dwordx4 %[t], %[b] offset:1024\n\t"
+            "s_mov_b64 exec, %[ke]\n\ts_mov_b32 m0, %[km]"
+            : [km] "=&s"(km), [ke] "=&s"(ke)
+            : [t] "v"(t), [b] "s"(src), [lds] "s"(lds_addr(buf)), [mlo] "i"((int)(MASK & 0xffffffffull)), [mhi] "i"((int)(MASK >> 32))
+            : "memory", "scc");
+    } else {
+        asm volatile(
+            "s_mov_b32 %[km], m0\n\ts_mov_b64 %[ke], exec\n\ts_mov_b32 m0, %[lds]\n\t"
+            "s_mov_b32 exec_lo, %[mlo]\n\ts_mov_b32 exec_hi, %[mhi]\n\t"
+            "global_load_lds_dwordx4 %[t], %[b]\n\t"
+            "s_mov_b64 exec, %[ke]\n\ts_mov_b32 m0, %[km]"
+            : [km] "=&s"(km), [ke] "=&s"(ke)
+            : [t] "v"(t), [b] "s"(src), [lds] "s"(lds_addr(buf)), [mlo] "i"((int)(MASK & 0xffffffffull)), [mhi] "i"((int)(MASK >> 32))
+            : "memory", "scc");
     }
 }
 
@@ -177,6 +210,19 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     IRLOSC_TS(0);
     if (tile == 0 && lane == 0) *giveup_count = 0;           // consumed by this step's stage 2, which runs later
 
+    // Device record and gains of device g first: loads retire in order, so anything issued behind the streams
+    // below would make the task-error code wait for megabytes it does not need.  (Unconditional, clamped index:
+    // a select on the loaded values would make the wave wait for them right here.)
+    auto gains_ptr = [&]() { return p.gains + (p.gains_per_instance ? (size_t)b * NDEV * IRLOSC_GAIN_WORDS : 0); };
+    const int gd = g < NDEV ? g : 0;
+    const DevMeta dm1 = p.dev[gd];
+    float gl[IRLOSC_GAIN_WORDS];
+    {
+        const float* gg = gains_ptr() + gd * IRLOSC_GAIN_WORDS;
+#pragma unroll
+        for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) gl[i] = gg[i];
+    }
+
     // ---------------- prologue --------------------------------------------------------------------------------
     // DMA issue order (CI instructions per chunk, retired in order):
     //   vec(NVEC) C0 C1 | C2 | C3 | ... first pass: C0..C6 = M (6 x 4 rows + row 24), then the J chunks;
@@ -195,12 +241,12 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     auto issue = [&](int m) {
         if (m >= NT) return;
         float* dst = ring + (m % NB) * SLOT;
-        if (m < 6) dma4rows<G>(Mt + m * 4 * N, N * N, dst, lane);
-        else if (m == 6) dma1row<G>(Mt + 24 * N, N * N, dst, lane);
+        if (m < 6) dma4rows<N * N * 4>(Mt + m * 4 * N, dst, lane);
+        else if (m == 6) dma1row<N * N * 4>(Mt + 24 * N, dst, lane);
         else {
             const int jc = (m < NCH1) ? m - NCHM : m - NCH1;
-            if (jc < 3) dma4rows<G>(Jt + jc * 4 * N, K * N, dst, lane);
-            else dma1row<G>(Jt + 12 * N, K * N, dst, lane);
+            if (jc < 3) dma4rows<K * N * 4>(Jt + jc * 4 * N, dst, lane);
+            else dma1row<K * N * 4>(Jt + 12 * N, dst, lane);
         }
     };
     // Rule: after chunk m has been consumed, chunk m + NB is issued into the slot it vacated - except that the
@@ -251,15 +297,10 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     // gains need only ee/tgt/gains.  The rows that depend on dx (branch B) are finished after the J phase.
     // (gains pointer and null-space gain are re-derived where they are used: carrying them through the
     //  register-critical phases spilled them to scratch)
-    auto gains_ptr = [&]() { return p.gains + (p.gains_per_instance ? (size_t)b * NDEV * IRLOSC_GAIN_WORDS : 0); };
     float e6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float kv_own = 0.f;
     if (g < NDEV) {
-        const DevMeta dm = p.dev[g];
-        const float* gg = gains_ptr() + g * IRLOSC_GAIN_WORDS;
-        float gl[IRLOSC_GAIN_WORDS];
-#pragma unroll
-        for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) gl[i] = gg[i];
+        const DevMeta dm = dm1;
         float ee[7], tg[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
@@ -618,6 +659,25 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
         biasr.o = 0.f;
         if (p.cfgflags & IRLOSC_USE_G) load_row_raw(p.bias + (size_t)b * N, biasr);
     }
+    // L2 warm-up for the block that will take over a slot on this XCD next (block ids go round-robin over the 8
+    // XCDs, and 2048 blocks are resident): one dword per 128-byte line of its small vectors, its first M rows and
+    // its first J chunk.  A wave's first memory round trip costs ~4 us under load and nothing can be done in that
+    // time; with the lines already in this XCD's L2 it is a fraction of that.  The loaded values are discarded.
+    {
+        const int ptile = tile + IRLOSC_PF_DIST;
+        if (IRLOSC_PF_DIST > 0 && ptile * TILE + TILE <= p.B) {
+            const size_t pb = (size_t)ptile * TILE;
+            const float* a0 = p.M + (pb + (lane >> 2)) * (N * N) + (lane & 3) * 32;        // 4 lines / instance: rows 0..4
+            const float* a1 = p.J + (pb + (lane >> 2)) * (K * N) + (lane & 3) * 32;        // 4 lines / instance: rows 0..4
+            const float* a2 = lane < 13 ? p.dq + pb * N + lane * 32
+                            : lane < 24 ? p.ee + pb * NDEV * 7 + (lane - 13) * 32
+                            : p.tgt + pb * NDEV * 7 + ((lane < 35 ? lane : 34) - 24) * 32;
+            float d0, d1, d2;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(d0) : "v"(a0));
+            asm volatile("global_load_dword %0, %1, off" : "=v"(d1) : "v"(a1));
+            asm volatile("global_load_dword %0, %1, off" : "=v"(d2) : "v"(a2));
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
     // ---------------- k x k: right-looking Cholesky of A in place (row pairs), cond certificate ---------------------
     bool pdA = true;
@@ -793,7 +853,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     if (p.dbg && lane == 0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) p.dbg[(size_t)tile * 10 + i] = ts[i];
-        p.dbg[(size_t)tile * 10 + 8] = rt0;
+        p.dbg[(size_t)tile * 10 + 8] = rt0 | ((unsigned long long)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & 0xf) << 60);   // XCC_ID in the top bits
         p.dbg[(size_t)tile * 10 + 9] = __builtin_amdgcn_s_memrealtime();
     }
 #undef IRLOSC_TS
