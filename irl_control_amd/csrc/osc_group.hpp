@@ -237,7 +237,7 @@ __device__ __forceinline__ void stage2_body(const S2Args a, int blk, int32_t* ld
             for (int r = 0; r < K; ++r) {
 #pragma unroll
                 for (int c = 0; c <= r; ++c) {
-                    const float a = (side + (size_t)e * side_cap)[(uint32_t)posc];   // uniform base + 32-bit lane offset
+                    const float a = side[(size_t)posc * (NA + K) + e];   // this instance's record: one address, immediate offsets
                     ++e;
                     L[r][c] = a;
                     nA2 = fmaf(c < r ? 2.f * a : a, a, nA2);
@@ -389,7 +389,7 @@ __device__ __forceinline__ void stage2_body(const S2Args a, int blk, int32_t* ld
         // t = P (A + sigma I)^-1 P w  (+ one refinement step against A when sigma > 0)
         float t[K];                            // w is fetched only now: 13 registers less through the iterations
 #pragma unroll
-        for (int i = 0; i < K; ++i) t[i] = (side + (size_t)(NA + i) * side_cap)[(uint32_t)posc];
+        for (int i = 0; i < K; ++i) t[i] = side[(size_t)posc * (NA + K) + NA + i];
         auto project = [&](float (&z)[K]) {
 #pragma unroll
             for (int s0 = 0; s0 < 3; ++s0) {
@@ -476,7 +476,7 @@ inline bool group_kernel_supports(int dtype, int n, int k, int ndev) {
 struct GroupScratch {
     int32_t* worklist2;   // [max_batch] instances stage 2 hands to the generic kernel
     int32_t* counts;      // [1] length of worklist2
-    float* side;          // [(K(K+1)/2 + K)][side_cap]: A and w of flagged instances, indexed by instance
+    float* side;          // [side_cap][K(K+1)/2 + K]: A and w of flagged instances, one record per instance
     int side_cap;
     bool stage1_only;         // roofline timing: launch the dominant kernel alone
     bool defer_stage2;        // pipelined steps: leave this step's stage 2 to the next launch (or to a flush)

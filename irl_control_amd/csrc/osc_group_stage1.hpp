@@ -14,9 +14,6 @@ namespace irlosc {
 struct S2Args;
 template <int K> __device__ __forceinline__ void stage2_body(const S2Args a, int blk, int32_t* list);
 
-#ifndef IRLOSC_PF_DIST
-#define IRLOSC_PF_DIST 2048
-#endif
 namespace grp {
 
 template <int G> struct Geo {
@@ -183,9 +180,16 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     constexpr int VEC_DQ = 0, VEC_EE = VEC_DQ + TILE * N, VEC_TGT = VEC_EE + TILE * NDEV * 7;
     constexpr int VEC_W = VEC_TGT + TILE * NDEV * 7, VEC_X = VEC_W + TILE * K, VEC_END = VEC_X + TILE * (N + K);
     static_assert(TILE * NA <= SLOT, "the A hand-off area must fit in one ring slot");
-    constexpr int NT = NCH1 + 1;                     // ring chunks: first pass, then J rows 0..3 once more (J0')
-    constexpr int RJ0 = K < 4 ? K : 4;               // second pass over J: rows [0, RJ0) from the ring,
-    constexpr int NDL = K - RJ0;                     //   rows [RJ0, K) by plain loads into registers
+    constexpr int NT = NCH1;                         // ring chunks (one pass; the tail of J simply stays in the ring)
+    // Second pass over J (u -= J^T t): rows 8..11 (chunk J2) are still in their ring slot and, for k = 13, row 12
+    // (chunk J3) in the other one; only rows 0..7 are fetched again, straight into registers.
+    constexpr int NDL = 8;                           // rows [0, NDL) by plain loads into registers
+    static_assert(NCHJ >= 3 && NDL == 4 * (NCHJ - 1 - (HASJ3 ? 1 : 0)), "rows 8.. must be the resident chunks");
+    constexpr int SLOT_J2 = (NCHM + 2) % NB;         // ring slot of chunk J2 (rows 8..11)
+    constexpr int SLOT_A = 1 - SLOT_J2;              // the other slot: J3 (k = 13: its first 400 floats) + the A hand-off area
+    static_assert(NB == 2, "resident-tail bookkeeping assumes two ring slots");
+    constexpr int A_OFF = HASJ3 ? TILE * N : 0;      // A records start behind J3's row
+    constexpr int A_FIT = (SLOT - A_OFF) / NA < TILE ? (SLOT - A_OFF) / NA : TILE;   // instances whose record fits in the slot
     __shared__ __attribute__((aligned(16))) float ring[NB * SLOT];
     __shared__ __attribute__((aligned(16))) float vec[VEC_END];
 
@@ -228,30 +232,28 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     //   vec(NVEC) C0 C1 | C2 | C3 | ... first pass: C0..C6 = M (6 x 4 rows + row 24), then the J chunks;
     //   "| Cn" = issued right after chunk n-2 has been consumed, into the slot (n % 2) that chunk vacated.
     //   Second pass over J (for u -= J^T t; keeping J resident would cost 21 KB of LDS and the second wave
-    //   per SIMD): J0' (rows 0..3) is issued into the ring when the last-but-one first-pass chunk is consumed;
-    //   the other rows are loaded straight into registers at the start of the k x k phase, when Y has died
-    //   (L2 / Infinity Cache hits), so the torque phase finds everything in place and never waits on a DMA.
+    //   per SIMD): the last chunks (rows 8..) stay where they are in the ring; rows 0..7 are loaded straight into
+    //   registers at the start of the k x k phase, when Y has died, so the torque phase finds everything in place
+    //   and never waits on memory.
     dmalinear<PDQ>(p.dq + t0 * N, vec + VEC_DQ, lane);
     dmalinear<PEE>(p.ee + t0 * NDEV * 7, vec + VEC_EE, lane);
     dmalinear<PEE>(p.tgt + t0 * NDEV * 7, vec + VEC_TGT, lane);
     const float* Mt = p.M + t0 * (N * N);
     const float* Jt = p.J + t0 * (K * N);
-    // chunk n of the first pass / chunk jc of the second pass -> DMA
-    // chunk m lives in ring slot m % NB; m < NCH1: first pass (M then J), else second pass over J
+    // chunk m lives in ring slot m % NB: M (6 x 4 rows + row 24), then J
     auto issue = [&](int m) {
         if (m >= NT) return;
         float* dst = ring + (m % NB) * SLOT;
         if (m < 6) dma4rows<N * N * 4>(Mt + m * 4 * N, dst, lane);
         else if (m == 6) dma1row<N * N * 4>(Mt + 24 * N, dst, lane);
         else {
-            const int jc = (m < NCH1) ? m - NCHM : m - NCH1;
+            const int jc = m - NCHM;
             if (jc < 3) dma4rows<K * N * 4>(Jt + jc * 4 * N, dst, lane);
             else dma1row<K * N * 4>(Jt + 12 * N, dst, lane);
         }
     };
-    // Rule: after chunk m has been consumed, chunk m + NB is issued into the slot it vacated - except that the
-    // successor of the LAST first-pass chunk waits until the A hand-off area, which borrows that slot, has been
-    // read.  Hence "younger DMAs possibly in flight while consuming m" = min(NB - 1, NT - 1 - m) chunks.
+    // Rule: after chunk m has been consumed, chunk m + NB is issued into the slot it vacated.  Hence "younger DMAs
+    // possibly in flight while consuming m" = min(NB - 1, NT - 1 - m) chunks.
 #pragma unroll
     for (int m = 0; m < NB; ++m) issue(m);
 
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
             __builtin_amdgcn_sched_barrier(0);
         }
         wait_lgkm0();
-        if (n != NCH1 - 1) issue(n + NB);             // the last first-pass slot is lent to the A hand-off area first
+        issue(n + NB);                                // nothing beyond the last chunk: the tail of J stays resident
         __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -590,9 +592,11 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
         for (int m = 0; m < KP; ++m) Ac[c][m] = v2f{0.f, 0.f};
     }
 #define IRLOSC_AE(r, c) (((r) & 1) ? Ac[c][(r) / 2].y : Ac[c][(r) / 2].x)
-    // Park A in the ring slot that the second J pass has not claimed yet (J0' went to the other one).  It is
-    // read back only by flagged instances, which hand A and w to the second stage.
-    float* aq = ring + ((NCH1 - 1) % NB) * SLOT + q * NA;
+    // Park A next to the resident tail of J (behind J3's row in its slot; the records that do not fit there go to
+    // the dq | ee | tgt | W area, which is dead by now).  It is read back only by flagged instances, which hand A
+    // and w to the second stage.
+    static_assert((TILE - A_FIT) * NA <= VEC_X - VEC_DQ, "overflow A records must fit in the dead vector area");
+    float* aq = q < A_FIT ? ring + SLOT_A * SLOT + A_OFF + q * NA : vec + VEC_DQ + (q - A_FIT) * NA;
     float nA2 = 0.f;
     // row by row: first all partial dots of the row, then the butterfly steps over the whole row, so that a
     // DPP add never has to wait on the instruction right before it (rows 0..2 are too short to hide it)
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     IRLOSC_TS(5);
     asm volatile("" : "+v"(nA2));
     __builtin_amdgcn_sched_barrier(0);
-    // second pass over J, rows RJ0..K-1: own-row elements straight from global memory (the registers Y held are free)
+    // second pass over J, rows 0..7: own-row elements straight from global memory (the registers Y held are free)
     // and the bias forces of the own rows.  Raw loads only: nothing here may consume a loaded value, or the wave
     // would sit out the memory latency right now (the padding slot carries junk that is never stored).
     Row jd[NDL > 0 ? NDL : 1];
@@ -653,30 +657,11 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
             }
         };
 #pragma unroll
-        for (int r = 0; r < NDL; ++r) load_row_raw(jg + (RJ0 + r) * N, jd[r]);
+        for (int r = 0; r < NDL; ++r) load_row_raw(jg + r * N, jd[r]);
 #pragma unroll
         for (int pp = 0; pp < P; ++pp) biasr.p[pp] = v2f{0.f, 0.f};
         biasr.o = 0.f;
         if (p.cfgflags & IRLOSC_USE_G) load_row_raw(p.bias + (size_t)b * N, biasr);
-    }
-    // L2 warm-up for the block that will take over a slot on this XCD next (block ids go round-robin over the 8
-    // XCDs, and 2048 blocks are resident): one dword per 128-byte line of its small vectors, its first M rows and
-    // its first J chunk.  A wave's first memory round trip costs ~4 us under load and nothing can be done in that
-    // time; with the lines already in this XCD's L2 it is a fraction of that.  The loaded values are discarded.
-    {
-        const int ptile = tile + IRLOSC_PF_DIST;
-        if (IRLOSC_PF_DIST > 0 && ptile * TILE + TILE <= p.B) {
-            const size_t pb = (size_t)ptile * TILE;
-            const float* a0 = p.M + (pb + (lane >> 2)) * (N * N) + (lane & 3) * 32;        // 4 lines / instance: rows 0..4
-            const float* a1 = p.J + (pb + (lane >> 2)) * (K * N) + (lane & 3) * 32;        // 4 lines / instance: rows 0..4
-            const float* a2 = lane < 13 ? p.dq + pb * N + lane * 32
-                            : lane < 24 ? p.ee + pb * NDEV * 7 + (lane - 13) * 32
-                            : p.tgt + pb * NDEV * 7 + ((lane < 35 ? lane : 34) - 24) * 32;
-            float d0, d1, d2;
-            asm volatile("global_load_dword %0, %1, off" : "=v"(d0) : "v"(a0));
-            asm volatile("global_load_dword %0, %1, off" : "=v"(d1) : "v"(a1));
-            asm volatile("global_load_dword %0, %1, off" : "=v"(d2) : "v"(a2));
-        }
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---------------- k x k: right-looking Cholesky of A in place (row pairs), cond certificate ---------------------
@@ -741,14 +726,16 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     const float cond_bound = sqrtf(nA2) * nW2;        // >= cond_2(A) for SPD A
     const bool plain = pdA && t_finite(cond_bound) && (!small_det || cond_bound < 0.99e5f);
     flags |= small_det ? IRLOSC_FLAG_PINV_BRANCH : 0u;
-    // Flagged instances hand A and w to the second stage now (side[e][b], indexed by instance: no atomics;
-    // stage-2 blocks compact their span from the flag words), which frees the slot for J1'.
+    // Flagged instances hand A and w to the second stage now: one contiguous record of NA + K floats per instance
+    // (indexed by instance: no atomics; stage-2 blocks compact their span from the flag words).  The group writes
+    // 16 contiguous bytes per store instruction, so a record costs its own bytes in write traffic and no more.
     if (!plain) {
         flags |= IRLOSC_FLAG_EIGEN_PATH;
-        for (int e = g; e < NA; e += G) side[(size_t)e * side_cap + b] = aq[e];
+        float* rec = side + (size_t)b * (NA + K);
+        for (int e = g; e < NA; e += G) rec[e] = aq[e];
 #pragma unroll
         for (int r = 0; r < K; ++r)
-            if ((r % G) == g) side[(size_t)(NA + r) * side_cap + b] = IRLOSC_WE(r);
+            if ((r % G) == g) rec[NA + r] = IRLOSC_WE(r);
     }
     __builtin_amdgcn_sched_barrier(0);
     float t[K];
@@ -788,24 +775,24 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
 #pragma unroll
     for (int pp = 0; pp < P; ++pp) jt.p[pp] = v2f{0.f, 0.f};
     jt.o = 0.f;
-    wait_vm<0>();                             // J0' and the register rows were issued a whole k x k phase ago
+    wait_vm<0>();                             // the register rows were issued a whole k x k phase ago
     {
-        const float* buf = ring + (NCH1 % NB) * SLOT;
-#pragma unroll
-        for (int rr = 0; rr < RJ0; ++rr) {
-            Row jr;
-            load_row(buf + q * GE::STR4 + rr * N, jr);
-            const v2f t2 = v2f{t[rr], t[rr]};
-#pragma unroll
-            for (int pp = 0; pp < P; ++pp) jt.p[pp] = __builtin_elementwise_fma(jr.p[pp], t2, jt.p[pp]);
-            if (ODD) jt.o = fmaf(jr.o, t[rr], jt.o);
-        }
 #pragma unroll
         for (int r = 0; r < NDL; ++r) {
-            const v2f t2 = v2f{t[RJ0 + r], t[RJ0 + r]};
+            const v2f t2 = v2f{t[r], t[r]};
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) jt.p[pp] = __builtin_elementwise_fma(jd[r].p[pp], t2, jt.p[pp]);
-            if (ODD) jt.o = fmaf(jd[r].o, t[RJ0 + r], jt.o);      // padding lanes: junk in, never stored
+            if (ODD) jt.o = fmaf(jd[r].o, t[r], jt.o);      // padding lanes: junk in, never stored
+        }
+#pragma unroll
+        for (int r = NDL; r < K; ++r) {                     // the resident tail: J2 (4 rows), then J3 (k = 13)
+            Row jr;
+            if (r < NDL + 4) load_row(ring + SLOT_J2 * SLOT + q * GE::STR4 + (r - NDL) * N, jr);
+            else load_row(ring + SLOT_A * SLOT + q * N, jr);
+            const v2f t2 = v2f{t[r], t[r]};
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) jt.p[pp] = __builtin_elementwise_fma(jr.p[pp], t2, jt.p[pp]);
+            if (ODD) jt.o = fmaf(jr.o, t[r], jt.o);
         }
         wait_lgkm0();
         __builtin_amdgcn_sched_barrier(0);
