@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 B="python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-secondary"
 rm -rf gpurun_out/prof_$tag gpurun_out/pmc_fetch_$tag gpurun_out/pmc_write_$tag
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o prof -- $B > gpurun_out/bench_prof_$tag.log 2>&1
-tail -1 gpurun_out/bench_prof_$tag.log > gpurun_out/bench_under_rocprof_$tag.json
+grep -a "^{\"metric\"" gpurun_out/bench_prof_$tag.log | tail -1 > gpurun_out/bench_under_rocprof_$tag.json
 python tools/rocprof_summary.py $(find gpurun_out/prof_$tag -name "*.db" | head -1) > gpurun_out/kernel_stats_$tag.txt 2>&1; cat gpurun_out/kernel_stats_$tag.txt
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch_$tag -o pmc -- $B > gpurun_out/pmc_fetch_$tag.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write_$tag -o pmc -- $B > gpurun_out/pmc_write_$tag.log 2>&1
