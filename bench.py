@@ -71,8 +71,10 @@ def cpu_baseline(lay, gains, arrays, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--preroll", type=int, default=2000,
+                    help="extra UNTIMED steps before the warm-up: after the idle set-up phase the power management needs ~50 ms of load to settle")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--slots", type=int, default=4)
@@ -97,7 +99,7 @@ def main():
 
     from irl_control_amd import BatchedOSC, sharding, synth
 
-    def measure(dtype_name, steps, warmup, with_check):
+    def measure(dtype_name, steps, warmup, with_check, preroll):
         dt = np.float32 if dtype_name == "f32" else np.float64
         esz = 4 if dtype_name == "f32" else 8
         B = args.batch
@@ -114,6 +116,8 @@ def main():
                               gains["null_kv"])
             else:
                 del arr
+        if preroll > 0:                                          # untimed: lets the clocks settle after the idle set-up
+            osc.step_resident(preroll)
         if warmup > 0:
             osc.step_resident(warmup)
         if world > 1:
@@ -130,9 +134,11 @@ def main():
             mk = torch.tensor([ms_kernel], device="cuda", dtype=torch.float64)
             dist.all_reduce(mk, op=dist.ReduceOp.MAX)
             ms_kernel = float(mk[0])
-        bytes_launch = algorithmic_bytes(lay.n, lay.k, lay.ndev, lay.admittance, esz) * B
-        # dominant kernel alone (stage 1 of the group path / the generic kernel), HIP events on its stream
-        ms_dom = osc.time_dominant_kernel(min(200, max(10, steps // 2)))
+        bytes_step = algorithmic_bytes(lay.n, lay.k, lay.ndev, lay.admittance, esz) * B
+        spl = osc.steps_per_launch              # the throughput path chains this many steps into one launch
+        bytes_launch = bytes_step * spl
+        # dominant kernel alone (the fused train launch of the group path / the generic kernel), HIP events on its stream
+        ms_dom = osc.time_dominant_kernel(min(200, max(10 * spl, steps // 2)))
         if world > 1:
             md = torch.tensor([ms_dom], device="cuda", dtype=torch.float64)
             dist.all_reduce(md, op=dist.ReduceOp.MAX)
@@ -141,9 +147,9 @@ def main():
         res = dict(value=rate, ms_per_step=elapsed / steps * 1e3, kernel=osc.kernel_name,
                    roofline=dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                                  frac=achieved / HBM_PEAK_GBS, traffic=measured_traffic(osc.kernel_name),
-                                 kernel=osc.kernel_name + (":fused(stage1 of step i + stage2 of step i-1)" if "group" in osc.kernel_name else ""),
-                                 kernel_ms=ms_dom, step_ms_events=ms_kernel,
-                                 whole_step_achieved=bytes_launch / (ms_kernel * 1e-3) / 1e9,
+                                 kernel=osc.kernel_name + ((":fused(stage 1 of %d chained steps + riding stage 2 of the previous launch)" % spl) if "group" in osc.kernel_name else ""),
+                                 kernel_ms=ms_dom, steps_per_launch=spl, step_ms_events=ms_kernel,
+                                 whole_step_achieved=bytes_step / (ms_kernel * 1e-3) / 1e9,
                                  algorithmic_bytes_per_launch=bytes_launch))
         check = None
         if with_check:
@@ -153,7 +159,7 @@ def main():
         osc.close()
         return res, check
 
-    primary, chk = measure(args.dtype, args.steps, args.warmup, with_check=(rank == 0))
+    primary, chk = measure(args.dtype, args.steps, args.warmup, with_check=(rank == 0), preroll=args.preroll)
     out = {
         "metric": "OSC control steps/sec", "value": primary["value"], "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": primary["ms_per_step"],
@@ -163,6 +169,7 @@ def main():
                                f"layout {args.layout}: k=13 task rows (both arms xyz+abg, base yaw), gravity + "
                                f"null-space on, inputs resident in HBM, {args.slots} rotating batches",
                    "instances_per_gpu": args.batch, "layout": args.layout, "kernel": primary["kernel"],
+                   "preroll_steps": args.preroll, "steps_per_launch": primary["roofline"]["steps_per_launch"],
                    "sharding": f"{world} x independent shards, no data-path collective"},
         "roofline": primary["roofline"],
     }
@@ -180,7 +187,8 @@ def main():
                                     "note": "GPU vs float64 oracle on the same (dtype-rounded) inputs"}
     if world == 1 and not args.no_secondary:
         other = "f64" if args.dtype == "f32" else "f32"
-        sec, _ = measure(other, max(20, args.steps // 4), max(5, args.warmup // 4), with_check=False)
+        sec, _ = measure(other, max(20, min(200, args.steps // 4)), max(5, min(20, args.warmup // 4)), with_check=False,
+                         preroll=min(args.preroll, 40))
         out["secondary"] = {"dtype": other, "value": sec["value"], "ms_per_step": sec["ms_per_step"],
                             "kernel": sec["kernel"], "roofline": sec["roofline"]}
     if rank == 0:

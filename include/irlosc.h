@@ -121,16 +121,21 @@ int irlosc_set_targets(irlosc_ctx* ctx, int32_t slot, int32_t B, const void* tgt
 int irlosc_step(irlosc_ctx* ctx, int32_t slot, int32_t B, void* u_host, uint32_t* flags_host);
 
 /* Benchmark form: `iters` back-to-back steps on resident data, slot = (first_slot + i) % n_slots,
- * no host copies.  *ms_total receives the HIP-event time of the whole region measured on the
- * library's own stream; *ms_kernel_avg the mean per-launch duration. */
+ * no host copies.  Consecutive steps are independent batches, so the throughput path chains several of them
+ * into one launch and lets the eigen-path stage of a launch's steps ride in the next launch; everything is
+ * complete when the call returns, and irlosc_download then yields the LAST step's outputs.  *ms_total receives
+ * the HIP-event time of the whole region on the library's own stream; *ms_kernel_avg = *ms_total / iters. */
 int irlosc_step_resident(irlosc_ctx* ctx, int32_t first_slot, int32_t B, int32_t iters,
                          float* ms_total, float* ms_kernel_avg);
 
-/* Roofline support: mean duration of the DOMINANT kernel launch of a step, measured live with one HIP event
- * pair per launch on the library's stream, over `iters` (<= 256) steps run exactly like
- * irlosc_step_resident.  Group path: the fused launch (stage 1 of step i + the riding stage 2 of step i-1);
- * generic path: the generic kernel.  Outputs are complete, as after irlosc_step_resident. */
+/* Roofline support: mean duration of the DOMINANT kernel launch, measured live with one HIP event pair per launch
+ * on the library's stream, over about `iters` (<= 256) steps run exactly like irlosc_step_resident.  Group path:
+ * the fused launch (stage 1 of irlosc_steps_per_launch() chained steps + the riding stage 2 of the previous
+ * launch's steps); generic path: the generic kernel.  Outputs are complete, as after irlosc_step_resident. */
 int irlosc_time_dominant_kernel(irlosc_ctx* ctx, int32_t slot, int32_t B, int32_t iters, float* ms_avg);
+/* Steps chained in one launch by irlosc_step_resident / irlosc_time_dominant_kernel (1 on the generic path):
+ * the algorithmic bytes of one dominant launch = this many steps' worth. */
+int irlosc_steps_per_launch(const irlosc_ctx* ctx);
 
 int irlosc_download(irlosc_ctx* ctx, int32_t B, void* u_host, uint32_t* flags_host);
 int irlosc_sync(irlosc_ctx* ctx);

@@ -18,7 +18,8 @@ FLAG_VEL_BRANCH_B, FLAG_BAD_JIDX, FLAG_NONFINITE = 16, 32, 64
 EXPORTS = ["irlosc_abi_version", "irlosc_device_count", "irlosc_create", "irlosc_destroy",
            "irlosc_last_error", "irlosc_kernel_name", "irlosc_set_gains", "irlosc_upload",
            "irlosc_set_targets", "irlosc_step", "irlosc_step_resident", "irlosc_download",
-           "irlosc_sync", "irlosc_step_device", "irlosc_time_dominant_kernel"]
+           "irlosc_sync", "irlosc_step_device", "irlosc_time_dominant_kernel",
+           "irlosc_steps_per_launch"]
 
 
 class Cfg(C.Structure):
@@ -63,6 +64,7 @@ def load():
     lib.irlosc_step.argtypes = [vp, i32, i32, vp, vp]
     lib.irlosc_step_resident.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.irlosc_time_dominant_kernel.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_float)]
+    lib.irlosc_steps_per_launch.argtypes = [vp]
     lib.irlosc_download.argtypes = [vp, i32, vp, vp]
     lib.irlosc_sync.argtypes = [vp]
     lib.irlosc_step_device.argtypes = [vp, i32] + [vp] * 11

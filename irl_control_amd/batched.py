@@ -109,6 +109,14 @@ class BatchedOSC:
         self._chk(self.lib.irlosc_time_dominant_kernel(self._h, slot, B, iters, C.byref(a)))
         return a.value
 
+    @property
+    def steps_per_launch(self) -> int:
+        """Steps chained into one launch by step_resident / time_dominant_kernel (1 on the generic path)."""
+        n = int(self.lib.irlosc_steps_per_launch(self._h))
+        if n < 1:
+            raise _lib.IrloscError(f"libirlosc error {n}")
+        return n
+
     def download(self, B: Optional[int] = None):
         B = self._B[0] if B is None else B
         u = np.empty((B, self.layout.n), dtype=self.dtype)

@@ -31,29 +31,35 @@ struct irlosc_ctx {
     // resident inputs, one set per slot
     std::vector<void*> dM, dJ, ddq, dbias, dee, dwrench, dtgt, dtvel;
     std::vector<int> has_wrench, has_tvel, uploaded, targeted;
-    // Outputs and the stage-2 hand-off buffers exist twice: irlosc_step_resident pipelines consecutive steps on
-    // the group path (stage 2 of step i rides in the stage-1 launch of step i+1), alternating the two sets.
-    void* du2[2] = {nullptr, nullptr};
-    uint32_t* dflags2[2] = {nullptr, nullptr};
-    float* dside2[2] = {nullptr, nullptr};
-    int32_t* dwl2[2] = {nullptr, nullptr};
-    int32_t* dwc2[2] = {nullptr, nullptr};
+    // Output sets (u, flags, stage-2 hand-off records, give-up list).  The group path chains up to TRAIN steps in
+    // one launch and the stage 2 of a train's steps rides in the NEXT train, so two trains' worth of sets exist;
+    // the generic path only ever uses set 0.
+    static constexpr int TRAIN_MAX = 8;
+    static constexpr int NSETS_MAX = 2 * TRAIN_MAX;
+    int nsets = 1;
+    int train = 1;                     // steps per launch in irlosc_step_resident (IRLOSC_TRAIN=1..8 overrides)
+    void* du_set[NSETS_MAX] = {};
+    uint32_t* dflags_set[NSETS_MAX] = {};
+    float* dside_set[NSETS_MAX] = {};
+    int32_t* dwl_set[NSETS_MAX] = {};
+    int32_t* dwc_set[NSETS_MAX] = {};
+    static constexpr int NTABLES = 16;
+    void* dtable[NTABLES] = {};        // device copies of the train tables: a small content-addressed cache
+    std::vector<unsigned char> htable[NTABLES];   // (a resident loop repeats a handful of tables; no copy then)
+    int table_next = 0;
     int cur = 0;                       // output set written by the most recent step
-    hipEvent_t tev_begin = nullptr, tev_end = nullptr;   // timing events handed to the next group launch (or null)
+    int set_half = 0;                  // which half of the sets the next train of irlosc_step_resident writes
+    hipEvent_t tev_begin = nullptr, tev_end = nullptr;   // timing events handed to the next train launch (or null)
     std::vector<hipEvent_t> tev_pool;
-    bool pending = false;              // a deferred stage 2 (of the step that wrote set `pending_set`) is outstanding
-    bool defer_next = false;           // set by irlosc_step_resident around its launches
-    int pending_nfast = 0;
-    int pending_set = 0;
-    KParams<float> pending_p{};
-    void* du = nullptr;                // = du2[cur]
-    uint32_t* dflags = nullptr;        // = dflags2[cur]
+    struct PendingStep { KParams<float> p; int set; int nfast; };
+    std::vector<PendingStep> pending;  // steps whose stage 2 has not run yet (it rides in the next train, or is flushed)
+    void* du = nullptr;                // = du_set[cur]
+    uint32_t* dflags = nullptr;        // = dflags_set[cur]
     void* dgains = nullptr;   // [nb][ndev][12] in dtype
     void* dnullkv = nullptr;  // [nb]
     int gains_nb = 0;
     unsigned long long* ddbg = nullptr;  // IRLOSC_PHASE_TIMING=1: 8 cycle stamps + 2 wall-clock stamps per stage-1 wave
     int kernel = IRLOSC_KERNEL_GENERIC;
-    bool stage1_only = false; // set only inside irlosc_time_dominant_kernel
     std::string kernel_name;
     std::string err;
 };
@@ -125,13 +131,15 @@ static int validate(const irlosc_cfg* c, int* k_out) {
 static void free_all(irlosc_ctx* c) {
     auto fr = [](std::vector<void*>& v) { for (void* p : v) if (p) (void)hipFree(p); v.clear(); };
     fr(c->dM); fr(c->dJ); fr(c->ddq); fr(c->dbias); fr(c->dee); fr(c->dwrench); fr(c->dtgt); fr(c->dtvel);
-    for (int k = 0; k < 2; ++k) {
-        if (c->du2[k]) (void)hipFree(c->du2[k]);
-        if (c->dflags2[k]) (void)hipFree(c->dflags2[k]);
-        if (c->dside2[k]) (void)hipFree(c->dside2[k]);
-        if (c->dwl2[k]) (void)hipFree(c->dwl2[k]);
-        if (c->dwc2[k]) (void)hipFree(c->dwc2[k]);
+    for (int k = 0; k < irlosc_ctx::NSETS_MAX; ++k) {
+        if (c->du_set[k]) (void)hipFree(c->du_set[k]);
+        if (c->dflags_set[k]) (void)hipFree(c->dflags_set[k]);
+        if (c->dside_set[k]) (void)hipFree(c->dside_set[k]);
+        if (c->dwl_set[k]) (void)hipFree(c->dwl_set[k]);
+        if (c->dwc_set[k]) (void)hipFree(c->dwc_set[k]);
     }
+    for (int k = 0; k < irlosc_ctx::NTABLES; ++k)
+        if (c->dtable[k]) (void)hipFree(c->dtable[k]);
     if (c->dgains) (void)hipFree(c->dgains);
     if (c->dnullkv) (void)hipFree(c->dnullkv);
     if (c->ddbg) (void)hipFree(c->ddbg);
@@ -168,18 +176,30 @@ static int create_impl(irlosc_ctx* c) {
     c->has_tvel.assign(g.n_slots, 0);
     c->uploaded.assign(g.n_slots, 0);
     c->targeted.assign(g.n_slots, 0);
-    for (int k2 = 0; k2 < 2; ++k2) {
-        HIPCHK(nullptr, hipMalloc(&c->du2[k2], B * n * e));
-        HIPCHK(nullptr, hipMalloc((void**)&c->dflags2[k2], B * sizeof(uint32_t)));
-        HIPCHK(nullptr, hipMalloc((void**)&c->dwl2[k2], B * sizeof(int32_t)));
-        HIPCHK(nullptr, hipMalloc((void**)&c->dwc2[k2], 64 * sizeof(int32_t)));
-        if (c->kernel == IRLOSC_KERNEL_GROUP)
-            HIPCHK(nullptr, hipMalloc((void**)&c->dside2[k2], (B + 16 * 64) * 104 * sizeof(float)));
-        HIPCHK(nullptr, hipMemsetAsync(c->dflags2[k2], 0, B * sizeof(uint32_t), c->stream));
-        HIPCHK(nullptr, hipMemsetAsync(c->dwc2[k2], 0, 64 * sizeof(int32_t), c->stream));
+    if (c->kernel == IRLOSC_KERNEL_GROUP) {
+        c->train = irlosc_ctx::TRAIN_MAX;
+        if (const char* ev = getenv("IRLOSC_TRAIN")) c->train = std::max(1, std::min((int)irlosc_ctx::TRAIN_MAX, atoi(ev)));
+        if (getenv("IRLOSC_NO_PIPELINE")) c->train = 1;
+        c->nsets = 2 * c->train;
     }
-    c->du = c->du2[0];
-    c->dflags = c->dflags2[0];
+    for (int k2 = 0; k2 < c->nsets; ++k2) {
+        HIPCHK(nullptr, hipMalloc(&c->du_set[k2], B * n * e));
+        HIPCHK(nullptr, hipMalloc((void**)&c->dflags_set[k2], B * sizeof(uint32_t)));
+        HIPCHK(nullptr, hipMemsetAsync(c->dflags_set[k2], 0, B * sizeof(uint32_t), c->stream));
+        if (c->kernel == IRLOSC_KERNEL_GROUP) {
+            HIPCHK(nullptr, hipMalloc((void**)&c->dwl_set[k2], B * sizeof(int32_t)));
+            HIPCHK(nullptr, hipMalloc((void**)&c->dwc_set[k2], 64 * sizeof(int32_t)));
+            HIPCHK(nullptr, hipMalloc((void**)&c->dside_set[k2], (B + 16 * 64) * 104 * sizeof(float)));
+            HIPCHK(nullptr, hipMemsetAsync(c->dwc_set[k2], 0, 64 * sizeof(int32_t), c->stream));
+        }
+    }
+#ifndef IRLOSC_NO_GROUP_KERNEL
+    if (c->kernel == IRLOSC_KERNEL_GROUP)
+        for (int t = 0; t < irlosc_ctx::NTABLES; ++t)
+            HIPCHK(nullptr, hipMalloc(&c->dtable[t], irlosc_ctx::TRAIN_MAX * sizeof(TrainStep)));
+#endif
+    c->du = c->du_set[0];
+    c->dflags = c->dflags_set[0];
     HIPCHK(nullptr, hipMalloc(&c->dgains, B * nd * IRLOSC_GAIN_WORDS * e));
     HIPCHK(nullptr, hipMalloc(&c->dnullkv, B * e));
     if (c->kernel == IRLOSC_KERNEL_GROUP && getenv("IRLOSC_PHASE_TIMING"))
@@ -339,23 +359,88 @@ static void fill_params(const irlosc_ctx* c, KParams<T>& p, int B, const void* M
 }
 
 #ifndef IRLOSC_NO_GROUP_KERNEL
-static GroupScratch scratch_for(const irlosc_ctx* c, int set) {
-    GroupScratch gs{};
-    gs.worklist2 = c->dwl2[set];
-    gs.counts = c->dwc2[set];
-    gs.side = c->dside2[set];
-    gs.side_cap = c->cfg.max_batch + 16 * 64;
-    return gs;
-}
-
-// Run the stage 2 that a pipelined irlosc_step_resident left outstanding (no-op otherwise).
-static int flush_pending(irlosc_ctx* c, hipStream_t st) {
-    if (!c->pending) return IRLOSC_OK;
-    c->pending = false;
-    const GroupScratch gs = scratch_for(c, c->pending_set);
-    int rc = launch_group_stage2<float>(c->pending_p, make_s2(c->pending_p, c->pending_nfast, gs), st);
-    if (rc) return fail(c, IRLOSC_ERR_HIP, "stage-2 launch failed: %s", hipGetErrorString((hipError_t)rc));
+// One fused launch for a train of `n` steps (ps[i] = parameters with the outputs of set sets[i]); the stage 2 of
+// the steps in c->pending rides in front of them.  n == 0: riders only (a flush).  With keep_pending the new steps'
+// stage 2 is left for the next train; otherwise it is flushed right away.
+static int group_train(irlosc_ctx* c, const KParams<float>* ps, const int* sets, int n, hipStream_t st, bool keep_pending) {
+    const int side_cap = c->cfg.max_batch + 16 * 64;
+    const int entries = std::max(n, (int)c->pending.size());
+    if (entries == 0) return IRLOSC_OK;
+    if (entries > irlosc_ctx::TRAIN_MAX) return fail(c, IRLOSC_ERR_STATE, "train of %d entries", entries);
+    std::vector<TrainStep> tab(entries);
+    std::vector<irlosc_ctx::PendingStep> fresh;
+    int acc = 0;
+    bool riders = false;
+    for (int i = 0; i < entries; ++i) {
+        TrainStep& e = tab[i];
+        memset(&e, 0, sizeof e);
+        int tiles = 0;
+        if (i < n) {
+            e.p = ps[i];
+            e.side = c->dside_set[sets[i]];
+            e.giveup_count = c->dwc_set[sets[i]];
+            tiles = ps[i].B / GROUP_TILE;
+            if (tiles > 0) fresh.push_back({ps[i], sets[i], tiles * GROUP_TILE});
+        }
+        e.side_cap = side_cap;
+        if (i < (int)c->pending.size()) {
+            const irlosc_ctx::PendingStep& q = c->pending[i];
+            for (int j = 0; j < n; ++j)
+                if (sets[j] == q.set) return fail(c, IRLOSC_ERR_STATE, "output set %d reused before its stage 2 ran", q.set);
+            e.prev.J = q.p.J; e.prev.u = q.p.u; e.prev.flags = q.p.flags; e.prev.nfast = q.nfast;   // field by field: the
+            e.prev.side = c->dside_set[q.set]; e.prev.side_cap = side_cap;                         // padding stays zero, so
+            e.prev.worklist2 = c->dwl_set[q.set]; e.prev.workcount2 = c->dwc_set[q.set];           // equal tables compare equal
+            e.prev_p = q.p;
+            e.prev_p.index = nullptr;
+            e.n2 = (q.nfast + S2_SPAN - 1) / S2_SPAN;
+            riders = true;
+        }
+        e.block0 = acc;
+        acc += e.n2 + tiles;
+    }
+    // Device copy of the table.  A resident loop keeps producing the same few tables, so the last NTABLES ones are
+    // kept and reused by content; a miss overwrites the oldest (stream order keeps that safe on one stream).
+    TrainStep* dt = nullptr;
+    const size_t tbytes = entries * sizeof(TrainStep);
+    for (int t = 0; t < irlosc_ctx::NTABLES && !dt; ++t)
+        if (c->htable[t].size() == tbytes && memcmp(c->htable[t].data(), tab.data(), tbytes) == 0) dt = (TrainStep*)c->dtable[t];
+    if (!dt || st != c->stream) {
+        if (getenv("IRLOSC_DEBUG_TABLES")) fprintf(stderr, "[irlosc] train table upload (%d entries)\n", entries);
+        const int t = c->table_next;
+        c->table_next = (c->table_next + 1) % irlosc_ctx::NTABLES;
+        dt = (TrainStep*)c->dtable[t];
+        c->htable[t].assign((const unsigned char*)tab.data(), (const unsigned char*)tab.data() + tbytes);
+        HIPCHK(c, hipMemcpyAsync(dt, c->htable[t].data(), tbytes, hipMemcpyHostToDevice, st));
+    }
+    if (c->tev_begin) HIPCHK(c, hipEventRecord(c->tev_begin, st));
+    int rc = launch_group_train(dt, entries, acc, c->k, c->cfg.ndev, st);
+    if (rc) return fail(c, IRLOSC_ERR_HIP, "group kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (c->tev_end) HIPCHK(c, hipEventRecord(c->tev_end, st));
+    if (riders && !getenv("IRLOSC_SKIP_LISTS")) {     // give-up lists of the steps whose stage 2 just ran (normally empty: 16 idle blocks per step)
+        rc = launch_giveup_lists(dt, entries, c->cfg.n, c->k, c->cfg.ndev, st);
+        if (rc) return fail(c, IRLOSC_ERR_HIP, "give-up kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    }
+    for (int i = 0; i < n; ++i) {   // ragged tail (< 16 instances): generic kernel on the last instances
+        const int nfast = (ps[i].B / GROUP_TILE) * GROUP_TILE, rem = ps[i].B - nfast;
+        if (rem > 0) {
+            KParams<float> pt = ps[i];
+            pt.index = nullptr;
+            pt.b0 = nfast;
+            hipLaunchKernelGGL(osc_generic_kernel<float>, dim3(rem), dim3(64), generic_smem_bytes<float>(pt.n, pt.k, pt.ndev), st, pt);
+            HIPCHK(c, hipGetLastError());
+        }
+    }
+    c->pending = fresh;
+    if (!keep_pending && !c->pending.empty()) return group_train(c, nullptr, nullptr, 0, st, false);
     return IRLOSC_OK;
+}
+static int flush_pending(irlosc_ctx* c, hipStream_t st) {
+    if (c->pending.empty()) return IRLOSC_OK;
+    hipEvent_t b = c->tev_begin, e = c->tev_end;      // a flush is never the timed launch
+    c->tev_begin = c->tev_end = nullptr;
+    int rc = group_train(c, nullptr, nullptr, 0, st, false);
+    c->tev_begin = b; c->tev_end = e;
+    return rc;
 }
 #else
 static int flush_pending(irlosc_ctx*, hipStream_t) { return IRLOSC_OK; }
@@ -370,33 +455,10 @@ static int launch_t(irlosc_ctx* c, int B, const void* M, const void* J, const vo
 #ifndef IRLOSC_NO_GROUP_KERNEL
     if (c->kernel == IRLOSC_KERNEL_GROUP) {
         if constexpr (sizeof(T) == 4) {
-            // which output set does `u` belong to?  (caller-owned buffers of irlosc_step_device use set `cur`)
-            const int set = (u == c->du2[1]) ? 1 : (u == c->du2[0] ? 0 : c->cur);
-            GroupScratch gs = scratch_for(c, set);
-            gs.stage1_only = c->stage1_only;
-            gs.ev_begin = c->tev_begin;
-            gs.ev_end = c->tev_end;
-            gs.defer_stage2 = c->defer_next && !c->stage1_only;
-            if (c->pending && c->pending_set != set && !c->stage1_only) {      // previous step's stage 2 rides along
-                const GroupScratch gp = scratch_for(c, c->pending_set);
-                gs.have_prev = true;
-                gs.prev = make_s2(c->pending_p, c->pending_nfast, gp);
-                gs.prev_p = c->pending_p;
-                c->pending = false;
-            } else if (c->pending && !c->stage1_only) {
-                int rc0 = flush_pending(c, st);                              // same set: must finish first
-                if (rc0) return rc0;
-            }
-            int rc = launch_group<float>(p, gs, st);
-            if (rc) return fail(c, IRLOSC_ERR_HIP, "group kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-            if (gs.defer_stage2) {
-                const int tile1 = 16;
-                c->pending = true;
-                c->pending_set = set;
-                c->pending_nfast = (B / tile1) * tile1;
-                c->pending_p = p;
-            }
-            return IRLOSC_OK;
+            int rc = flush_pending(c, st);
+            if (rc) return rc;
+            const int set = c->cur;           // hand-off buffers of the current set (u / flags may be the caller's)
+            return group_train(c, &p, &set, 1, st, false);
         } else {
             return fail(c, IRLOSC_ERR_ARG, "no fp64 group kernel");
         }
@@ -478,30 +540,70 @@ extern "C" int irlosc_step(irlosc_ctx* c, int32_t slot, int32_t B, void* u_host,
     return IRLOSC_OK;
 }
 
+// Parameters of the step on resident slot `slot` with the outputs of set `set`.
+static void slot_params(const irlosc_ctx* c, KParams<float>& p, int slot, int B, int set) {
+    fill_params<float>(c, p, B, c->dM[slot], c->dJ[slot], c->ddq[slot], c->dbias[slot], c->dee[slot], c->dtgt[slot],
+                       c->has_tvel[slot] ? c->dtvel[slot] : nullptr, c->has_wrench[slot] ? c->dwrench[slot] : nullptr,
+                       c->du_set[set], c->dflags_set[set]);
+}
+
+#ifndef IRLOSC_NO_GROUP_KERNEL
+// `iters` steps on the group path, chained `train` per launch; events (if any) go around launch number `timed`.
+static int resident_trains(irlosc_ctx* c, int first_slot, int B, int iters, const std::vector<hipEvent_t>* evs, int skip) {
+    int done = 0, launch_no = 0;
+    while (done < iters) {
+        const int n = std::min(c->train, iters - done);
+        KParams<float> ps[irlosc_ctx::TRAIN_MAX];
+        int sets[irlosc_ctx::TRAIN_MAX];
+        for (int i = 0; i < n; ++i) {
+            const int slot = (first_slot + done + i) % c->cfg.n_slots;
+            if (!c->uploaded[slot] || !c->targeted[slot])
+                return fail(c, IRLOSC_ERR_STATE, "slot %d: irlosc_upload and irlosc_set_targets must precede a step", slot);
+            sets[i] = c->set_half * c->train + i;
+            slot_params(c, ps[i], slot, B, sets[i]);
+        }
+        if (evs && launch_no >= skip && 2 * (launch_no - skip) + 1 < (int)evs->size()) {
+            c->tev_begin = (*evs)[2 * (launch_no - skip)];
+            c->tev_end = (*evs)[2 * (launch_no - skip) + 1];
+        }
+        int rc = group_train(c, ps, sets, n, c->stream, true);
+        c->tev_begin = c->tev_end = nullptr;
+        if (rc) return rc;
+        c->cur = sets[n - 1];
+        c->set_half ^= 1;
+        done += n;
+        ++launch_no;
+    }
+    c->du = c->du_set[c->cur];
+    c->dflags = c->dflags_set[c->cur];
+    return flush_pending(c, c->stream);
+}
+#endif
+
 extern "C" int irlosc_step_resident(irlosc_ctx* c, int32_t first_slot, int32_t B, int32_t iters, float* ms_total,
                                     float* ms_kernel_avg) {
     if (!c) return IRLOSC_ERR_ARG;
     int rc = check_slot(c, first_slot, B);
     if (rc) return rc;
     if (iters < 1) return fail(c, IRLOSC_ERR_ARG, "iters must be >= 1");
+    if (c->gains_nb == 0) return fail(c, IRLOSC_ERR_STATE, "irlosc_set_gains has not been called");
     HIPCHK(c, hipSetDevice(c->cfg.hip_device));
-    // Group path: consecutive steps are pipelined - step i writes output set i % 2 and its stage 2 rides in the
-    // stage-1 launch of step i + 1 (the last one is flushed below), all on one stream.
-    const bool pipe = c->kernel == IRLOSC_KERNEL_GROUP && !getenv("IRLOSC_NO_PIPELINE");
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    for (int i = 0; i < iters; ++i) {
-        if (pipe) {
-            c->cur ^= 1;
-            c->du = c->du2[c->cur];
-            c->dflags = c->dflags2[c->cur];
-        }
-        c->defer_next = pipe;
-        rc = launch_slot(c, (first_slot + i) % c->cfg.n_slots, B);
-        c->defer_next = false;
+#ifndef IRLOSC_NO_GROUP_KERNEL
+    if (c->kernel == IRLOSC_KERNEL_GROUP && B > 0) {
+        // Group path: up to `train` consecutive steps are chained in one launch (different resident slots, different
+        // output sets), and their stage 2 rides in the next launch; the last train is flushed before returning.
+        rc = flush_pending(c, c->stream);
+        if (!rc) rc = resident_trains(c, first_slot, B, iters, nullptr, 0);
         if (rc) return rc;
+    } else
+#endif
+    {
+        for (int i = 0; i < iters; ++i) {
+            rc = launch_slot(c, (first_slot + i) % c->cfg.n_slots, B);
+            if (rc) return rc;
+        }
     }
-    rc = flush_pending(c, c->stream);
-    if (rc) return rc;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));
     float ms = 0.f;
@@ -511,50 +613,47 @@ extern "C" int irlosc_step_resident(irlosc_ctx* c, int32_t first_slot, int32_t B
     return IRLOSC_OK;
 }
 
+extern "C" int irlosc_steps_per_launch(const irlosc_ctx* c) {
+    if (!c) return IRLOSC_ERR_ARG;
+    return c->kernel == IRLOSC_KERNEL_GROUP ? c->train : 1;
+}
+
 extern "C" int irlosc_time_dominant_kernel(irlosc_ctx* c, int32_t slot, int32_t B, int32_t iters, float* ms_avg) {
     if (!c) return IRLOSC_ERR_ARG;
     int rc = check_slot(c, slot, B);
     if (rc) return rc;
     if (iters < 1 || iters > 256 || !ms_avg) return fail(c, IRLOSC_ERR_ARG, "iters must be in [1,256] and ms_avg non-NULL");
     HIPCHK(c, hipSetDevice(c->cfg.hip_device));
-    if (c->kernel != IRLOSC_KERNEL_GROUP) {          // generic path: a step IS the dominant kernel
+    if (c->kernel != IRLOSC_KERNEL_GROUP || B == 0) {          // generic path: a step IS the dominant kernel
         float tot = 0.f;
         rc = irlosc_step_resident(c, slot, B, iters, &tot, ms_avg);
         return rc;
     }
-    // Group path: the same pipelined launches as irlosc_step_resident, with a HIP event pair around each
-    // dominant launch (stage 1 of step i fused with the riding stage 2 of step i-1) - this is the kernel a
-    // rocprofv3 kernel trace of the timed region shows, so the two averages are comparable.
-    while ((int)c->tev_pool.size() < 2 * iters) {
+#ifndef IRLOSC_NO_GROUP_KERNEL
+    // Group path: the same chained launches as irlosc_step_resident, with a HIP event pair around each dominant
+    // launch (a train of irlosc_steps_per_launch() steps' stage 1, fused with the riding stage 2 of the previous
+    // train) - this is the kernel a rocprofv3 kernel trace of the timed region shows, so the two averages are
+    // comparable.  The first launch is not timed (nothing rides in it yet).
+    if (c->gains_nb == 0) return fail(c, IRLOSC_ERR_STATE, "irlosc_set_gains has not been called");
+    const int launches = std::max(1, iters / c->train);
+    while ((int)c->tev_pool.size() < 2 * launches) {
         hipEvent_t ev;
         HIPCHK(c, hipEventCreate(&ev));
         c->tev_pool.push_back(ev);
     }
-    const bool pipe = !getenv("IRLOSC_NO_PIPELINE");
-    for (int i = -1; i < iters; ++i) {               // i = -1: untimed first launch (nothing rides in it yet)
-        if (pipe) {
-            c->cur ^= 1;
-            c->du = c->du2[c->cur];
-            c->dflags = c->dflags2[c->cur];
-        }
-        c->defer_next = pipe;
-        c->tev_begin = i >= 0 ? c->tev_pool[2 * i] : nullptr;
-        c->tev_end = i >= 0 ? c->tev_pool[2 * i + 1] : nullptr;
-        rc = launch_slot(c, (slot + i + 1) % c->cfg.n_slots, B);
-        c->defer_next = false;
-        c->tev_begin = c->tev_end = nullptr;
-        if (rc) return rc;
-    }
+    std::vector<hipEvent_t> evs(c->tev_pool.begin(), c->tev_pool.begin() + 2 * launches);
     rc = flush_pending(c, c->stream);
+    if (!rc) rc = resident_trains(c, slot, B, (launches + 1) * c->train, &evs, 1);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     double tot = 0.0;
-    for (int i = 0; i < iters; ++i) {
+    for (int i = 0; i < launches; ++i) {
         float ms = 0.f;
-        HIPCHK(c, hipEventElapsedTime(&ms, c->tev_pool[2 * i], c->tev_pool[2 * i + 1]));
+        HIPCHK(c, hipEventElapsedTime(&ms, evs[2 * i], evs[2 * i + 1]));
         tot += ms;
     }
-    *ms_avg = (float)(tot / iters);
+    *ms_avg = (float)(tot / launches);
+#endif
     return IRLOSC_OK;
 }
 

@@ -10,6 +10,21 @@
 
 namespace irlosc {
 
+// Copy of a plain struct that may live in the constant address space (train tables are read through it so that
+// the loads are scalar): C++ will not bind an implicit copy constructor across address spaces.
+template <typename T>
+__device__ __forceinline__ T pod_copy(const T& src) { return src; }
+template <typename T>
+__device__ __forceinline__ T pod_copy(const __attribute__((address_space(4))) T& src) {
+    static_assert(sizeof(T) % 4 == 0, "word-wise copy");
+    T dst;
+    const __attribute__((address_space(4))) uint32_t* w = (const __attribute__((address_space(4))) uint32_t*)&src;
+    uint32_t* d = reinterpret_cast<uint32_t*>(&dst);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) d[i] = w[i];
+    return dst;
+}
+
 // Per-target-device metadata, broadcast to every instance (lives in kernarg/SGPR space).
 struct DevMeta {
     int32_t row0;         // first row of this device's block in the stacked J / task vector

@@ -53,17 +53,14 @@ __device__ __forceinline__ bool wave_cholesky(T* A, int m, int ld, int lane, T* 
     return ok;
 }
 
-template <typename T>
-__global__ __launch_bounds__(64) void osc_generic_kernel(const KParams<T> p) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    T* smem = reinterpret_cast<T*>(smem_raw);
+// One instance, one wavefront (a 64-thread block): the whole of osc.py:41-200 for instance b.  `smem` =
+// generic_smem_bytes() bytes of LDS.  P is KParams<T> or a reference to one in the constant address space.
+template <typename T, typename P>
+__device__ __forceinline__ void generic_instance(const P& p, const int b, T* smem) {
     const int lane = threadIdx.x;
     const int n = p.n, k = p.k, ndev = p.ndev;
     const int ldn = n | 1, ldk = k | 1;
-    // identity mode: block i handles instance b0 + i; worklist mode: grid-stride over index[0..*index_count)
-    const int wl_count = p.index ? *p.index_count : 0;
-    for (int it = blockIdx.x; p.index ? (it < wl_count) : (it == (int)blockIdx.x); it += gridDim.x) {
-    const int b = p.index ? p.index[it] : p.b0 + it;
+    {
 
     T* Ms = smem;                 // n x ldn   (M, then its Cholesky factor L in the lower triangle)
     T* Js = Ms + n * ldn;         // k x ldn
@@ -106,7 +103,7 @@ __global__ __launch_bounds__(64) void osc_generic_kernel(const KParams<T> p) {
 
     // ---- per-device task-space signal (osc.py:156-181): lane d handles device d -----------------
     if (lane < ndev) {
-        const DevMeta dm = p.dev[lane];
+        const DevMeta dm = pod_copy<DevMeta>(p.dev[lane]);
         const T* g = gbase + lane * IRLOSC_GAIN_WORDS;
         const T* ee = p.ee + ((size_t)b * ndev + lane) * 7;
         const T* tg = p.tgt + ((size_t)b * ndev + lane) * 7;
@@ -309,7 +306,17 @@ __global__ __launch_bounds__(64) void osc_generic_kernel(const KParams<T> p) {
     if (__ballot(bad)) flags |= IRLOSC_FLAG_NONFINITE;
     if (lane == 0) p.flags[b] = flags;
     __syncthreads();
-    }  // instance loop
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void osc_generic_kernel(const KParams<T> p) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    // identity mode: block i handles instance b0 + i; worklist mode: grid-stride over index[0..*index_count)
+    const int wl_count = p.index ? *p.index_count : 0;
+    for (int it = blockIdx.x; p.index ? (it < wl_count) : (it == (int)blockIdx.x); it += gridDim.x)
+        generic_instance<T>(p, p.index ? p.index[it] : p.b0 + it, smem);
 }
 
 template <typename T>

@@ -458,12 +458,6 @@ __device__ __forceinline__ void stage2_body(const S2Args a, int blk, int32_t* ld
     }
 }
 
-template <int K>
-__global__ __launch_bounds__(64) void osc_group_stage2_f32(const S2Args a) {
-    __shared__ int32_t lds[S2Lds<K>::WORDS];
-    stage2_body<K>(a, blockIdx.x, lds);
-}
-
 }  // namespace irlosc
 #include "osc_group_stage1.hpp"
 namespace irlosc {
@@ -472,105 +466,35 @@ inline bool group_kernel_supports(int dtype, int n, int k, int ndev) {
     return dtype == IRLOSC_F32 && n == 25 && ((k == 13 && ndev == 3) || (k == 12 && ndev == 2));
 }
 
-// Device scratch owned by the context for the two-stage group path (one set per output buffer set).
-struct GroupScratch {
-    int32_t* worklist2;   // [max_batch] instances stage 2 hands to the generic kernel
-    int32_t* counts;      // [1] length of worklist2
-    float* side;          // [side_cap][K(K+1)/2 + K]: A and w of flagged instances, one record per instance
-    int side_cap;
-    bool stage1_only;         // roofline timing: launch the dominant kernel alone
-    bool defer_stage2;        // pipelined steps: leave this step's stage 2 to the next launch (or to a flush)
-    bool have_prev;           // a previous step's stage 2 is pending and rides in this launch
-    S2Args prev;              // ... its arguments
-    KParams<float> prev_p;    // ... and its full parameters (for the give-up list -> generic kernel)
-    hipEvent_t ev_begin, ev_end;   // optional: recorded right before / after the dominant (stage-1 / fused) launch
-};
+constexpr int GROUP_TILE = 16;        // instances per stage-1 wave
 
-inline S2Args make_s2(const KParams<float>& p, int nfast, const GroupScratch& gs) {
-    return S2Args{p.J, p.u, p.flags, nfast, gs.side, gs.side_cap, gs.worklist2, gs.counts};
+// Give-up lists of a train (normally all empty): grid (16, nsteps), one wave per instance, grid-strided per list.
+__global__ __launch_bounds__(64) void osc_generic_lists_kernel(const TrainStep* __restrict__ table) {
+    extern __shared__ __align__(16) unsigned char smem_raw_l[];
+    float* smem = reinterpret_cast<float*>(smem_raw_l);
+    typedef const __attribute__((address_space(4))) TrainStep* ctab_t;
+    const ctab_t ct = (ctab_t)table;
+    const __attribute__((address_space(4))) S2Args& a = ct[blockIdx.y].prev;
+    if (a.nfast <= 0) return;
+    const int count = *a.workcount2;
+    for (int it = blockIdx.x; it < count; it += gridDim.x) generic_instance<float>(ct[blockIdx.y].prev_p, a.worklist2[it], smem);
 }
 
-template <typename T>
-int launch_group(const KParams<T>& p, const GroupScratch& gs, hipStream_t st);
-template <typename T>
-int launch_group_stage2(const KParams<T>& p, const S2Args& a, hipStream_t st);
-
-template <>
-inline int launch_group<double>(const KParams<double>&, const GroupScratch&, hipStream_t) {
-    return (int)hipErrorNotSupported;
-}
-template <>
-inline int launch_group_stage2<double>(const KParams<double>&, const S2Args&, hipStream_t) {
-    return (int)hipErrorNotSupported;
-}
-
-// Standalone stage 2 (+ the generic kernel over its give-up list) for the step described by (p, a).
-template <>
-inline int launch_group_stage2<float>(const KParams<float>& p, const S2Args& a, hipStream_t st) {
-    if (a.nfast <= 0) return 0;
-    const int g2 = (a.nfast + S2_SPAN - 1) / S2_SPAN;
-    if (p.k == 13) hipLaunchKernelGGL((osc_group_stage2_f32<13>), dim3(g2), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((osc_group_stage2_f32<12>), dim3(g2), dim3(64), 0, st, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-    KParams<float> pw = p;                 // instances stage 2 gave up on (> 3 sub-threshold eigenvalues,
-    pw.index = a.worklist2;                // normally none): a handful of grid-strided generic blocks
-    pw.index_count = a.workcount2;
-    pw.b0 = 0;
-    hipLaunchKernelGGL(osc_generic_kernel<float>, dim3(16), dim3(64), generic_smem_bytes<float>(p.n, p.k, p.ndev), st, pw);
+// The fused train launch: table[0..nsteps) on the device, total_blocks = sum of (riders + tiles) over the steps.
+inline int launch_group_train(const TrainStep* dtable, int nsteps, int total_blocks, int k, int ndev, hipStream_t st) {
+    if (total_blocks <= 0) return 0;
+    const dim3 grid(total_blocks);
+    if (k == 13 && ndev == 3) hipLaunchKernelGGL((osc_group_kernel_f32<4, 13, 3, 2>), grid, dim3(64), 0, st, dtable, nsteps);
+    else if (k == 12 && ndev == 2) hipLaunchKernelGGL((osc_group_kernel_f32<4, 12, 2, 2>), grid, dim3(64), 0, st, dtable, nsteps);
+    else return (int)hipErrorNotSupported;
     return (int)hipGetLastError();
 }
 
-template <>
-inline int launch_group<float>(const KParams<float>& p, const GroupScratch& gs, hipStream_t st) {
-    constexpr int G = 4;
-    const int TILE1 = 64 / G;
-    const int tiles = p.B / TILE1;
-    const int nfast = tiles * TILE1;
-    const int rem = p.B - nfast;
-    int32_t* wc2 = gs.counts;              // length of worklist2; zeroed by the first stage-1 block
-    hipError_t e;
-    const bool ride = gs.have_prev && gs.prev.nfast > 0 && !gs.stage1_only;
-    const int n2 = ride ? (gs.prev.nfast + S2_SPAN - 1) / S2_SPAN : 0;
-    if (tiles > 0) {
-        const dim3 grid(tiles + n2);
-        if (gs.ev_begin && (e = hipEventRecord(gs.ev_begin, st)) != hipSuccess) return (int)e;
-#define IRLOSC_LAUNCH1(GG, KK, ND, NBB) \
-        hipLaunchKernelGGL((osc_group_kernel_f32<GG, KK, ND, NBB>), grid, dim3(64), 0, st, p, gs.side, gs.side_cap, wc2, gs.prev, n2)
-        if (p.k == 13 && p.ndev == 3) {
-            IRLOSC_LAUNCH1(4, 13, 3, 2);
-        } else if (p.k == 12 && p.ndev == 2) {
-            IRLOSC_LAUNCH1(4, 12, 2, 2);
-        } else return (int)hipErrorNotSupported;
-#undef IRLOSC_LAUNCH1
-        e = hipGetLastError();
-        if (e != hipSuccess) return (int)e;
-        if (gs.ev_end && (e = hipEventRecord(gs.ev_end, st)) != hipSuccess) return (int)e;
-    } else if (ride) {
-        int rc = launch_group_stage2<float>(gs.prev_p, gs.prev, st);
-        if (rc) return rc;
-    }
-    if (gs.stage1_only) return 0;
-    const size_t smem = generic_smem_bytes<float>(p.n, p.k, p.ndev);
-    if (ride && tiles > 0) {               // give-up list of the previous step (its stage 2 just ran in the fused launch)
-        KParams<float> pw = gs.prev_p;
-        pw.index = gs.prev.worklist2;
-        pw.index_count = gs.prev.workcount2;
-        pw.b0 = 0;
-        hipLaunchKernelGGL(osc_generic_kernel<float>, dim3(16), dim3(64), smem, st, pw);
-        e = hipGetLastError();
-        if (e != hipSuccess) return (int)e;
-    }
-    if (rem > 0) {   // ragged tail (< TILE instances): generic kernel on the last instances
-        KParams<float> pt = p;
-        pt.index = nullptr;
-        pt.b0 = nfast;
-        hipLaunchKernelGGL(osc_generic_kernel<float>, dim3(rem), dim3(64), smem, st, pt);
-        e = hipGetLastError();
-        if (e != hipSuccess) return (int)e;
-    }
-    if (!gs.defer_stage2 && tiles > 0) return launch_group_stage2<float>(p, make_s2(p, nfast, gs), st);
-    return 0;
+// The generic kernel over the give-up lists of the steps whose stage 2 rode in `dtable`'s train.
+inline int launch_giveup_lists(const TrainStep* dtable, int nsteps, int n, int k, int ndev, hipStream_t st) {
+    if (nsteps <= 0) return 0;
+    hipLaunchKernelGGL(osc_generic_lists_kernel, dim3(16, nsteps), dim3(64), generic_smem_bytes<float>(n, k, ndev), st, dtable);
+    return (int)hipGetLastError();
 }
 
 }  // namespace irlosc

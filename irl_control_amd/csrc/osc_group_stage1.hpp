@@ -158,10 +158,36 @@ template <int PIECES> __device__ __forceinline__ void dmalinear(const float* src
 
 }  // namespace grp
 
+// One launch = a TRAIN of steps: table[s] describes step s (its resident inputs, its output set, the step whose
+// stage 2 rides in front of its tiles, and the first block of its range).  Steps of a train are independent
+// (different input slots, different output sets) and their riders belong to the PREVIOUS train, so nothing in a
+// launch waits on anything else in it; a train of one step is the plain single-step launch.  Chaining steps in one
+// grid removes the ramp-up / drain / launch gap between them (~17 us per launch against ~35 us per wave round).
+// The table is written by the host before the launch and never by the kernel: it is read through the constant
+// address space, i.e. with scalar loads at the point of use, exactly like kernel arguments.
+struct TrainStep {
+    KParams<float> p;
+    S2Args prev;              // nfast == 0: nothing rides in this step
+    KParams<float> prev_p;    // full parameters of that previous step (its give-up list -> generic kernel)
+    float* side;              // [side_cap][NA + K] hand-off records of this step's output set
+    int32_t* giveup_count;    // length of this step's give-up list (zeroed here, filled by its stage 2 later)
+    int side_cap;
+    int n2;                   // rider blocks in front of the tiles
+    int block0;               // first block of this step's range
+    int pad;
+};
+
 template <int G, int K, int NDEV, int NB>
-__global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<float> p, float* __restrict__ side, int side_cap,
-                                                             int32_t* __restrict__ giveup_count,
-                                                             const S2Args prev, int n2) {
+__global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const TrainStep* __restrict__ table, const int nsteps) {
+    typedef const __attribute__((address_space(4))) TrainStep* ctab_t;
+    const ctab_t ct = (ctab_t)table;
+    int step = 0;
+    while (step + 1 < nsteps && (int)blockIdx.x >= ct[step + 1].block0) ++step;
+    const __attribute__((address_space(4))) KParams<float>& p = ct[step].p;
+    float* __restrict__ const side = ct[step].side;
+    int32_t* __restrict__ const giveup_count = ct[step].giveup_count;
+    const int n2 = ct[step].n2;
+    const int blk = (int)blockIdx.x - ct[step].block0;
     using namespace grp;
     using GE = Geo<G>;
     constexpr int TILE = GE::TILE, P = GE::P, NS = GE::NS, LS = GE::LS, CI = GE::CI;
@@ -197,13 +223,14 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     // of this step.  Stage 2 alone keeps one latency-bound wave per SIMD busy for ~28 us with the other slot
     // idle; inside this launch its waves share the SIMDs with stage-1 waves instead.
     static_assert(S2Lds<K>::WORDS <= NB * SLOT, "stage 2 borrows the ring as its LDS");
-    if ((int)blockIdx.x < n2) {
-        stage2_body<K>(prev, blockIdx.x, reinterpret_cast<int32_t*>(ring));
+    if (blk < n2) {
+        const S2Args prev = pod_copy<S2Args>(ct[step].prev);
+        stage2_body<K>(prev, blk, reinterpret_cast<int32_t*>(ring));
         return;
     }
     const int lane = threadIdx.x;
     const int g = lane % G, q = lane / G;
-    const int tile = (int)blockIdx.x - n2;
+    const int tile = blk - n2;
     const int b = tile * TILE + q;
     const size_t t0 = (size_t)tile * TILE;
     const bool has_tv = p.tvel != nullptr;
@@ -219,7 +246,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     // a select on the loaded values would make the wave wait for them right here.)
     auto gains_ptr = [&]() { return p.gains + (p.gains_per_instance ? (size_t)b * NDEV * IRLOSC_GAIN_WORDS : 0); };
     const int gd = g < NDEV ? g : 0;
-    const DevMeta dm1 = p.dev[gd];
+    const DevMeta dm1 = pod_copy<DevMeta>(p.dev[gd]);
     float gl[IRLOSC_GAIN_WORDS];
     {
         const float* gg = gains_ptr() + gd * IRLOSC_GAIN_WORDS;
@@ -534,7 +561,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const KParams<floa
     float kvn = 0.f;
     if (p.cfgflags & IRLOSC_NULLSPACE) kvn = p.null_kv[p.gains_per_instance ? b : 0];
     if (g < NDEV) {
-        const DevMeta dm = p.dev[g];
+        const DevMeta dm = pod_copy<DevMeta>(p.dev[g]);
         const float* gg = gains_ptr() + g * IRLOSC_GAIN_WORDS;
         kv_own = gg[1];
         float tv[6];

@@ -236,6 +236,53 @@ def test_group_vs_generic_fp32_kernels_agree():
     assert (((fg ^ fe) & _lib.FLAG_TRUNCATED) != 0).mean() < 0.02
 
 
+@pytest.mark.parametrize("iters", [1, 2, 7, 8, 9, 17, 24])
+def test_step_resident_trains_equal_single_steps(iters):
+    """irlosc_step_resident chains up to 8 steps per launch and lets their eigen-path stage ride in the next
+    launch; whatever the train split, the outputs left behind are bit-for-bit those of a plain single step on the
+    last slot visited (n_slots = 3 distinct batches, truncation-heavy data so that stage 2 has work in every step)."""
+    nslots, B = 3, 1024 + 16
+    lay = synth.make_layout("k13")
+    osc = BatchedOSC(lay, B, dtype=np.float32, n_slots=nslots)
+    batches = []
+    for sl in range(nslots):
+        _, gains, g = synth.make_batch("k13", B, seed=100 + sl, dtype=np.float32)
+        osc.upload(g["M"], g["J"], g["dq"], g["bias"], g["ee_pose"], g.get("wrench"), slot=sl)
+        osc.set_targets(g["tgt_pose"], g.get("tgt_vel"), slot=sl)
+        batches.append(g)
+        if sl == 0:
+            osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+    assert 1 <= osc.steps_per_launch <= 8
+    first = 1
+    osc.step_resident(iters, first_slot=first)
+    u_train, f_train = osc.download(B)
+    last = (first + iters - 1) % nslots
+    osc.step(slot=last)
+    u_one, f_one = osc.download(B)
+    assert (f_one & _lib.FLAG_EIGEN_PATH).mean() > 0.03          # stage 2 really ran
+    assert np.array_equal(u_train, u_one) and np.array_equal(f_train, f_one)
+    # and a second resident call right after (pending state fully flushed, sets reused) still agrees
+    osc.step_resident(iters, first_slot=last)
+    u2, f2 = osc.download(B)
+    last2 = (last + iters - 1) % nslots
+    osc.step(slot=last2)
+    u3, f3 = osc.download(B)
+    assert np.array_equal(u2, u3) and np.array_equal(f2, f3)
+    osc.close()
+
+
+def test_time_dominant_kernel_leaves_complete_outputs():
+    lay, gains, g = synth.make_batch("k13", 4096, seed=9, dtype=np.float32)
+    osc = BatchedOSC(lay, 4096, dtype=np.float32)
+    osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+    ref = osc.generate_batched(g["M"], g["J"], g["dq"], g["bias"], g["ee_pose"], g["tgt_pose"], g.get("tgt_vel"), g.get("wrench"))
+    ms = osc.time_dominant_kernel(16)
+    assert ms > 0
+    u, _ = osc.download(4096)
+    assert np.array_equal(u, ref)
+    osc.close()
+
+
 def test_step_device_raw_pointers():
     """irlosc_step_device: caller-owned device buffers (here: torch tensors), no copies by the library."""
     torch = pytest.importorskip("torch")
