@@ -21,6 +21,12 @@ def main(path):
         a["n"] += 1; a["tot"] += dur; a["mn"] = min(a["mn"], dur); a["mx"] = max(a["mx"], dur)
     tot_all = sum(a["tot"] for a in agg.values()) or 1.0
     print(f"# rocprofv3 --kernel-trace summary of {path}")
+    if "grid_x" in ix:      # the fused train kernel is launched in several shapes (full train, first train, flush):
+        by = {}             # break the dominant kernel down by grid size so like is compared with like
+        for r in rows:
+            key = (r[ix[name_c]], r[ix["grid_x"]])
+            a = by.setdefault(key, [0, 0.0])
+            a[0] += 1; a[1] += (r[ix["end"]] - r[ix["start"]]) / 1e3
     print(f"{'kernel':70s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}  extra")
     for nm, a in sorted(agg.items(), key=lambda kv: -kv[1]["tot"]):
         r = a["row"]
@@ -30,6 +36,12 @@ def main(path):
                          if c in ix)
         print(f"{nm[:70]:70s} {a['n']:6d} {a['tot'] / 1e3:10.3f} {a['tot'] / a['n']:10.2f} {a['mn']:10.2f} "
               f"{a['mx']:10.2f} {100 * a['tot'] / tot_all:6.2f}  {extra}")
+    if "grid_x" in ix:
+        dom = max(agg.items(), key=lambda kv: kv[1]["tot"])[0]
+        print(f"# dominant kernel by launch shape (grid_x = 64 x blocks): full trains / first train of a call / flushes")
+        for (nm, gx), (n, tot) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+            if nm == dom:
+                print(f"#   grid_x={gx:9d} calls={n:5d} avg_us={tot / n:10.2f}")
 
 
 if __name__ == "__main__":
