@@ -12,11 +12,11 @@
 // pinv cut of osc.py:55) and the host-side launch logic.  STAGE 1 (all instances; streaming,
 // Cholesky of M, Y, A, certificate, solve, u) is osc_group_stage1.hpp.
 //
-// Launch structure (launch_group): one fused launch = [n2 blocks running stage 2 of the PREVIOUS
-// step's flagged instances] + [stage-1 tiles of this step]; flagged instances hand A and w over
-// through `side` (indexed by instance, no worklist); each stage-2 block compacts its own 64-instance
-// span in LDS.  Instances stage 2 cannot finish (more than 3 eigenvalues under the cut) go to a
-// small give-up list handled by the generic kernel (Jacobi).  DESIGN.md section 4.2 has the numbers.
+// Launch structure (launch_group_train): one fused launch = a TRAIN of up to 8 independent steps; in front of each
+// step's stage-1 tiles ride the stage-2 blocks of the corresponding step of the PREVIOUS train.  Flagged instances
+// hand A and w over in one contiguous record per instance (no worklist); each stage-2 block compacts its own
+// 384-instance span in LDS.  Instances stage 2 cannot finish (more than 3 eigenvalues under the cut) go to a small
+// give-up list handled by the generic kernel (Jacobi).  DESIGN.md section 4.2 has the numbers.
 #pragma once
 #include "osc_common.hpp"
 #include "osc_generic.hpp"
