@@ -283,6 +283,19 @@ def test_time_dominant_kernel_leaves_complete_outputs():
     osc.close()
 
 
+def test_headless_gain_test_loop_runs():
+    """examples/gain_test_headless.py: the reference's tick loop (examples/gain_test.py:98-175) on the build's
+    classes with an injected simulator; OSC.generate goes through the C ABI every tick."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "gain_test_headless.py")
+    spec = importlib.util.spec_from_file_location("gain_test_headless", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.run(ticks=80, demo="figure8", verbose=False)
+    assert out["switches"] >= 2 and np.all(np.isfinite(out["ctrl"])) and np.abs(out["ctrl"]).max() > 0
+
+
 def test_step_device_raw_pointers():
     """irlosc_step_device: caller-owned device buffers (here: torch tensors), no copies by the library."""
     torch = pytest.importorskip("torch")
