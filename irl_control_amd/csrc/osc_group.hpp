@@ -80,87 +80,12 @@ __device__ __forceinline__ void wait_lgkm0() {
     asm volatile("" ::: "memory");
 }
 
-// ---- LDS-DMA issue (global_load_lds_*), hand-counted -----------------------------------------------
-// Issued through inline asm on purpose: hipcc treats the builtin form as a store to LDS that may
-// alias every later ds_read and drains it with s_waitcnt vmcnt(0), which would serialise the ring.
-// In asm the compiler neither counts nor waits for these loads; the kernel's own wait_vm<N>() calls
-// are the only synchronisation (guide §5.7: M0 written in the same statement, s_nop 0 before use).
-// Address form: SGPR-pair base (wave-uniform) + 32-bit VGPR byte offset.  LDS destination:
-// M0 + lane * size, M0 advanced by `step` bytes per instruction.
-#define IRLOSC_GLDS7(OP, STEP)                                                                         \
-    asm volatile("s_mov_b32 %[keep], m0\n\t"                                                            \
-                 "s_mov_b32 m0, %[lds]\n\t"                                                             \
-                 "s_nop 0\n\t" OP " %[o0], %[base]\n\t"                                                \
-                 "s_add_u32 m0, m0, " STEP "\n\ts_nop 0\n\t" OP " %[o1], %[base]\n\t"                  \
-                 "s_add_u32 m0, m0, " STEP "\n\ts_nop 0\n\t" OP " %[o2], %[base]\n\t"                  \
-                 "s_add_u32 m0, m0, " STEP "\n\ts_nop 0\n\t" OP " %[o3], %[base]\n\t"                  \
-                 "s_add_u32 m0, m0, " STEP "\n\ts_nop 0\n\t" OP " %[o4], %[base]\n\t"                  \
-                 "s_add_u32 m0, m0, " STEP "\n\ts_nop 0\n\t" OP " %[o5], %[base]\n\t"                  \
-                 "s_add_u32 m0, m0, " STEP "\n\ts_nop 0\n\t" OP " %[o6], %[base]\n\t"                  \
-                 "s_mov_b32 m0, %[keep]"                                                                \
-                 : [keep] "=&s"(keep)                                                                   \
-                 : [o0] "v"(o[0]), [o1] "v"(o[1]), [o2] "v"(o[2]), [o3] "v"(o[3]), [o4] "v"(o[4]),      \
-                   [o5] "v"(o[5]), [o6] "v"(o[6]), [base] "s"(base), [lds] "s"(lds)                     \
-                 : "memory", "scc")
-
+// LDS-DMA (global_load_lds_*) is issued through inline asm on purpose: hipcc treats the builtin form as a store to
+// LDS that may alias every later ds_read and drains it with s_waitcnt vmcnt(0), which would serialise the ring.  In
+// asm the compiler neither counts nor waits for these loads; the kernel's own wait_vm<N>() calls are the only
+// synchronisation.  The chunk-level issue code lives in osc_group_stage1.hpp.
 __device__ __forceinline__ uint32_t lds_addr(const float* p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
-}
-
-// DMA a 4-row chunk (100 floats = 25 x 16 B per instance, 16 instances): 7 wave instructions.
-// src = first float of (tile instance 0, row0), wave-uniform; stride = floats between instances.
-__device__ __forceinline__ void dma_rows4(const float* src, int stride, float* buf, int lane) {
-    uint32_t o[7];
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        int x = j * 64 + lane;               // 16-byte piece index, instance-major (25 per instance)
-        x = x > 399 ? 399 : x;
-        int inst = (x * 5243) >> 17;         // x / 25 for x < 2^12
-        int pc = x - inst * 25;
-        o[j] = (uint32_t)(inst * stride + pc * 4) * 4u;
-    }
-    const float* base = src;
-    uint32_t lds = lds_addr(buf), keep;
-    IRLOSC_GLDS7("global_load_lds_dwordx4", "0x400");
-}
-// DMA a single-row chunk (25 floats per instance): 7 wave instructions of 4 B per lane.
-__device__ __forceinline__ void dma_rows1(const float* src, int stride, float* buf, int lane) {
-    uint32_t o[7];
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        int x = j * 64 + lane;
-        x = x > 399 ? 399 : x;
-        int inst = (x * 5243) >> 17;
-        int e = x - inst * 25;
-        o[j] = (uint32_t)(inst * stride + e) * 4u;
-    }
-    const float* base = src;
-    uint32_t lds = lds_addr(buf), keep;
-    IRLOSC_GLDS7("global_load_lds_dword", "0x100");
-}
-// DMA a contiguous block of `pieces` 16-byte pieces (pieces <= 128): 2 wave instructions.
-__device__ __forceinline__ void dma_linear2(const float* src, int pieces, float* buf, int lane) {
-    int x0 = lane, x1 = 64 + lane;
-    x0 = x0 >= pieces ? pieces - 1 : x0;
-    x1 = x1 >= pieces ? pieces - 1 : x1;
-    const uint32_t o0 = (uint32_t)x0 * 16u, o1 = (uint32_t)x1 * 16u;
-    const float* base = src;
-    uint32_t lds = lds_addr(buf), keep;
-    asm volatile("s_mov_b32 %[keep], m0\n\t"
-                 "s_mov_b32 m0, %[lds]\n\t"
-                 "s_nop 0\n\tglobal_load_lds_dwordx4 %[o0], %[base]\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o1], %[base]\n\t"
-                 "s_mov_b32 m0, %[keep]"
-                 : [keep] "=&s"(keep)
-                 : [o0] "v"(o0), [o1] "v"(o1), [base] "s"(base), [lds] "s"(lds)
-                 : "memory", "scc");
-}
-
-// Row rr of J chunk jc for quad q.  Chunks 0,1,2 (4 rows, stride 100) sit in ring slots 1,2,0;
-// chunk 3 (1 row, stride 25) in the tail buffer.
-__device__ __forceinline__ const float* jrow_ptr(const float* ring, const float* jtail, int jc, int q, int rr) {
-    if (jc < 3) return ring + ((jc + 1) % 3) * BUF_FLOATS + q * 100 + rr * N;
-    return jtail + q * N;
 }
 
 }  // namespace grp
