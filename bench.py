@@ -63,9 +63,26 @@ def cpu_baseline(lay, gains, arrays, seconds_target=12.0):
     finally:
         if ctx is not None:
             ctx.__exit__(None, None, None)
-    return dict(value=nsamp / dt, unit="steps/s", cores=1, kind="port",
-                sample=f"{nsamp} of the {a64['M'].shape[0]} instances of slot 0, oracle/osc_oracle.py "
-                       f"(float64 NumPy, OPENBLAS threads=1), {dt:.1f} s"), ref, range(576, 576 + nsamp)
+    out = dict(value=nsamp / dt, unit="steps/s", cores=1, kind="port",
+               sample=f"{nsamp} of the {a64['M'].shape[0]} instances of slot 0, oracle/osc_oracle.py "
+                      f"(float64 NumPy, OPENBLAS threads=1), {dt:.1f} s")
+    # a stronger CPU figure next to it: the same arithmetic with the batch axis inside NumPy's stacked LAPACK
+    # calls (no per-instance interpreter overhead), BLAS threads left at the library default
+    try:
+        from oracle import osc_oracle_batched
+        nb = int(min(a64["M"].shape[0], 16384))
+        sl = {k: (v[:nb] if isinstance(v, np.ndarray) else v) for k, v in a64.items()}
+        gb = {k: (np.asarray(v)[:nb] if np.ndim(v) > {"kp": 1, "kv": 1, "ko": 1, "k": 2, "d": 2, "max_vel": 2,
+                                                       "null_kv": 0}.get(k, 99) else v) for k, v in gains.items()}
+        t0 = time.perf_counter()
+        osc_oracle_batched.generate_batch(od, gb, sl["M"], sl["J"], sl["dq"], sl["bias"], sl["ee_pose"], sl["tgt_pose"],
+                                          sl.get("wrench"), sl.get("tgt_vel"))
+        dtb = time.perf_counter() - t0
+        out["vectorised"] = dict(value=nb / dtb, unit="steps/s", cores=os.cpu_count(),
+                                 sample=f"{nb} instances, oracle/osc_oracle_batched.py (stacked np.linalg calls), {dtb:.1f} s")
+    except Exception as e:                                  # the baseline must never break the bench line
+        out["vectorised"] = dict(error=str(e))
+    return out, ref, range(576, 576 + nsamp)
 
 
 def main():
