@@ -10,7 +10,9 @@
  *   OSC.__init__ gain tables (osc.py:19-39), device row masks /
  *   joint sets (device.py:36,66-69; robot.py:28-32,50-55)       -> irlosc_create, irlosc_set_gains
  *   Robot.get_all_states(): M, dq, J stack, EE pose, wrench
- *   (robot.py:44-72,125-136; device.py:115-170; osc.py:132-138) -> irlosc_upload
+ *   (robot.py:44-72,125-136; device.py:115-170; osc.py:132-138) -> irlosc_upload (records assembled by the caller)
+ *                                                                  irlosc_upload_raw (assembled on the GPU from raw
+ *                                                                  simulator arrays)
  *   targets dict (utils.py:5-67; osc.py:156-159,172)            -> irlosc_set_targets
  *   OSC.generate numerical body (osc.py:41-118,144-200)         -> irlosc_step / irlosc_step_device
  *   forces gather u_all[actuator_trnids] (osc.py:203-210)       -> host side, from u[B,n]
@@ -136,6 +138,28 @@ int irlosc_time_dominant_kernel(irlosc_ctx* ctx, int32_t slot, int32_t B, int32_
 /* Steps chained in one launch by irlosc_step_resident / irlosc_time_dominant_kernel (1 on the generic path):
  * the algorithmic bytes of one dominant launch = this many steps' worth. */
 int irlosc_steps_per_launch(const irlosc_ctx* ctx);
+
+/* State assembly on the GPU (what Robot.get_all_states() / Device.get_state() do per robot on the host:
+ * robot.py:44-72,125-136; device.py:115-170): one batch of RAW simulator arrays in, the resident records of slot
+ * `slot` out (M, J, dq, bias, ee_pose, wrench), same result as irlosc_upload of host-assembled records.
+ *   qM[B][nv][nv]            dense inertia matrix (mj_fullM), nv = sim.model.nv (may exceed n: free bodies)
+ *   qvel[B][nv], qfrc_bias[B][nv]
+ *   jacp[B][ndev][3][nv], jacr[B][ndev][3][nv]   EE-body Jacobians of the target devices, targets order
+ *   ee_xpos[B][ndev][3], ee_xquat[B][ndev][4]    EE-body pose (w,x,y,z)
+ *   site_xmat[B][ndev][9], sensordata[B][n_sensor]   F/T site frames and raw sensor readings; both may be NULL
+ *                                                    (wrench = 0), devices without a sensor have ft_force0 = -1
+ * The row mask ctrlr_dof and the block order come from the context's cfg. */
+typedef struct irlosc_raw_desc {
+    int32_t nv;                               /* dofs in the scene (columns of the raw Jacobians) */
+    int32_t n_sensor;                         /* sensordata length per instance */
+    int32_t joint_ids[IRLOSC_MAX_N];          /* robot.joint_ids_all: raw dof of robot position p (robot.py:28-32) */
+    int32_t dq_src[IRLOSC_MAX_N];             /* raw dof whose qvel lands in dq[p], -1 = 0 (robot.py:60-65) */
+    int32_t ft_force0[IRLOSC_MAX_DEV];        /* first sensordata index of the force triple, -1 = no sensor (device.py:139-170) */
+    int32_t ft_torque0[IRLOSC_MAX_DEV];
+} irlosc_raw_desc;
+int irlosc_upload_raw(irlosc_ctx* ctx, int32_t slot, int32_t B, const irlosc_raw_desc* desc, const void* qM,
+                      const void* qvel, const void* qfrc_bias, const void* jacp, const void* jacr,
+                      const void* ee_xpos, const void* ee_xquat, const void* site_xmat, const void* sensordata);
 
 int irlosc_download(irlosc_ctx* ctx, int32_t B, void* u_host, uint32_t* flags_host);
 int irlosc_sync(irlosc_ctx* ctx);

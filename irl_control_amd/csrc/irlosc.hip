@@ -16,6 +16,7 @@
 #include "osc_generic.hpp"
 #ifndef IRLOSC_NO_GROUP_KERNEL
 #include "osc_group.hpp"
+#include "osc_assemble.hpp"
 #endif
 
 using namespace irlosc;
@@ -55,6 +56,8 @@ struct irlosc_ctx {
     std::vector<PendingStep> pending;  // steps whose stage 2 has not run yet (it rides in the next train, or is flushed)
     void* du = nullptr;                // = du_set[cur]
     uint32_t* dflags = nullptr;        // = dflags_set[cur]
+    void* draw = nullptr;     // staging for irlosc_upload_raw (raw simulator arrays), grown on demand
+    size_t draw_bytes = 0;
     void* dgains = nullptr;   // [nb][ndev][12] in dtype
     void* dnullkv = nullptr;  // [nb]
     int gains_nb = 0;
@@ -140,6 +143,7 @@ static void free_all(irlosc_ctx* c) {
     }
     for (int k = 0; k < irlosc_ctx::NTABLES; ++k)
         if (c->dtable[k]) (void)hipFree(c->dtable[k]);
+    if (c->draw) (void)hipFree(c->draw);
     if (c->dgains) (void)hipFree(c->dgains);
     if (c->dnullkv) (void)hipFree(c->dnullkv);
     if (c->ddbg) (void)hipFree(c->ddbg);
@@ -313,6 +317,78 @@ extern "C" int irlosc_upload(irlosc_ctx* c, int32_t slot, int32_t B, const void*
     if (wrench) HIPCHK(c, hipMemcpyAsync(c->dwrench[slot], wrench, b * nd * 6 * e, hipMemcpyHostToDevice, c->stream));
     c->has_wrench[slot] = wrench != nullptr;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->uploaded[slot] = 1;
+    return IRLOSC_OK;
+}
+
+template <typename T>
+static int upload_raw_t(irlosc_ctx* c, int slot, int B, const irlosc_raw_desc* rd, const void* qM, const void* qvel,
+                        const void* qfrc_bias, const void* jacp, const void* jacr, const void* ee_xpos,
+                        const void* ee_xquat, const void* site_xmat, const void* sensordata) {
+    const size_t b = (size_t)B, nv = (size_t)rd->nv, nd = (size_t)c->cfg.ndev, ns = (size_t)rd->n_sensor, e = sizeof(T);
+    const bool ft = site_xmat && sensordata && ns > 0;
+    // staging layout: qM | qvel | qfrc_bias | jacp | jacr | ee_xpos | ee_xquat | site_xmat | sensordata
+    const size_t sz[9] = {b * nv * nv * e, b * nv * e, b * nv * e, b * nd * 3 * nv * e, b * nd * 3 * nv * e,
+                          b * nd * 3 * e, b * nd * 4 * e, ft ? b * nd * 9 * e : 0, ft ? b * ns * e : 0};
+    const void* src[9] = {qM, qvel, qfrc_bias, jacp, jacr, ee_xpos, ee_xquat, site_xmat, sensordata};
+    size_t off[9], total = 0;
+    for (int i = 0; i < 9; ++i) { off[i] = total; total += (sz[i] + 255) & ~(size_t)255; }
+    if (total > c->draw_bytes) {
+        if (c->draw) HIPCHK(c, hipFree(c->draw));
+        c->draw = nullptr; c->draw_bytes = 0;
+        HIPCHK(c, hipMalloc(&c->draw, total));
+        c->draw_bytes = total;
+    }
+    unsigned char* base = (unsigned char*)c->draw;
+    for (int i = 0; i < 9; ++i)
+        if (sz[i]) HIPCHK(c, hipMemcpyAsync(base + off[i], src[i], sz[i], hipMemcpyHostToDevice, c->stream));
+    RawDesc d;
+    memset(&d, 0, sizeof d);
+    d.nv = rd->nv; d.n_sensor = rd->n_sensor; d.n = c->cfg.n; d.k = c->k; d.ndev = c->cfg.ndev;
+    for (int i = 0; i < c->cfg.n; ++i) { d.joint_ids[i] = rd->joint_ids[i]; d.dq_src[i] = rd->dq_src[i]; }
+    for (int dv = 0; dv < c->cfg.ndev; ++dv) {
+        d.ft_force0[dv] = rd->ft_force0[dv]; d.ft_torque0[dv] = rd->ft_torque0[dv];
+        for (int i = 0; i < 6; ++i) if (c->cfg.ctrlr_dof[dv][i]) d.dofmask[dv] |= 1u << i;
+    }
+    RawPtrs<T> r;
+    r.qM = (const T*)(base + off[0]); r.qvel = (const T*)(base + off[1]); r.qfrc_bias = (const T*)(base + off[2]);
+    r.jacp = (const T*)(base + off[3]); r.jacr = (const T*)(base + off[4]);
+    r.ee_xpos = (const T*)(base + off[5]); r.ee_xquat = (const T*)(base + off[6]);
+    r.site_xmat = ft ? (const T*)(base + off[7]) : nullptr; r.sensordata = ft ? (const T*)(base + off[8]) : nullptr;
+    r.M = (T*)c->dM[slot]; r.J = (T*)c->dJ[slot]; r.dq = (T*)c->ddq[slot]; r.bias = (T*)c->dbias[slot];
+    r.ee = (T*)c->dee[slot]; r.wrench = (T*)c->dwrench[slot];
+    hipLaunchKernelGGL(osc_assemble_kernel<T>, dim3(std::min(B, 65536)), dim3(64), 0, c->stream, d, r, B);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return IRLOSC_OK;
+}
+
+extern "C" int irlosc_upload_raw(irlosc_ctx* c, int32_t slot, int32_t B, const irlosc_raw_desc* rd, const void* qM,
+                                 const void* qvel, const void* qfrc_bias, const void* jacp, const void* jacr,
+                                 const void* ee_xpos, const void* ee_xquat, const void* site_xmat,
+                                 const void* sensordata) {
+    if (!c) return IRLOSC_ERR_ARG;
+    int rc = check_slot(c, slot, B);
+    if (rc) return rc;
+    if (B == 0) { c->uploaded[slot] = 1; return IRLOSC_OK; }
+    if (!rd || !qM || !qvel || !qfrc_bias || !jacp || !jacr || !ee_xpos || !ee_xquat)
+        return fail(c, IRLOSC_ERR_ARG, "desc, qM, qvel, qfrc_bias, jacp, jacr, ee_xpos and ee_xquat are required");
+    if (rd->nv < 1 || rd->n_sensor < 0) return fail(c, IRLOSC_ERR_ARG, "bad nv / n_sensor");
+    for (int i = 0; i < c->cfg.n; ++i) {
+        if (rd->joint_ids[i] < 0 || rd->joint_ids[i] >= rd->nv) return fail(c, IRLOSC_ERR_ARG, "joint_ids[%d] out of [0,nv)", i);
+        if (rd->dq_src[i] >= rd->nv) return fail(c, IRLOSC_ERR_ARG, "dq_src[%d] out of range", i);
+    }
+    for (int dv = 0; dv < c->cfg.ndev; ++dv) {
+        const int f0 = rd->ft_force0[dv], t0 = rd->ft_torque0[dv];
+        if ((f0 >= 0 && f0 + 3 > rd->n_sensor) || (t0 >= 0 && t0 + 3 > rd->n_sensor))
+            return fail(c, IRLOSC_ERR_ARG, "F/T sensor slice of device %d exceeds n_sensor", dv);
+    }
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    rc = c->cfg.dtype == IRLOSC_F64
+             ? upload_raw_t<double>(c, slot, B, rd, qM, qvel, qfrc_bias, jacp, jacr, ee_xpos, ee_xquat, site_xmat, sensordata)
+             : upload_raw_t<float>(c, slot, B, rd, qM, qvel, qfrc_bias, jacp, jacr, ee_xpos, ee_xquat, site_xmat, sensordata);
+    if (rc) return rc;
+    c->has_wrench[slot] = 1;
     c->uploaded[slot] = 1;
     return IRLOSC_OK;
 }

@@ -91,6 +91,28 @@ class OSCLayout:
                     use_g=self.use_g, admittance=self.admittance, nullspace=self.nullspace)
 
     @classmethod
+    def from_devices(cls, devs, robot, use_g: bool = True, admittance: bool = False, nullspace: bool = True,
+                     J_idxs=None) -> "OSCLayout":
+        """Layout for the target devices `devs` (targets order) of `robot`; J_idxs as returned by
+        Robot.get_state(RobotState.J)[1] (robot.py:50-55) or None to derive it from the robot's device order."""
+        import numpy as np
+        if J_idxs is None:
+            J_idxs, row = {}, 0
+            for name, dv in robot.sub_devices_dict.items():
+                r = int(np.sum(dv.ctrlr_dof))
+                J_idxs[name] = np.arange(row, row + r)
+                row += r
+        return cls(
+            n=int(robot.num_joints_total), dev_names=[dv.name for dv in devs],
+            ctrlr_dof=[[bool(x) for x in dv.ctrlr_dof] for dv in devs],
+            joint_ids=[[int(j) for j in dv.joint_ids_all] for dv in devs],
+            j_idx0=[int(J_idxs[dv.name][0]) if len(J_idxs[dv.name]) else 0 for dv in devs],
+            calc_xyz=[bool(np.sum(dv.ctrlr_dof_xyz) > 0) for dv in devs],
+            calc_abg=[bool(np.sum(dv.ctrlr_dof_abg) > 0) for dv in devs],
+            has_max_vel=[dv.max_vel is not None for dv in devs],
+            use_g=bool(use_g), admittance=bool(admittance), nullspace=bool(nullspace))
+
+    @classmethod
     def from_dict(cls, d: Dict) -> "OSCLayout":
         nd = len(d["ctrlr_dof"])
         return cls(n=d["n"], dev_names=list(d.get("dev_names", [f"dev{i}" for i in range(nd)])),

@@ -63,16 +63,8 @@ class OSC():
     # ------------------------------------------------------------------------------------------
     def _layout_for(self, names: List[str], J_idxs) -> OSCLayout:
         devs = [self.robot.get_device(nm) for nm in names]
-        return OSCLayout(
-            n=int(self.robot.num_joints_total), dev_names=list(names),
-            ctrlr_dof=[[bool(x) for x in dv.ctrlr_dof] for dv in devs],
-            joint_ids=[[int(j) for j in dv.joint_ids_all] for dv in devs],
-            j_idx0=[int(J_idxs[nm][0]) if len(J_idxs[nm]) else 0 for nm in names],
-            calc_xyz=[bool(np.sum(dv.ctrlr_dof_xyz) > 0) for dv in devs],
-            calc_abg=[bool(np.sum(dv.ctrlr_dof_abg) > 0) for dv in devs],
-            has_max_vel=[dv.max_vel is not None for dv in devs],
-            use_g=bool(self.use_g), admittance=bool(self.admittance is True),
-            nullspace=self.nullspace_config is not None)
+        return OSCLayout.from_devices(devs, self.robot, use_g=bool(self.use_g), admittance=bool(self.admittance is True),
+                                      nullspace=self.nullspace_config is not None, J_idxs=J_idxs)
 
     def generate(self, targets: Dict[str, Target]):
         if self.robot.is_using_sim() is False:
