@@ -515,32 +515,43 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const TrainStep* _
             for (int pp = 0; pp < P; ++pp) bb[rr].p[pp] = bb[rr].p[pp] * dinv.p[pp];     // b' = D^-1 b
             if (ODD) bb[rr].o *= dinv.o;
         }
-        // column-oriented substitution: y_c = b_c / L[c][c] (owner lane), then b_i -= L[i][c] y_c
+        // column-oriented substitution: y_c = b_c / L[c][c] (owner lane), then b_i -= L[i][c] y_c.  Two rows are
+        // advanced together, column by column: a row's broadcast of y_c reads a register its own previous
+        // multiply-adds have just written (a DPP source needs two wait states after a VALU write), and the other
+        // row's instructions fill exactly that gap instead of an s_nop.
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr) {
-            v2f part24 = v2f{0.f, 0.f};          // this lane's share of sum_c L'[24][c] y_c
+        for (int r0 = 0; r0 < R; r0 += 2) {
+            const int RR = (R - r0) < 2 ? (R - r0) : 2;
+            v2f part24[2] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}};          // this lane's share of sum_c L'[24][c] y_c
 #pragma unroll
             for (int c = 0; c < 24; ++c) {
                 const int sc = c / G, gc = c % G, pc = sc >> 1;
-                const float ycs = -gbcast<G>(sget(bb[rr], sc), gc);      // y_c = b'_c, final once columns < c are done
-                const v2f yc = v2f{ycs, ycs};
 #pragma unroll
-                for (int pp = pc; pp < P; ++pp) bb[rr].p[pp] = __builtin_elementwise_fma(Lp[pp][c], yc, bb[rr].p[pp]);
-                if (gc == G - 1 && (sc & 1)) {   // pair pc is final in every lane of the group now
-                    part24 = __builtin_elementwise_fma(Lq[pc], bb[rr].p[pc], part24);
-                    asm volatile("" : "+v"(part24), "+v"(bb[rr].p[P - 1]));
+                for (int h = 0; h < RR; ++h) {
+                    Row& bw = bb[r0 + h];
+                    const float ycs = -gbcast<G>(sget(bw, sc), gc);      // y_c = b'_c, final once columns < c are done
+                    const v2f yc = v2f{ycs, ycs};
+#pragma unroll
+                    for (int pp = pc; pp < P; ++pp) bw.p[pp] = __builtin_elementwise_fma(Lp[pp][c], yc, bw.p[pp]);
+                    if (gc == G - 1 && (sc & 1))     // pair pc is final in every lane of the group now
+                        part24[h] = __builtin_elementwise_fma(Lq[pc], bw.p[pc], part24[h]);
+                    asm volatile("" : "+v"(part24[h]), "+v"(bw.p[P - 1]));
                 }
             }
-            if (ODD) {
-                const float y24 = bb[rr].o - gsum<G>(part24.x + part24.y);            // b'_24 sits on lane 0 only
-                bb[rr].o = lastpad ? 0.f : y24;
+#pragma unroll
+            for (int h = 0; h < RR; ++h) {
+                const int rr = r0 + h;
+                if (ODD) {
+                    const float y24 = bb[rr].o - gsum<G>(part24[h].x + part24[h].y);            // b'_24 sits on lane 0 only
+                    bb[rr].o = lastpad ? 0.f : y24;
+                }
+#pragma unroll
+                for (int pp = 0; pp < P; ++pp) Y[jc * 4 + rr].p[pp] = bb[rr].p[pp];
+                Y[jc * 4 + rr].o = ODD ? bb[rr].o : 0.f;
+#pragma unroll
+                for (int pp = 0; pp < P; ++pp) asm volatile("" : "+v"(Y[jc * 4 + rr].p[pp]));
+                if (ODD) asm volatile("" : "+v"(Y[jc * 4 + rr].o));
             }
-#pragma unroll
-            for (int pp = 0; pp < P; ++pp) Y[jc * 4 + rr].p[pp] = bb[rr].p[pp];
-            Y[jc * 4 + rr].o = ODD ? bb[rr].o : 0.f;
-#pragma unroll
-            for (int pp = 0; pp < P; ++pp) asm volatile("" : "+v"(Y[jc * 4 + rr].p[pp]));
-            if (ODD) asm volatile("" : "+v"(Y[jc * 4 + rr].o));
             __builtin_amdgcn_sched_barrier(0);
         }
         wait_lgkm0();
