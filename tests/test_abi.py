@@ -34,6 +34,13 @@ def test_cfg_struct_matches_header_layout():
     assert C.sizeof(_lib.Cfg) == 8 * 4 + 16 + 24 + 4 + 4 + 16 + 16
 
 
+def test_raw_desc_struct_matches_header_layout():
+    # struct irlosc_raw_desc: nv, n_sensor, joint_ids[32], dq_src[32], ft_force0[4], ft_torque0[4] (all int32)
+    assert C.sizeof(_lib.RawDesc) == 4 * (2 + 32 + 32 + 4 + 4)
+    hdr = open(os.path.join(ROOT, "include", "irlosc.h")).read()
+    assert "#define IRLOSC_MAX_N 32" in hdr and "#define IRLOSC_MAX_DEV 4" in hdr
+
+
 def _layout():
     return OSCLayout(n=25, dev_names=["a", "b"], ctrlr_dof=[[True] * 6, [True] * 6],
                      joint_ids=[list(range(1, 13)), list(range(13, 25))], j_idx0=[1, 7])
