@@ -271,6 +271,21 @@ def test_step_resident_trains_equal_single_steps(iters):
     osc.close()
 
 
+def test_stage2_many_flagged_per_span():
+    """Every instance rank-deficient by one (a duplicated Jacobian row): all 384 instances of a stage-2 span are
+    flagged, so a stage-2 block needs several rounds of 64; the truncated solve must agree with the generic kernel."""
+    B = 1024
+    lay, gains, g = synth.make_batch("k13", B, seed=71, dtype=np.float32)
+    g["J"][:, 12] = g["J"][:, 0] * np.float32(1.0)
+    g["J"][:, 7] = g["J"][:, 3]
+    ref, fref, _ = run_gpu(lay, gains, g, np.float32, _lib.KERNEL_GENERIC)
+    u, fl, name = run_gpu(lay, gains, g, np.float32, _lib.KERNEL_GROUP)
+    assert "group" in name
+    assert np.all(fl & _lib.FLAG_EIGEN_PATH) and np.all(fl & _lib.FLAG_TRUNCATED) and np.all(fref & _lib.FLAG_TRUNCATED)
+    d = np.abs(u - ref).max(axis=1) / np.abs(ref).max(axis=1)
+    assert np.all(np.isfinite(u)) and np.median(d) < 1e-3 and np.quantile(d, 0.95) < 5e-2, (float(np.median(d)), float(d.max()))
+
+
 def test_give_up_instances_inside_trains():
     """Instances whose task Jacobian loses FIVE ranks exceed what stage 2 deflates (three vectors): they must come out
     of the give-up list -> generic kernel path also when steps are chained in trains, and agree with the generic kernel
