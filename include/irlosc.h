@@ -161,6 +161,14 @@ int irlosc_upload_raw(irlosc_ctx* ctx, int32_t slot, int32_t B, const irlosc_raw
                       const void* qvel, const void* qfrc_bias, const void* jacp, const void* jacr,
                       const void* ee_xpos, const void* ee_xquat, const void* site_xmat, const void* sensordata);
 
+/* Same assembly for simulators whose state already lives in HBM: every array pointer is a DEVICE pointer (layouts
+ * as above), hip_stream a hipStream_t (NULL = the context's stream).  No copies; the call returns after enqueueing the
+ * kernel, and steps of this context issued on the same stream see the assembled slot. */
+int irlosc_assemble_device(irlosc_ctx* ctx, int32_t slot, int32_t B, const irlosc_raw_desc* desc, const void* d_qM,
+                           const void* d_qvel, const void* d_qfrc_bias, const void* d_jacp, const void* d_jacr,
+                           const void* d_ee_xpos, const void* d_ee_xquat, const void* d_site_xmat,
+                           const void* d_sensordata, void* hip_stream);
+
 int irlosc_download(irlosc_ctx* ctx, int32_t B, void* u_host, uint32_t* flags_host);
 int irlosc_sync(irlosc_ctx* ctx);
 

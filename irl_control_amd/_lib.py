@@ -19,7 +19,7 @@ EXPORTS = ["irlosc_abi_version", "irlosc_device_count", "irlosc_create", "irlosc
            "irlosc_last_error", "irlosc_kernel_name", "irlosc_set_gains", "irlosc_upload",
            "irlosc_set_targets", "irlosc_step", "irlosc_step_resident", "irlosc_download",
            "irlosc_sync", "irlosc_step_device", "irlosc_time_dominant_kernel",
-           "irlosc_steps_per_launch", "irlosc_upload_raw"]
+           "irlosc_steps_per_launch", "irlosc_upload_raw", "irlosc_assemble_device"]
 
 
 class RawDesc(C.Structure):
@@ -72,6 +72,7 @@ def load():
     lib.irlosc_time_dominant_kernel.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_float)]
     lib.irlosc_steps_per_launch.argtypes = [vp]
     lib.irlosc_upload_raw.argtypes = [vp, i32, i32, C.POINTER(RawDesc)] + [vp] * 9
+    lib.irlosc_assemble_device.argtypes = [vp, i32, i32, C.POINTER(RawDesc)] + [vp] * 10
     lib.irlosc_download.argtypes = [vp, i32, vp, vp]
     lib.irlosc_sync.argtypes = [vp]
     lib.irlosc_step_device.argtypes = [vp, i32] + [vp] * 11

@@ -321,6 +321,43 @@ extern "C" int irlosc_upload(irlosc_ctx* c, int32_t slot, int32_t B, const void*
     return IRLOSC_OK;
 }
 
+// Enqueue the assembly kernel: dptr = device pointers {qM, qvel, qfrc_bias, jacp, jacr, ee_xpos, ee_xquat, site_xmat, sensordata}.
+template <typename T>
+static int assemble_launch(irlosc_ctx* c, int slot, int B, const irlosc_raw_desc* rd, const void* const* dptr, hipStream_t st) {
+    RawDesc d;
+    memset(&d, 0, sizeof d);
+    d.nv = rd->nv; d.n_sensor = rd->n_sensor; d.n = c->cfg.n; d.k = c->k; d.ndev = c->cfg.ndev;
+    for (int i = 0; i < c->cfg.n; ++i) { d.joint_ids[i] = rd->joint_ids[i]; d.dq_src[i] = rd->dq_src[i]; }
+    for (int dv = 0; dv < c->cfg.ndev; ++dv) {
+        d.ft_force0[dv] = rd->ft_force0[dv]; d.ft_torque0[dv] = rd->ft_torque0[dv];
+        for (int i = 0; i < 6; ++i) if (c->cfg.ctrlr_dof[dv][i]) d.dofmask[dv] |= 1u << i;
+    }
+    const bool ft = dptr[7] && dptr[8] && rd->n_sensor > 0;
+    RawPtrs<T> r;
+    r.qM = (const T*)dptr[0]; r.qvel = (const T*)dptr[1]; r.qfrc_bias = (const T*)dptr[2];
+    r.jacp = (const T*)dptr[3]; r.jacr = (const T*)dptr[4]; r.ee_xpos = (const T*)dptr[5]; r.ee_xquat = (const T*)dptr[6];
+    r.site_xmat = ft ? (const T*)dptr[7] : nullptr; r.sensordata = ft ? (const T*)dptr[8] : nullptr;
+    r.M = (T*)c->dM[slot]; r.J = (T*)c->dJ[slot]; r.dq = (T*)c->ddq[slot]; r.bias = (T*)c->dbias[slot];
+    r.ee = (T*)c->dee[slot]; r.wrench = (T*)c->dwrench[slot];
+    hipLaunchKernelGGL(osc_assemble_kernel<T>, dim3(std::min(B, 65536)), dim3(64), 0, st, d, r, B);
+    HIPCHK(c, hipGetLastError());
+    return IRLOSC_OK;
+}
+
+static int check_raw_desc(irlosc_ctx* c, const irlosc_raw_desc* rd) {
+    if (rd->nv < 1 || rd->n_sensor < 0) return fail(c, IRLOSC_ERR_ARG, "bad nv / n_sensor");
+    for (int i = 0; i < c->cfg.n; ++i) {
+        if (rd->joint_ids[i] < 0 || rd->joint_ids[i] >= rd->nv) return fail(c, IRLOSC_ERR_ARG, "joint_ids[%d] out of [0,nv)", i);
+        if (rd->dq_src[i] >= rd->nv) return fail(c, IRLOSC_ERR_ARG, "dq_src[%d] out of range", i);
+    }
+    for (int dv = 0; dv < c->cfg.ndev; ++dv) {
+        const int f0 = rd->ft_force0[dv], t0 = rd->ft_torque0[dv];
+        if ((f0 >= 0 && f0 + 3 > rd->n_sensor) || (t0 >= 0 && t0 + 3 > rd->n_sensor))
+            return fail(c, IRLOSC_ERR_ARG, "F/T sensor slice of device %d exceeds n_sensor", dv);
+    }
+    return IRLOSC_OK;
+}
+
 template <typename T>
 static int upload_raw_t(irlosc_ctx* c, int slot, int B, const irlosc_raw_desc* rd, const void* qM, const void* qvel,
                         const void* qfrc_bias, const void* jacp, const void* jacr, const void* ee_xpos,
@@ -342,23 +379,10 @@ static int upload_raw_t(irlosc_ctx* c, int slot, int B, const irlosc_raw_desc* r
     unsigned char* base = (unsigned char*)c->draw;
     for (int i = 0; i < 9; ++i)
         if (sz[i]) HIPCHK(c, hipMemcpyAsync(base + off[i], src[i], sz[i], hipMemcpyHostToDevice, c->stream));
-    RawDesc d;
-    memset(&d, 0, sizeof d);
-    d.nv = rd->nv; d.n_sensor = rd->n_sensor; d.n = c->cfg.n; d.k = c->k; d.ndev = c->cfg.ndev;
-    for (int i = 0; i < c->cfg.n; ++i) { d.joint_ids[i] = rd->joint_ids[i]; d.dq_src[i] = rd->dq_src[i]; }
-    for (int dv = 0; dv < c->cfg.ndev; ++dv) {
-        d.ft_force0[dv] = rd->ft_force0[dv]; d.ft_torque0[dv] = rd->ft_torque0[dv];
-        for (int i = 0; i < 6; ++i) if (c->cfg.ctrlr_dof[dv][i]) d.dofmask[dv] |= 1u << i;
-    }
-    RawPtrs<T> r;
-    r.qM = (const T*)(base + off[0]); r.qvel = (const T*)(base + off[1]); r.qfrc_bias = (const T*)(base + off[2]);
-    r.jacp = (const T*)(base + off[3]); r.jacr = (const T*)(base + off[4]);
-    r.ee_xpos = (const T*)(base + off[5]); r.ee_xquat = (const T*)(base + off[6]);
-    r.site_xmat = ft ? (const T*)(base + off[7]) : nullptr; r.sensordata = ft ? (const T*)(base + off[8]) : nullptr;
-    r.M = (T*)c->dM[slot]; r.J = (T*)c->dJ[slot]; r.dq = (T*)c->ddq[slot]; r.bias = (T*)c->dbias[slot];
-    r.ee = (T*)c->dee[slot]; r.wrench = (T*)c->dwrench[slot];
-    hipLaunchKernelGGL(osc_assemble_kernel<T>, dim3(std::min(B, 65536)), dim3(64), 0, c->stream, d, r, B);
-    HIPCHK(c, hipGetLastError());
+    const void* dptr[9];
+    for (int i = 0; i < 9; ++i) dptr[i] = sz[i] ? (const void*)(base + off[i]) : nullptr;
+    int rc = assemble_launch<T>(c, slot, B, rd, dptr, c->stream);
+    if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return IRLOSC_OK;
 }
@@ -373,20 +397,35 @@ extern "C" int irlosc_upload_raw(irlosc_ctx* c, int32_t slot, int32_t B, const i
     if (B == 0) { c->uploaded[slot] = 1; return IRLOSC_OK; }
     if (!rd || !qM || !qvel || !qfrc_bias || !jacp || !jacr || !ee_xpos || !ee_xquat)
         return fail(c, IRLOSC_ERR_ARG, "desc, qM, qvel, qfrc_bias, jacp, jacr, ee_xpos and ee_xquat are required");
-    if (rd->nv < 1 || rd->n_sensor < 0) return fail(c, IRLOSC_ERR_ARG, "bad nv / n_sensor");
-    for (int i = 0; i < c->cfg.n; ++i) {
-        if (rd->joint_ids[i] < 0 || rd->joint_ids[i] >= rd->nv) return fail(c, IRLOSC_ERR_ARG, "joint_ids[%d] out of [0,nv)", i);
-        if (rd->dq_src[i] >= rd->nv) return fail(c, IRLOSC_ERR_ARG, "dq_src[%d] out of range", i);
-    }
-    for (int dv = 0; dv < c->cfg.ndev; ++dv) {
-        const int f0 = rd->ft_force0[dv], t0 = rd->ft_torque0[dv];
-        if ((f0 >= 0 && f0 + 3 > rd->n_sensor) || (t0 >= 0 && t0 + 3 > rd->n_sensor))
-            return fail(c, IRLOSC_ERR_ARG, "F/T sensor slice of device %d exceeds n_sensor", dv);
-    }
+    rc = check_raw_desc(c, rd);
+    if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->cfg.hip_device));
     rc = c->cfg.dtype == IRLOSC_F64
              ? upload_raw_t<double>(c, slot, B, rd, qM, qvel, qfrc_bias, jacp, jacr, ee_xpos, ee_xquat, site_xmat, sensordata)
              : upload_raw_t<float>(c, slot, B, rd, qM, qvel, qfrc_bias, jacp, jacr, ee_xpos, ee_xquat, site_xmat, sensordata);
+    if (rc) return rc;
+    c->has_wrench[slot] = 1;
+    c->uploaded[slot] = 1;
+    return IRLOSC_OK;
+}
+
+extern "C" int irlosc_assemble_device(irlosc_ctx* c, int32_t slot, int32_t B, const irlosc_raw_desc* rd, const void* qM,
+                                      const void* qvel, const void* qfrc_bias, const void* jacp, const void* jacr,
+                                      const void* ee_xpos, const void* ee_xquat, const void* site_xmat,
+                                      const void* sensordata, void* hip_stream) {
+    if (!c) return IRLOSC_ERR_ARG;
+    int rc = check_slot(c, slot, B);
+    if (rc) return rc;
+    if (B == 0) { c->uploaded[slot] = 1; return IRLOSC_OK; }
+    if (!rd || !qM || !qvel || !qfrc_bias || !jacp || !jacr || !ee_xpos || !ee_xquat)
+        return fail(c, IRLOSC_ERR_ARG, "desc, qM, qvel, qfrc_bias, jacp, jacr, ee_xpos and ee_xquat are required");
+    rc = check_raw_desc(c, rd);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    const void* dptr[9] = {qM, qvel, qfrc_bias, jacp, jacr, ee_xpos, ee_xquat, site_xmat, sensordata};
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    rc = c->cfg.dtype == IRLOSC_F64 ? assemble_launch<double>(c, slot, B, rd, dptr, st)
+                                    : assemble_launch<float>(c, slot, B, rd, dptr, st);
     if (rc) return rc;
     c->has_wrench[slot] = 1;
     c->uploaded[slot] = 1;

@@ -395,6 +395,49 @@ def test_upload_raw_equals_host_state_assembly(dtype, cfg_file, admittance, name
         assert np.array_equal(u_raw, u_host)
 
 
+def test_assemble_device_from_gpu_resident_raw_state():
+    """irlosc_assemble_device: raw simulator arrays that already live in HBM (here: torch tensors) -> resident slot,
+    no copies; the following step must equal the host-staged irlosc_upload_raw path bit for bit."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    B, nv, ns = 256, 37, 18
+    lay = synth.make_layout("k13")
+    rng = np.random.default_rng(5)
+    f = np.float32
+    spd = rng.normal(size=(B, nv, nv))
+    arr = dict(qM=(spd @ spd.transpose(0, 2, 1) / nv + np.eye(nv)).astype(f), qvel=rng.normal(size=(B, nv)).astype(f),
+               qfrc_bias=rng.normal(size=(B, nv)).astype(f), jacp=rng.normal(size=(B, 3, 3, nv)).astype(f),
+               jacr=rng.normal(size=(B, 3, 3, nv)).astype(f), ee_xpos=rng.normal(size=(B, 3, 3)).astype(f),
+               ee_xquat=rng.normal(size=(B, 3, 4)).astype(f), site_xmat=rng.normal(size=(B, 3, 9)).astype(f),
+               sensordata=rng.normal(size=(B, ns)).astype(f))
+    d = _lib.RawDesc()
+    d.nv, d.n_sensor = nv, ns
+    for p_ in range(32):
+        d.joint_ids[p_] = p_ + 3 if p_ < 25 else 0           # the robot's dofs sit behind three others
+        d.dq_src[p_] = p_ if p_ < 25 else -1
+    for i in range(4):
+        d.ft_force0[i], d.ft_torque0[i] = (6 * i, 6 * i + 3) if i < 2 else (-1, -1)
+    _, gains, g = synth.make_batch("k13", B, seed=2, dtype=f)
+    osc = BatchedOSC(lay, B, dtype=f)
+    osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+    osc.upload_raw(d, **arr)
+    osc.set_targets(g["tgt_pose"])
+    u_ref = osc.step()
+    dev = {k: torch.from_numpy(v).cuda() for k, v in arr.items()}
+    torch.cuda.synchronize()
+    pp = lambda t: C.c_void_p(t.data_ptr())
+    # scribble over the slot first so that a no-op would be noticed
+    osc.upload(np.zeros((B, 25, 25), f) + np.eye(25, dtype=f), np.zeros((B, 13, 25), f), np.zeros((B, 25), f),
+               np.zeros((B, 25), f), g["ee_pose"], None)
+    rc = osc.lib.irlosc_assemble_device(osc._h, 0, B, C.byref(d), pp(dev["qM"]), pp(dev["qvel"]), pp(dev["qfrc_bias"]),
+                                        pp(dev["jacp"]), pp(dev["jacr"]), pp(dev["ee_xpos"]), pp(dev["ee_xquat"]),
+                                        pp(dev["site_xmat"]), pp(dev["sensordata"]), None)
+    assert rc == 0, osc.lib.irlosc_last_error(osc._h)
+    u_dev = osc.step()
+    osc.close()
+    assert np.all(np.isfinite(u_ref)) and np.array_equal(u_dev, u_ref)
+
+
 def test_step_device_raw_pointers():
     """irlosc_step_device: caller-owned device buffers (here: torch tensors), no copies by the library."""
     torch = pytest.importorskip("torch")
