@@ -520,7 +520,6 @@ static int group_train(irlosc_ctx* c, const KParams<float>* ps, const int* sets,
     for (int t = 0; t < irlosc_ctx::NTABLES && !dt; ++t)
         if (c->htable[t].size() == tbytes && memcmp(c->htable[t].data(), tab.data(), tbytes) == 0) dt = (TrainStep*)c->dtable[t];
     if (!dt || st != c->stream) {
-        if (getenv("IRLOSC_DEBUG_TABLES")) fprintf(stderr, "[irlosc] train table upload (%d entries)\n", entries);
         const int t = c->table_next;
         c->table_next = (c->table_next + 1) % irlosc_ctx::NTABLES;
         dt = (TrainStep*)c->dtable[t];
@@ -531,7 +530,7 @@ static int group_train(irlosc_ctx* c, const KParams<float>* ps, const int* sets,
     int rc = launch_group_train(dt, entries, acc, c->k, c->cfg.ndev, st);
     if (rc) return fail(c, IRLOSC_ERR_HIP, "group kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     if (c->tev_end) HIPCHK(c, hipEventRecord(c->tev_end, st));
-    if (riders && !getenv("IRLOSC_SKIP_LISTS")) {     // give-up lists of the steps whose stage 2 just ran (normally empty: 16 idle blocks per step)
+    if (riders) {     // give-up lists of the steps whose stage 2 just ran (normally empty: 16 idle blocks per step)
         rc = launch_giveup_lists(dt, entries, c->cfg.n, c->k, c->cfg.ndev, st);
         if (rc) return fail(c, IRLOSC_ERR_HIP, "give-up kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     }
