@@ -238,7 +238,7 @@ def test_group_vs_generic_fp32_kernels_agree():
 
 @pytest.mark.parametrize("iters", [1, 2, 7, 8, 9, 17, 24])
 def test_step_resident_trains_equal_single_steps(iters):
-    """irlosc_step_resident chains up to 8 steps per launch and lets their eigen-path stage ride in the next
+    """irlosc_step_resident chains several steps (8 by default) per launch and lets their eigen-path stage ride in the next
     launch; whatever the train split, the outputs left behind are bit-for-bit those of a plain single step on the
     last slot visited (n_slots = 3 distinct batches, truncation-heavy data so that stage 2 has work in every step)."""
     nslots, B = 3, 1024 + 16
@@ -252,7 +252,7 @@ def test_step_resident_trains_equal_single_steps(iters):
         batches.append(g)
         if sl == 0:
             osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
-    assert 1 <= osc.steps_per_launch <= 8
+    assert 1 <= osc.steps_per_launch <= 16
     first = 1
     osc.step_resident(iters, first_slot=first)
     u_train, f_train = osc.download(B)
