@@ -513,6 +513,7 @@ static int group_train(irlosc_ctx* c, const KParams<float>* ps, const int* sets,
         e.block0 = acc;
         acc += e.n2 + tiles;
     }
+    if (acc > 0) {
     // Device copy of the table.  A resident loop keeps producing the same few tables, so the last NTABLES ones are
     // kept and reused by content; a miss overwrites the oldest (stream order keeps that safe on one stream).
     TrainStep* dt = nullptr;
@@ -534,6 +535,7 @@ static int group_train(irlosc_ctx* c, const KParams<float>* ps, const int* sets,
         rc = launch_giveup_lists(dt, entries, c->cfg.n, c->k, c->cfg.ndev, st);
         if (rc) return fail(c, IRLOSC_ERR_HIP, "give-up kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     }
+    }   // acc > 0 (a batch smaller than one tile is all ragged tail: nothing to launch here)
     for (int i = 0; i < n; ++i) {   // ragged tail (< 16 instances): generic kernel on the last instances
         const int nfast = (ps[i].B / GROUP_TILE) * GROUP_TILE, rem = ps[i].B - nfast;
         if (rem > 0) {

@@ -322,6 +322,40 @@ def test_time_dominant_kernel_leaves_complete_outputs():
     osc.close()
 
 
+def test_fleet_example_matches_per_robot_generate():
+    """examples/fleet_batched.py (raw arrays -> GPU assembly -> one batched step -> ctrl) gives every robot the
+    actuator forces OSC.generate gives that robot alone (the B = 1 drop-in path), fp64."""
+    import importlib.util
+    import os
+    import irl_control_amd as ic
+    from irl_control_amd.fakesim import FakeSim, randomize
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "fleet_batched.py")
+    spec = importlib.util.spec_from_file_location("fleet_batched", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n = 24
+    ctrl = mod.run(n_robots=n, ticks=1, seed=3, dtype=np.float64, verbose=False)
+    rng = np.random.default_rng(3)                     # the same simulators, one robot at a time through OSC.generate
+    for b in range(n):
+        sim = randomize(FakeSim(), rng, wrench=True)
+        app = ic.MujocoApp("default_xyz_abg.yaml", None, sim=sim)
+        rob = app.get_robot("DualUR5")
+        cfgs = [("ur5right", app.get_controller_config("osc2")), ("ur5left", app.get_controller_config("osc2")),
+                ("base", app.get_controller_config("osc0"))]
+        osc = ic.OSC(rob, sim, cfgs, app.get_controller_config("nullspace"))
+        targets = {}
+        for i, nm in enumerate(["ur5right", "ur5left", "base"]):
+            dv = rob.get_device(nm)
+            t = ic.Target()
+            pose = dv.pack_pose7()
+            t.set_all_quat(pose[:3] + 0.1 * np.sin(np.arange(3)), pose[3:])
+            targets[nm] = t
+        expect = np.zeros_like(sim.data.ctrl)
+        for idx, f in zip(*osc.generate(targets)):
+            expect[idx] = f
+        assert np.max(np.abs(ctrl[b] - expect)) <= 1e-9 * max(1.0, np.abs(expect).max()), b
+
+
 def test_headless_gain_test_loop_runs():
     """examples/gain_test_headless.py: the reference's tick loop (examples/gain_test.py:98-175) on the build's
     classes with an injected simulator; OSC.generate goes through the C ABI every tick."""
