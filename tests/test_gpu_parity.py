@@ -170,6 +170,27 @@ def test_linearity_in_bias_and_empty_batch():
     assert out.shape == (0, 25)
 
 
+def test_admittance_wrench_enters_linearly_full_size():
+    """Size-independent property at the full 65 536-instance size, admittance layout (BASELINE configs[4]): the
+    external wrench enters u only through -J^T Mx ext_f (osc.py:184-185), so u is affine in it."""
+    B = 65536
+    lay, gains, g = synth.make_batch("k12_admit", B, seed=13, dtype=np.float32)
+    assert lay.admittance and g.get("wrench") is not None
+    u1, f1, name = run_gpu(lay, gains, g, np.float32)
+    g0 = dict(g); g0["wrench"] = np.zeros_like(g["wrench"])
+    u0, _, _ = run_gpu(lay, gains, g0, np.float32)
+    g2 = dict(g); g2["wrench"] = (2.0 * g["wrench"]).astype(np.float32)
+    u2, _, _ = run_gpu(lay, gains, g2, np.float32)
+    assert "group" in name
+    ok = np.isfinite(u0).all(axis=1) & np.isfinite(u1).all(axis=1) & np.isfinite(u2).all(axis=1)
+    assert ok.mean() > 0.999
+    d1, d2 = (u1 - u0)[ok], (u2 - u1)[ok]
+    scale = np.maximum(np.abs(u1[ok]).max(axis=1, keepdims=True), 1.0)
+    err = np.abs(d2 - d1).max(axis=1) / scale[:, 0]
+    assert np.quantile(err, 0.99) < 2e-3 and np.median(err) < 2e-5, (float(np.median(err)), float(np.quantile(err, 0.99)))
+    assert np.abs(d1).max() > 1.0                         # the wrench really acts
+
+
 # ------------------------------------------------------------------------------------------------
 # Throughput (group) path specifics
 # ------------------------------------------------------------------------------------------------
