@@ -44,6 +44,7 @@ class OSC():
         self._dtype = dtype
         self._hip_device = hip_device
         self._ctx: Dict[tuple, BatchedOSC] = {}
+        self._layouts: Dict[tuple, OSCLayout] = {}
         self.last_flags = 0
 
     # ------------------------------------------------------------------------------------------
@@ -63,6 +64,19 @@ class OSC():
     # ------------------------------------------------------------------------------------------
     def _layout_for(self, names: List[str], J_idxs) -> OSCLayout:
         devs = [self.robot.get_device(nm) for nm in names]
+        # the layout only changes when the caller re-masks a device (ps_move example) or passes other targets:
+        # key on exactly what it is built from and reuse the object (and with it the GPU context)
+        key = (tuple(names), tuple(tuple(bool(x) for x in dv.ctrlr_dof) for dv in devs),
+               tuple((bool(np.sum(dv.ctrlr_dof_xyz) > 0), bool(np.sum(dv.ctrlr_dof_abg) > 0)) for dv in devs),
+               tuple(dv.max_vel is not None for dv in devs), tuple(int(J_idxs[nm][0]) if len(J_idxs[nm]) else 0 for nm in names),
+               bool(self.use_g), bool(self.admittance is True), self.nullspace_config is not None)
+        hit = self._layouts.get(key)
+        if hit is not None:
+            return hit
+        self._layouts[key] = lay = self._build_layout(devs, J_idxs)
+        return lay
+
+    def _build_layout(self, devs, J_idxs) -> OSCLayout:
         return OSCLayout.from_devices(devs, self.robot, use_g=bool(self.use_g), admittance=bool(self.admittance is True),
                                       nullspace=self.nullspace_config is not None, J_idxs=J_idxs)
 
