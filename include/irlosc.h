@@ -76,7 +76,8 @@ typedef enum {
 /* kernel selection (cfg.kernel) */
 #define IRLOSC_KERNEL_AUTO    0
 #define IRLOSC_KERNEL_GENERIC 1   /* one wavefront per instance, LDS tiles, any n<=32, k<=16 */
-#define IRLOSC_KERNEL_GROUP   2   /* G lanes per instance, register-resident factors (n=25 shapes) */
+#define IRLOSC_KERNEL_GROUP   2   /* fp32: 4 lanes per instance, register-resident factors (n=25 shapes) */
+#define IRLOSC_KERNEL_ROW16   3   /* fp64: 16 lanes (one DPP row) per instance, broadcast-FMA formulation (n=25 shapes) */
 
 typedef struct irlosc_cfg {
     int32_t hip_device;                      /* HIP device ordinal */

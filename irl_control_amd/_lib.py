@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("IRLOSC_LIB", os.path.join(_HERE, "libirlosc.so"))   #
 MAX_DEV, MAX_N, MAX_K, GAIN_WORDS = 4, 32, 16, 12
 F32, F64 = 0, 1
 USE_G, ADMITTANCE, NULLSPACE = 1, 2, 4
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_GROUP = 0, 1, 2
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_GROUP, KERNEL_ROW16 = 0, 1, 2, 3
 FLAG_M_NOT_PD, FLAG_PINV_BRANCH, FLAG_EIGEN_PATH, FLAG_TRUNCATED = 1, 2, 4, 8
 FLAG_VEL_BRANCH_B, FLAG_BAD_JIDX, FLAG_NONFINITE = 16, 32, 64
 

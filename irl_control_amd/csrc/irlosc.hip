@@ -14,10 +14,9 @@
 #include "../../include/irlosc.h"
 #include "osc_common.hpp"
 #include "osc_generic.hpp"
-#ifndef IRLOSC_NO_GROUP_KERNEL
 #include "osc_group.hpp"
 #include "osc_assemble.hpp"
-#endif
+#include "osc_row16.hpp"
 
 using namespace irlosc;
 
@@ -38,7 +37,7 @@ struct irlosc_ctx {
     static constexpr int TRAIN_MAX = 16;
     static constexpr int NSETS_MAX = 2 * TRAIN_MAX;
     int nsets = 1;
-    int train = 1;                     // steps per launch in irlosc_step_resident (IRLOSC_TRAIN=1..16 overrides)
+    int train = 1;                     // steps per launch in irlosc_step_resident
     void* du_set[NSETS_MAX] = {};
     uint32_t* dflags_set[NSETS_MAX] = {};
     float* dside_set[NSETS_MAX] = {};
@@ -58,6 +57,12 @@ struct irlosc_ctx {
     uint32_t* dflags = nullptr;        // = dflags_set[cur]
     void* draw = nullptr;     // staging for irlosc_upload_raw (raw simulator arrays), grown on demand
     size_t draw_bytes = 0;
+    // fp64 row16 path: zero page for the padding lanes, worklist of the instances handed to the generic kernel, and
+    // two counters used alternately (the worklist pass of a step zeroes the counter of the next one)
+    void* dzeros = nullptr;
+    int32_t* dr16_list = nullptr;
+    int32_t* dr16_count = nullptr;
+    int r16_parity = 0;
     void* dgains = nullptr;   // [nb][ndev][12] in dtype
     void* dnullkv = nullptr;  // [nb]
     int gains_nb = 0;
@@ -125,7 +130,7 @@ static int validate(const irlosc_cfg* c, int* k_out) {
         k += pc;
     }
     if (k < 1 || k > IRLOSC_MAX_K) return fail(nullptr, IRLOSC_ERR_ARG, "k=%d out of [1,%d]", k, IRLOSC_MAX_K);
-    if (c->kernel < IRLOSC_KERNEL_AUTO || c->kernel > IRLOSC_KERNEL_GROUP)
+    if (c->kernel < IRLOSC_KERNEL_AUTO || c->kernel > IRLOSC_KERNEL_ROW16)
         return fail(nullptr, IRLOSC_ERR_ARG, "unknown kernel id %d", c->kernel);
     *k_out = k;
     return IRLOSC_OK;
@@ -144,6 +149,9 @@ static void free_all(irlosc_ctx* c) {
     for (int k = 0; k < irlosc_ctx::NTABLES; ++k)
         if (c->dtable[k]) (void)hipFree(c->dtable[k]);
     if (c->draw) (void)hipFree(c->draw);
+    if (c->dzeros) (void)hipFree(c->dzeros);
+    if (c->dr16_list) (void)hipFree(c->dr16_list);
+    if (c->dr16_count) (void)hipFree(c->dr16_count);
     if (c->dgains) (void)hipFree(c->dgains);
     if (c->dnullkv) (void)hipFree(c->dnullkv);
     if (c->ddbg) (void)hipFree(c->ddbg);
@@ -182,8 +190,6 @@ static int create_impl(irlosc_ctx* c) {
     c->targeted.assign(g.n_slots, 0);
     if (c->kernel == IRLOSC_KERNEL_GROUP) {
         c->train = 8;                       // 16 gains another ~1 % at twice the output-set memory
-        if (const char* ev = getenv("IRLOSC_TRAIN")) c->train = std::max(1, std::min((int)irlosc_ctx::TRAIN_MAX, atoi(ev)));
-        if (getenv("IRLOSC_NO_PIPELINE")) c->train = 1;
         c->nsets = 2 * c->train;
     }
     for (int k2 = 0; k2 < c->nsets; ++k2) {
@@ -197,11 +203,17 @@ static int create_impl(irlosc_ctx* c) {
             HIPCHK(nullptr, hipMemsetAsync(c->dwc_set[k2], 0, 64 * sizeof(int32_t), c->stream));
         }
     }
-#ifndef IRLOSC_NO_GROUP_KERNEL
     if (c->kernel == IRLOSC_KERNEL_GROUP)
         for (int t = 0; t < irlosc_ctx::NTABLES; ++t)
             HIPCHK(nullptr, hipMalloc(&c->dtable[t], irlosc_ctx::TRAIN_MAX * sizeof(TrainStep)));
-#endif
+    if (c->kernel == IRLOSC_KERNEL_ROW16) {
+        constexpr size_t ZB = 64 * 1024;
+        HIPCHK(nullptr, hipMalloc(&c->dzeros, ZB));
+        HIPCHK(nullptr, hipMemsetAsync(c->dzeros, 0, ZB, c->stream));
+        HIPCHK(nullptr, hipMalloc((void**)&c->dr16_list, B * sizeof(int32_t)));
+        HIPCHK(nullptr, hipMalloc((void**)&c->dr16_count, 2 * sizeof(int32_t)));
+        HIPCHK(nullptr, hipMemsetAsync(c->dr16_count, 0, 2 * sizeof(int32_t), c->stream));
+    }
     c->du = c->du_set[0];
     c->dflags = c->dflags_set[0];
     HIPCHK(nullptr, hipMalloc(&c->dgains, B * nd * IRLOSC_GAIN_WORDS * e));
@@ -213,12 +225,10 @@ static int create_impl(irlosc_ctx* c) {
 }
 
 static bool group_supported(const irlosc_ctx* c) {
-#ifndef IRLOSC_NO_GROUP_KERNEL
     return group_kernel_supports(c->cfg.dtype, c->cfg.n, c->k, c->cfg.ndev);
-#else
-    (void)c;
-    return false;
-#endif
+}
+static bool row16_supported(const irlosc_ctx* c) {
+    return row16_kernel_supports(c->cfg.dtype, c->cfg.n, c->k, c->cfg.ndev);
 }
 
 extern "C" int irlosc_create(const irlosc_cfg* cfg, irlosc_ctx** out) {
@@ -241,10 +251,19 @@ extern "C" int irlosc_create(const irlosc_cfg* cfg, irlosc_ctx** out) {
         delete c;
         return fail(nullptr, IRLOSC_ERR_ARG, "group kernel not available for n=%d k=%d ndev=%d", cfg->n, k, cfg->ndev);
     }
-    c->kernel = (cfg->kernel == IRLOSC_KERNEL_GENERIC || !group_supported(c)) ? IRLOSC_KERNEL_GENERIC
-                                                                              : IRLOSC_KERNEL_GROUP;
+    if (cfg->kernel == IRLOSC_KERNEL_ROW16 && !row16_supported(c)) {
+        delete c;
+        return fail(nullptr, IRLOSC_ERR_ARG, "row16 kernel not available for dtype=%d n=%d k=%d ndev=%d", cfg->dtype, cfg->n, k, cfg->ndev);
+    }
+    // AUTO: the throughput kernel of the dtype where the shape has one (fp32: group, fp64: row16), else generic
+    c->kernel = IRLOSC_KERNEL_GENERIC;
+    if (cfg->kernel != IRLOSC_KERNEL_GENERIC) {
+        if (cfg->kernel != IRLOSC_KERNEL_ROW16 && group_supported(c)) c->kernel = IRLOSC_KERNEL_GROUP;
+        else if (cfg->kernel != IRLOSC_KERNEL_GROUP && row16_supported(c)) c->kernel = IRLOSC_KERNEL_ROW16;
+    }
     char nm[96];
-    snprintf(nm, sizeof nm, "%s_%s_n%d_k%d", c->kernel == IRLOSC_KERNEL_GROUP ? "osc_group" : "osc_generic",
+    snprintf(nm, sizeof nm, "%s_%s_n%d_k%d",
+             c->kernel == IRLOSC_KERNEL_GROUP ? "osc_group" : c->kernel == IRLOSC_KERNEL_ROW16 ? "osc_row16" : "osc_generic",
              cfg->dtype == IRLOSC_F64 ? "f64" : "f32", cfg->n, k);
     c->kernel_name = nm;
     rc = create_impl(c);
@@ -473,7 +492,6 @@ static void fill_params(const irlosc_ctx* c, KParams<T>& p, int B, const void* M
     }
 }
 
-#ifndef IRLOSC_NO_GROUP_KERNEL
 // One fused launch for a train of `n` steps (ps[i] = parameters with the outputs of set sets[i]); the stage 2 of
 // the steps in c->pending rides in front of them.  n == 0: riders only (a flush).  With keep_pending the new steps'
 // stage 2 is left for the next train; otherwise it is flushed right away.
@@ -558,9 +576,6 @@ static int flush_pending(irlosc_ctx* c, hipStream_t st) {
     c->tev_begin = b; c->tev_end = e;
     return rc;
 }
-#else
-static int flush_pending(irlosc_ctx*, hipStream_t) { return IRLOSC_OK; }
-#endif
 
 template <typename T>
 static int launch_t(irlosc_ctx* c, int B, const void* M, const void* J, const void* dq, const void* bias,
@@ -568,7 +583,6 @@ static int launch_t(irlosc_ctx* c, int B, const void* M, const void* J, const vo
                     uint32_t* flags, hipStream_t st) {
     KParams<T> p;
     fill_params<T>(c, p, B, M, J, dq, bias, ee, tgt, tvel, wrench, u, flags);
-#ifndef IRLOSC_NO_GROUP_KERNEL
     if (c->kernel == IRLOSC_KERNEL_GROUP) {
         if constexpr (sizeof(T) == 4) {
             int rc = flush_pending(c, st);
@@ -579,7 +593,24 @@ static int launch_t(irlosc_ctx* c, int B, const void* M, const void* J, const vo
             return fail(c, IRLOSC_ERR_ARG, "no fp64 group kernel");
         }
     }
-#endif
+    if (c->kernel == IRLOSC_KERNEL_ROW16) {
+        if constexpr (sizeof(T) == 8) {
+            // all instances on the row16 kernel; those it cannot certify as the reference's inverse branch are
+            // recomputed by the generic kernel (Jacobi) from the worklist it leaves behind
+            int32_t* cnt = c->dr16_count + c->r16_parity;
+            int32_t* nxt = c->dr16_count + (c->r16_parity ^ 1);
+            c->r16_parity ^= 1;
+            const Row16Extra x{c->dzeros, c->dr16_list, cnt};
+            int rc = launch_row16<T>(p, x, st);
+            if (rc) return fail(c, IRLOSC_ERR_HIP, "row16 kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+            hipLaunchKernelGGL(osc_generic_worklist_kernel<T>, dim3(std::min(B, 2048)), dim3(64),
+                               generic_smem_bytes<T>(p.n, p.k, p.ndev), st, p, c->dr16_list, cnt, nxt);
+            HIPCHK(c, hipGetLastError());
+            return IRLOSC_OK;
+        } else {
+            return fail(c, IRLOSC_ERR_ARG, "no fp32 row16 kernel");
+        }
+    }
     size_t smem = generic_smem_bytes<T>(p.n, p.k, p.ndev);
     hipLaunchKernelGGL(osc_generic_kernel<T>, dim3(B), dim3(64), smem, st, p);
     HIPCHK(c, hipGetLastError());
@@ -663,7 +694,6 @@ static void slot_params(const irlosc_ctx* c, KParams<float>& p, int slot, int B,
                        c->du_set[set], c->dflags_set[set]);
 }
 
-#ifndef IRLOSC_NO_GROUP_KERNEL
 // `iters` steps on the group path, chained `train` per launch; events (if any) go around launch number `timed`.
 static int resident_trains(irlosc_ctx* c, int first_slot, int B, int iters, const std::vector<hipEvent_t>* evs, int skip) {
     int done = 0, launch_no = 0;
@@ -694,7 +724,6 @@ static int resident_trains(irlosc_ctx* c, int first_slot, int B, int iters, cons
     c->dflags = c->dflags_set[c->cur];
     return flush_pending(c, c->stream);
 }
-#endif
 
 extern "C" int irlosc_step_resident(irlosc_ctx* c, int32_t first_slot, int32_t B, int32_t iters, float* ms_total,
                                     float* ms_kernel_avg) {
@@ -705,16 +734,13 @@ extern "C" int irlosc_step_resident(irlosc_ctx* c, int32_t first_slot, int32_t B
     if (c->gains_nb == 0) return fail(c, IRLOSC_ERR_STATE, "irlosc_set_gains has not been called");
     HIPCHK(c, hipSetDevice(c->cfg.hip_device));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-#ifndef IRLOSC_NO_GROUP_KERNEL
     if (c->kernel == IRLOSC_KERNEL_GROUP && B > 0) {
         // Group path: up to `train` consecutive steps are chained in one launch (different resident slots, different
         // output sets), and their stage 2 rides in the next launch; the last train is flushed before returning.
         rc = flush_pending(c, c->stream);
         if (!rc) rc = resident_trains(c, first_slot, B, iters, nullptr, 0);
         if (rc) return rc;
-    } else
-#endif
-    {
+    } else {
         for (int i = 0; i < iters; ++i) {
             rc = launch_slot(c, (first_slot + i) % c->cfg.n_slots, B);
             if (rc) return rc;
@@ -745,7 +771,6 @@ extern "C" int irlosc_time_dominant_kernel(irlosc_ctx* c, int32_t slot, int32_t 
         rc = irlosc_step_resident(c, slot, B, iters, &tot, ms_avg);
         return rc;
     }
-#ifndef IRLOSC_NO_GROUP_KERNEL
     // Group path: the same chained launches as irlosc_step_resident, with a HIP event pair around each dominant
     // launch (a train of irlosc_steps_per_launch() steps' stage 1, fused with the riding stage 2 of the previous
     // train) - this is the kernel a rocprofv3 kernel trace of the timed region shows, so the two averages are
@@ -769,7 +794,6 @@ extern "C" int irlosc_time_dominant_kernel(irlosc_ctx* c, int32_t slot, int32_t 
         tot += ms;
     }
     *ms_avg = (float)(tot / launches);
-#endif
     return IRLOSC_OK;
 }
 

@@ -559,11 +559,6 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const TrainStep* _
         __builtin_amdgcn_sched_barrier(0);
     }
 
-#if defined(IRLOSC_CUT) && IRLOSC_CUT == 2
-    { v2f h = v2f{0.f,0.f};
-      for (int r = 0; r < K; ++r) for (int pp = 0; pp < P; ++pp) h += Y[r].p[pp];
-      p.u[(size_t)b * N + g] = h.x + h.y; return; }
-#endif
     IRLOSC_TS(3);
     // ---------------- task-space signal, part 2: rows of device g into the exchange area --------------------------
     float* wls = vec + VEC_W + q * K;

@@ -1,0 +1,625 @@
+// fp64 throughput kernel: SIXTEEN LANES (one DPP row) PER ROBOT INSTANCE, four instances per wavefront.
+//
+// The reference computes in float64 end to end (osc.py:49-55,66-67) and north_star's tolerance is 1e-5 relative,
+// which the task-space solve only meets in fp64 once cond(J M^-1 J^T) reaches 1e3..1e6.  gfx950 issues v_fma_f64
+// at the v_pk_fma_f32 instruction rate, and its only 64-bit DPP mode, row_newbcast (lane N of each 16-lane row to
+// the whole row), can be FUSED into v_fmac_f64: "acc += bcast_lane_N(x) * y" is one instruction.  The whole
+// algorithm is laid out so that every inner product runs on that instruction and nothing is ever reduced across lanes:
+//
+//   lane l of a row owns joint rows i = l (slot 0) and i = 16 + l (slot 1, real for l < n - 16) of M and L, and, in a
+//   third register set, the right-hand side r = l of the substitution (the "T slot": T[c] = Y[r][c], Y = J L^-T).
+//
+//   main loop, column j = 0..n-1 (left-looking Cholesky of M with the substitution fused in, osc.py:49-50):
+//     m_s  = M[j][i_s]                      the coalesced row j of M IS the column (M symmetric): plain global loads
+//     mdq_s += bcast(dq_j) * m_s            uv_all = M dq (osc.py:151)
+//     dx    += bcast(dq_j) * J[r][j]        dx = J dq (osc.py:150)
+//     for c < j:  m_s -= bcast(L[j][c]) * L[i_s][c];   t -= bcast(L[j][c]) * T[c]     (one DPP source, three uses)
+//     d = bcast(m at row j); L[i][j] = m_i / sqrt(d); T[j] = t / sqrt(d)
+//   A[r][c] = sum_i bcast(T[i] of lane r) * T[i]   -> lane c holds column c (= row c) of A = J M^-1 J^T, no reduction
+//   k x k:  L~ D L~^T of A with column-per-lane storage, W = L~^-1, trace(A^-1) for the condition certificate,
+//           t = A^-1 w by W and one back substitution, all on bcast-FMAs                          (osc.py:51-55)
+//   u_i  = u0_i + bias_i - kvn * mdq_i - sum_r bcast(t_r) * J[r][i]                               (osc.py:174-200)
+//
+// J is read once, coalesced, and parked in LDS (10 KB per wave): column j of it in the right-hand-side layout is one
+// conflict-free ds_read per iteration, and the rows come back in the joint layout for J^T t.  Nothing else uses LDS
+// beyond a 1 KB exchange area, there is no inter-wave communication and no ring: occupancy is bounded by registers.
+// Instances whose k x k solve is not certifiably the reference's inverse branch are appended to a worklist and
+// recomputed by the generic kernel (cyclic Jacobi), exactly like the tail of the fp32 group path.
+//
+// Hazard discipline: the hardware does NOT interlock "VALU writes a VGPR -> DPP reads it" (2 wait states; measured:
+// tools/probe/dpp64.hip) and the compiler cannot see into inline asm, so (1) every DPP instruction is volatile asm
+// (kept in program order), (2) a DPP source is either produced two or more instructions earlier by this file's own
+// asm or sits behind a sched_barrier, and (3) the first DPP instruction after a sched_barrier carries "s_nop 1".
+#pragma once
+#include <type_traits>
+#include <utility>
+
+#include "osc_common.hpp"
+
+namespace irlosc {
+namespace r16 {
+
+template <int B_, int E_, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B_ < E_) {
+        f(std::integral_constant<int, B_>{});
+        static_for<B_ + 1, E_>(f);
+    }
+}
+template <int B_, int E_, typename F>      // E_-1 down to B_
+__device__ __forceinline__ void static_for_down(F&& f) {
+    if constexpr (B_ < E_) {
+        f(std::integral_constant<int, E_ - 1>{});
+        static_for_down<B_, E_ - 1>(f);
+    }
+}
+
+// acc += bcast(src, lane LANE of the row) * mul
+template <int LANE>
+__device__ __forceinline__ void fmac_bc(double& acc, const double src, const double mul) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(LANE));
+}
+template <int LANE>
+__device__ __forceinline__ void fmac_bc_nop(double& acc, const double src, const double mul) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(LANE));
+}
+// acc -= bcast(src, LANE) * mul
+template <int LANE>
+__device__ __forceinline__ void fmac_bc_n(double& acc, const double src, const double mul) {
+    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(LANE));
+}
+template <int LANE>
+__device__ __forceinline__ void fmac_bc_n_nop(double& acc, const double src, const double mul) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(LANE));
+}
+// bcast(src, LANE); safe right behind the instruction that wrote src
+template <int LANE>
+__device__ __forceinline__ double bc_nop(const double src) {
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "n"(LANE));
+    return r;
+}
+
+// 32-bit DPP move (the compiler inserts the wait states for builtins)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov64(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// sum over the 16 lanes of a row, result in every lane: quad butterflies, then the mirrored half, then the mirrored row
+__device__ __forceinline__ double row_sum(double v) {
+    v += dpp_mov64<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_mov64<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_mov64<0x141>(v);    // row_half_mirror
+    v += dpp_mov64<0x140>(v);    // row_mirror
+    return v;
+}
+__device__ __forceinline__ double quad_bcast(double v, int g) {
+    switch (g & 3) {
+        case 0: return dpp_mov64<0x00>(v);
+        case 1: return dpp_mov64<0x55>(v);
+        case 2: return dpp_mov64<0xAA>(v);
+        default: return dpp_mov64<0xFF>(v);
+    }
+}
+
+// 1/sqrt(d) and 1/d to fp64 accuracy from the 2^-24 hardware seeds (one cubic / quadratic correction; measured
+// max relative error 2.6e-16 and 0 against 1/sqrt and 1/ of the host, tools/probe/dpp64.hip)
+__device__ __forceinline__ double rsq_refined(double d) {
+    const double q = __builtin_amdgcn_rsq(d);
+    const double e = fma(-(d * q), q, 1.0);
+    return fma(q * e, fma(0.375, e, 0.5), q);
+}
+__device__ __forceinline__ double rcp_refined(double d) {
+    const double r = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, r, 1.0);
+    return fma(r * e, 1.0 + e, r);
+}
+
+// ---- k x k building blocks: lane c of a row holds column c (= row c) of a symmetric K x K matrix in K registers -----
+
+// In-place L~ D L~^T of A + sigma I.  Out: F[j] in lane c = L~[c][j] for c > j, else 0 (row c of L~); G[i] in lane c =
+// L~[i][c] for i > c, else 0 (column c of L~); invd_own = 1 / d_c in lane c; pd = all pivots positive; det = prod d.
+template <int K>
+__device__ __forceinline__ void ldl16(double (&A)[K], const int l, const double sigma, double (&F)[K], double (&G)[K],
+                                      double& invd_own, bool& pd, double& det) {
+    pd = true;
+    det = 1.0;
+    invd_own = 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, K>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        double d = bc_nop<j>(A[j]) + sigma;
+        const bool npd = !(d > 0.0);
+        pd = pd && !npd;
+        const double dfix = (d == d && d != 0.0) ? fabs(d) : 1.0;
+        d = npd ? dfix : d;
+        det *= d;
+        const double invd = rcp_refined(d);
+        const double f = A[j] * invd;
+        F[j] = (l > j) ? f : 0.0;
+        invd_own = (l == j) ? invd : invd_own;
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<j + 1, K>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i == j + 1) fmac_bc_n_nop<j>(A[i], A[i], F[j]);
+            else fmac_bc_n<j>(A[i], A[i], F[j]);
+        });
+    });
+#pragma unroll
+    for (int i = 0; i < K; ++i) G[i] = (l < i) ? A[i] * invd_own : 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// z <- (L~ D L~^T)^-1 z, one component per lane: two chains of dependent broadcast-FMAs
+template <int K>
+__device__ __forceinline__ void solve16(double& z, const double (&F)[K], const double (&G)[K], const double invd_own) {
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, K - 1>([&](auto jc) { fmac_bc_n_nop<decltype(jc)::value>(z, z, F[decltype(jc)::value]); });
+    z *= invd_own;
+    __builtin_amdgcn_sched_barrier(0);
+    static_for_down<1, K>([&](auto ic) { fmac_bc_n_nop<decltype(ic)::value>(z, z, G[decltype(ic)::value]); });
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// y = A x
+template <int K>
+__device__ __forceinline__ double matvec16(const double x, const double (&Ac)[K]) {
+    double y = 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, K>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        if constexpr (r == 0) fmac_bc_nop<r>(y, x, Ac[r]);
+        else fmac_bc<r>(y, x, Ac[r]);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    return y;
+}
+
+// t = pinv(A, rcond 1e-5) w for the rows of the wave with `flagged` set (osc.py:55; A symmetric positive semi-definite):
+//   lambda_max by power iteration (Rayleigh quotient; iterated further only where a candidate sits within 2 % of the cut),
+//   the eigenpairs under 1e-5 lambda_max one at a time by deflated inverse iteration through the factorisation the
+//   caller already has (A + 2^-40 ||A||_F I is factored here instead where that one broke down: exactly singular J),
+//   t = P A^-1 P w with P the projector off those eigenvectors.  More than three of them: give up (-> Jacobi).
+// Every quantity is uniform over the 16 lanes of an instance and frozen at the instance's own convergence, so a
+// result never depends on the other instances of the wave (sharding a batch differently changes no bit).
+template <int K>
+__device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], double (&G)[K], double& invd_own, const bool pdA,
+                                        const double nA2, const double w, const int l, const bool flagged, double& t,
+                                        uint32_t& fl, bool& giveup) {
+    const double hi = sqrt(nA2);
+    double sigma = 0.0;
+    giveup = flagged && !(hi > 0.0 && t_finite(hi));
+    if (__any(flagged && !pdA)) {
+        double A2[K], F2[K], G2[K], invd2, det2;
+        bool pd2;
+#pragma unroll
+        for (int r = 0; r < K; ++r) A2[r] = Ac[r];
+        const double sg = hi * 0x1p-40;
+        ldl16<K>(A2, l, sg, F2, G2, invd2, pd2, det2);
+        const bool use = flagged && !pdA;
+#pragma unroll
+        for (int r = 0; r < K; ++r) { F[r] = use ? F2[r] : F[r]; G[r] = use ? G2[r] : G[r]; }
+        invd_own = use ? invd2 : invd_own;
+        sigma = use ? sg : 0.0;
+        giveup = giveup || (use && !pd2);
+    }
+    // lambda_max
+    const double sc = rcp_refined(hi > 0.0 ? hi : 1.0);
+    double xp = l < K ? 0.2 + 0.05 * (double)((l * 7) % 5) : 0.0;
+    for (int it = 0; it < 24; ++it) xp = matvec16<K>(xp, Ac) * sc;
+    auto rayleigh = [&](double& x) {
+        const double n2 = row_sum(x * x);
+        x *= rsq_refined(n2 > 0.0 ? n2 : 1.0);
+        const double y = matvec16<K>(x, Ac);
+        const double lm = row_sum(x * y);
+        return (lm > 0.0 && lm <= hi * 1.0000001) ? lm : hi;
+    };
+    double lmax = rayleigh(xp);
+    double cutoff = 1e-5 * lmax;
+    // sub-threshold eigenpairs
+    double v[3] = {0.0, 0.0, 0.0};
+    int m = 0;
+    bool active = flagged && !giveup;
+#pragma unroll
+    for (int slot = 0; slot < 4; ++slot) {
+        if (!__any(active)) break;
+        double x = l < K ? 0.3 + 0.1 * (double)(((l + 3 * slot) * 5) % 7) - 0.05 * (double)slot : 0.0;
+        double lam = 0.0, lam_prev = -1.0;
+        bool fin = !active;
+        for (int it = 0; it < 16; ++it) {
+            double xn = x;
+#pragma unroll
+            for (int s0 = 0; s0 < 3; ++s0) {
+                if (s0 < slot) xn = fma(-row_sum(v[s0] * xn), v[s0], xn);     // unused v are exact zeros
+            }
+            solve16<K>(xn, F, G, invd_own);
+            const double n2 = row_sum(xn * xn);
+            const double rn = rsq_refined(n2 > 0.0 ? n2 : 1.0);
+            const double lamn = rn - sigma;                 // 1 / ||(A + sigma)^-1 x|| -> lambda + sigma (from above)
+            const bool settled = fabs(lamn - lam_prev) <= 1e-11 * fabs(lamn) || lamn > 4.0 * cutoff;
+            x = fin ? x : xn * rn;
+            lam = fin ? lam : lamn;
+            lam_prev = lam;
+            fin = fin || (it >= 3 && settled);
+            if (!__any(!fin)) break;
+        }
+        // a candidate within 2 % of the cut: sharpen lambda_max before deciding (rare; only those instances move)
+        const bool amb = active && fabs(lam - cutoff) < 0.02 * cutoff;
+        if (__any(amb)) {
+            for (int it = 0; it < 200; ++it) xp = matvec16<K>(xp, Ac) * sc;
+            double xq2 = xp;
+            const double lm2 = rayleigh(xq2);
+            lmax = (amb && lm2 > lmax) ? lm2 : lmax;
+            cutoff = 1e-5 * lmax;
+        }
+        const bool below = active && (lam <= cutoff);
+        if (slot < 3) {
+            v[slot] = below ? x : 0.0;
+            m += below ? 1 : 0;
+        } else {
+            giveup = giveup || below;              // a 4th sub-threshold eigenvalue: not handled here
+        }
+        active = below;
+    }
+    // t = P (A + sigma)^-1 P w
+    double tt = w;
+#pragma unroll
+    for (int s0 = 0; s0 < 3; ++s0) tt = fma(-row_sum(v[s0] * tt), v[s0], tt);
+    solve16<K>(tt, F, G, invd_own);
+#pragma unroll
+    for (int s0 = 0; s0 < 3; ++s0) tt = fma(-row_sum(v[s0] * tt), v[s0], tt);
+    t = tt;
+    fl = m > 0 ? IRLOSC_FLAG_TRUNCATED : 0u;
+}
+
+}  // namespace r16
+
+// What the row16 kernel needs beyond KParams: a page of zeros (padding lanes load from it instead of being masked),
+// and the worklist of the instances handed to the generic kernel.
+struct Row16Extra {
+    const void* zeros;         // >= 32 * 32 * 8 bytes of zeros
+    int32_t* worklist;         // [B]
+    int32_t* workcount;        // counter of this step (zero on entry)
+};
+
+// TIN = storage type of the records (double, or float for the mixed path); arithmetic is double throughout.
+template <int K, int NDEV, typename TIN, int N>
+__global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, const Row16Extra x) {
+    using namespace r16;
+    static_assert(N > 16 && N <= 32 && K >= 1 && K <= 16 && NDEV >= 1 && NDEV <= 4, "shape");
+    constexpr int N1 = N - 16;                 // real rows in slot 1
+    constexpr int PF = 4;                      // rows of M in flight ahead of the column being eliminated
+    __shared__ double Jl[4 * (K + 1) * N + 16];   // [q][r][i]; row K of each instance is zeros (lanes >= K read it)
+    __shared__ double Wl[4][16];               // task vector, written by the device lanes
+    __shared__ double Dxl[4][16];              // dx for the target-velocity branch
+    __shared__ double Kvl[4][4];
+    __shared__ int Brl[4][4];
+
+    const int lane = threadIdx.x, q = lane >> 4, l = lane & 15;
+    const int b = blockIdx.x * 4 + q;
+    const bool live = b < p.B;
+    const int bc = live ? b : p.B - 1;
+    const bool v1 = l < N1;
+    const TIN* __restrict__ zeros = reinterpret_cast<const TIN*>(x.zeros);
+    const TIN* __restrict__ m0p = p.M + (size_t)bc * (N * N) + l;
+    const TIN* __restrict__ m1p = v1 ? p.M + (size_t)bc * (N * N) + 16 + l : zeros;
+    double* Jq = Jl + q * ((K + 1) * N);
+    uint32_t flags = 0;
+
+    // ---- prologue: first rows of M in flight, J (coalesced) into LDS, dq ------------------------------------------
+    TIN pm0[N], pm1[N];
+    static_for<0, PF>([&](auto jc) { constexpr int j = decltype(jc)::value; pm0[j] = m0p[j * N]; pm1[j] = m1p[j * N]; });
+    {
+        const TIN* __restrict__ Jb = p.J + (size_t)bc * (K * N);
+        TIN j0[K], j1[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) j0[r] = Jb[r * N + l];
+        const TIN* __restrict__ Jb1 = v1 ? Jb + 16 + l : zeros;
+#pragma unroll
+        for (int r = 0; r < K; ++r) j1[r] = Jb1[r * N];
+#pragma unroll
+        for (int r = 0; r < K; ++r) Jq[r * N + l] = (double)j0[r];
+        Jq[K * N + l] = 0.0;
+        if (v1) {
+#pragma unroll
+            for (int r = 0; r < K; ++r) Jq[r * N + 16 + l] = (double)j1[r];
+            Jq[K * N + 16 + l] = 0.0;
+        }
+        Wl[q][l] = 0.0;
+    }
+    const double dq0 = (double)p.dq[(size_t)bc * N + l];
+    const double dq1 = (double)(v1 ? p.dq + (size_t)bc * N + 16 + l : zeros)[0];
+    __syncthreads();
+
+    // ---- task-space signal, part 1 (osc.py:101-118,70-99,160-168): quad d of the row = device d -------------------
+    // Lane a of the quad evaluates ONE of the three Euler angles (the fp64 atan2 is the expensive part), the quad
+    // broadcasts them, every lane of the quad finishes the gains, lane 0 parks the controlled rows in LDS.
+    const double kvn = (p.cfgflags & IRLOSC_NULLSPACE) ? (double)p.null_kv[p.gains_per_instance ? bc : 0] : 0.0;
+    const bool has_tv = p.tvel != nullptr;
+    const bool has_wr = (p.cfgflags & IRLOSC_ADMITTANCE) && p.wrench != nullptr;
+    const int dv = l >> 2, ang_id = l & 3;
+    const int dd = dv < NDEV ? dv : NDEV - 1;
+    const DevMeta dm = p.dev[dd];
+    bool own_brB = false;
+    {
+        const TIN* __restrict__ eep = p.ee + ((size_t)bc * NDEV + dd) * 7;
+        const TIN* __restrict__ tgp = p.tgt + ((size_t)bc * NDEV + dd) * 7;
+        const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * NDEV * IRLOSC_GAIN_WORDS : 0) + dd * IRLOSC_GAIN_WORDS;
+        double ee[7], tg[7], g[IRLOSC_GAIN_WORDS];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { ee[i] = (double)eep[i]; tg[i] = (double)tgp[i]; }
+#pragma unroll
+        for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) g[i] = (double)gp[i];
+        double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (dm.calc & 1u) { e[0] = ee[0] - tg[0]; e[1] = ee[1] - tg[1]; e[2] = ee[2] - tg[2]; }
+        if (dm.calc & 2u) {
+            // transforms3d calls of osc.py:115-117, same formulas as task_error6 (osc_common.hpp)
+            const double tw = tg[3], tx = tg[4], ty = tg[5], tz = tg[6];
+            const double nrm = sqrt(tw * tw + tx * tx + ty * ty + tz * tz);
+            const double w1 = tw / nrm, x1 = tx / nrm, y1 = ty / nrm, z1 = tz / nrm;
+            const double w2 = ee[3], x2 = -ee[4], y2 = -ee[5], z2 = -ee[6];
+            const double rw = w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2;
+            const double rx = w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2;
+            const double ry = w1 * y2 + y1 * w2 + z1 * x2 - x1 * z2;
+            const double rz = w1 * z2 + z1 * w2 + x1 * y2 - y1 * x2;
+            const double w = rw, xq = -rx, yq = -ry, zq = -rz;
+            const double Nq = w * w + xq * xq + yq * yq + zq * zq;
+            double r00 = 1.0, r10 = 0.0, r20 = 0.0, r21 = 0.0, r22 = 1.0, r11 = 1.0, r12 = 0.0;
+            if (!(Nq < 2.220446049250313e-16)) {
+                const double s = 2.0 / Nq;
+                const double X = xq * s, Y = yq * s, Z = zq * s;
+                const double wX = w * X, wY = w * Y, wZ = w * Z;
+                const double xX = xq * X, xY = xq * Y, xZ = xq * Z;
+                const double yY = yq * Y, yZ = yq * Z, zZ = zq * Z;
+                r00 = 1.0 - (yY + zZ); r10 = xY + wZ; r20 = xZ - wY; r21 = yZ + wX;
+                r22 = 1.0 - (xX + yY); r11 = 1.0 - (xX + zZ); r12 = yZ - wX;
+            }
+            const double cy = sqrt(r00 * r00 + r10 * r10);
+            const bool gimbal = !(cy > 4.0 * 2.220446049250313e-16);
+            double ay = 0.0, ax = 1.0;             // atan2(0, 1) = 0: the idle lane and the gimbal-lock az
+            if (ang_id == 0) { ay = gimbal ? -r12 : r21; ax = gimbal ? r11 : r22; }
+            else if (ang_id == 1) { ay = -r20; ax = cy; }
+            else if (ang_id == 2 && !gimbal) { ay = r10; ax = r00; }
+            const double ang = atan2(ay, ax);
+            e[3] = quad_bcast(ang, 0);
+            e[4] = quad_bcast(ang, 1);
+            e[5] = quad_bcast(ang, 2);
+        }
+        apply_gains6<double>(g, e);
+        bool all_nonzero = has_tv;
+        if (has_tv) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) all_nonzero = all_nonzero && ((double)p.tvel[((size_t)bc * NDEV + dd) * 6 + i] != 0.0);
+        }
+        own_brB = all_nonzero && dv < NDEV;          // np.all(target_vel) == 0 quirk, osc.py:173
+        if (ang_id == 0 && dv < NDEV) {
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if (dm.dofmask & (1u << i)) { Wl[q][dm.row0 + cnt] = e[i]; ++cnt; }
+            Kvl[q][dv] = g[1];
+            Brl[q][dv] = all_nonzero ? 0 : 1;
+        }
+        if (own_brB) {
+            flags |= IRLOSC_FLAG_VEL_BRANCH_B;
+            if (dm.jidx0 + dm.rows > K) flags |= IRLOSC_FLAG_BAD_JIDX;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- main loop: Cholesky of M, Y = L^-1 J^T (as T), M dq, J dq ------------------------------------------------
+    double L0[15], L1[24], T[N];
+    double mdq0 = 0.0, mdq1 = 0.0, dx = 0.0;
+    const double* trow = Jq + (l < K ? l : K) * N;
+    static_for<0, N>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int sj = j >> 4, gj = j & 15;
+        if constexpr (j + PF < N) { pm0[j + PF] = m0p[(j + PF) * N]; pm1[j + PF] = m1p[(j + PF) * N]; }
+        double m0 = (double)pm0[j], m1 = (double)pm1[j];
+        double tj = trow[j];
+        const double dqs = sj ? dq1 : dq0;
+        __builtin_amdgcn_sched_barrier(0);
+        fmac_bc_nop<gj>(mdq0, dqs, m0);
+        fmac_bc<gj>(mdq1, dqs, m1);
+        fmac_bc<gj>(dx, dqs, tj);
+        static_for<0, j>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (j < 16) {
+                fmac_bc_n<gj>(m0, L0[c], L0[c]);
+                fmac_bc_n<gj>(m1, L0[c], L1[c]);
+                fmac_bc_n<gj>(tj, L0[c], T[c]);
+            } else {
+                fmac_bc_n<gj>(m1, L1[c], L1[c]);
+                fmac_bc_n<gj>(tj, L1[c], T[c]);
+            }
+        });
+        double d = bc_nop<gj>(sj ? m1 : m0);
+        flags |= !(d > 0.0) ? IRLOSC_FLAG_M_NOT_PD : 0u;      // also catches NaN
+        d = fmax(d, 1e-300);
+        const double dinv = rsq_refined(d);
+        if constexpr (j < 15) L0[j] = m0 * dinv;
+        if constexpr (j < 24) L1[j] = m1 * dinv;
+        T[j] = tj * dinv;
+        __builtin_amdgcn_sched_barrier(0);
+    });
+
+    // ---- A = Y^T Y: lane c ends up with A[r][c], r = 0..K-1 -------------------------------------------------------
+    double A[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) A[r] = 0.0;
+    static_for<0, N>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        static_for<0, K>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            if constexpr (i == 0 && r == 0) fmac_bc_nop<r>(A[r], T[i], T[i]);
+            else fmac_bc<r>(A[r], T[i], T[i]);
+        });
+    });
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- task-space signal, part 2: target-velocity branch B and the admittance wrench (osc.py:173-185) -----------
+    Dxl[q][l] = dx;
+    __syncthreads();
+    if ((own_brB || has_wr) && ang_id == 0 && dv < NDEV) {
+        const double kv = Kvl[q][dv];
+        const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * NDEV * IRLOSC_GAIN_WORDS : 0) + dd * IRLOSC_GAIN_WORDS;
+        int cnt = 0;
+        for (int i = 0; i < 6; ++i) {
+            if (dm.dofmask & (1u << i)) {
+                double v = Wl[q][dm.row0 + cnt];
+                if (own_brB) {
+                    const int row = dm.jidx0 + cnt;
+                    const double dxv = row < K ? Dxl[q][row] : 0.0;
+                    const double damp = i < 3 ? (double)gp[6 + i] : 1.0;
+                    v += kv * (dxv - (double)p.tvel[((size_t)bc * NDEV + dd) * 6 + i]) * damp;
+                }
+                if (has_wr) v += (double)p.wrench[((size_t)bc * NDEV + dd) * 6 + i];
+                Wl[q][dm.row0 + cnt] = v;
+                ++cnt;
+            }
+        }
+    }
+    __syncthreads();
+    // w = u_task_all [+ ext_f] - kvn * dx  (null-space term folded in: osc_generic.hpp header)
+    const double w = Wl[q][l] - kvn * dx;
+
+    // ---- k x k: A = L~ D L~^T, column c (= row c) of everything in lane c -------------------------------------------
+    double nA2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < K; ++r) nA2 = fma(A[r], A[r], nA2);
+    nA2 = row_sum(nA2);
+    double Ac[K];           // A itself, for the eigen path (the factorisation runs in place)
+#pragma unroll
+    for (int r = 0; r < K; ++r) Ac[r] = A[r];
+    double F[K], G[K];      // rows / columns of L~ (see ldl16)
+    double invd_own = 0.0;  // 1 / d_c in lane c
+    double detA = 1.0;
+    bool pdA = true;
+    ldl16<K>(A, l, 0.0, F, G, invd_own, pdA, detA);
+    // W = L~^-1, row c in lane c: X[m] = W[c][m]
+    double X[K];
+#pragma unroll
+    for (int m = 0; m < K; ++m) X[m] = (l == m) ? 1.0 : 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, K - 1>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        static_for<0, j + 1>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            if constexpr (j < 3 || m == 0) fmac_bc_n_nop<j>(X[m], X[m], F[j]);
+            else fmac_bc_n<j>(X[m], X[m], F[j]);
+        });
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    double trA = 0.0;
+#pragma unroll
+    for (int m = 0; m < K; ++m) trA = fma(X[m], X[m], trA);
+    trA = row_sum(trA * invd_own);                     // trace(A^-1) >= 1 / lambda_min
+    const bool small_det = !(fabs(detA) >= 1e-4);
+    const double cond_bound = sqrt(nA2) * trA;         // >= cond_2(A) for SPD A
+    const bool plain = pdA && t_finite(cond_bound) && (!small_det || cond_bound < 0.99e5);
+    flags |= small_det ? IRLOSC_FLAG_PINV_BRANCH : 0u;
+    flags |= plain ? 0u : IRLOSC_FLAG_EIGEN_PATH;
+    // t = A^-1 w = L~^-T D^-1 (W w)
+    double z = 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, K>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        if constexpr (m == 0) fmac_bc_nop<m>(z, w, X[m]);
+        else fmac_bc<m>(z, w, X[m]);
+    });
+    double t = z * invd_own;
+    __builtin_amdgcn_sched_barrier(0);
+    static_for_down<1, K>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        fmac_bc_n_nop<i>(t, t, G[i]);
+    });
+    // Instances that are not certifiably on the reference's inverse branch: truncated pseudo-inverse (osc.py:55).
+    // Wave-uniform branch: the whole wave runs it (DPP sources must be active lanes), the others keep their t.
+    bool giveup = false;
+    if (__any(!plain)) {
+        double t2 = 0.0;
+        uint32_t f2 = 0;
+        eigen16<K>(Ac, F, G, invd_own, pdA, nA2, w, l, !plain, t2, f2, giveup);
+        t = plain ? t : t2;
+        flags |= plain ? 0u : f2;
+    }
+
+    // ---- joint torques of the own rows: u = u0 + bias - kvn * Mdq - J^T t (osc.py:174,184-200) --------------------
+    double jt0 = 0.0, jt1 = 0.0;
+    {
+        double jr0[K], jr1[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) { jr0[r] = Jq[r * N + l]; jr1[r] = Jq[r * N + 16 + l]; }   // padding lanes: junk, never stored
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, K>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            if constexpr (r == 0) fmac_bc_nop<r>(jt0, t, jr0[r]);
+            else fmac_bc<r>(jt0, t, jr0[r]);
+            fmac_bc<r>(jt1, t, jr1[r]);
+        });
+    }
+    double u0 = 0.0, u1 = 0.0;
+#pragma unroll
+    for (int d2 = 0; d2 < NDEV; ++d2) {       // branch A damping, osc.py:174 (assignment, device order)
+        const bool brA = Brl[q][d2] != 0;
+        const double kvd = Kvl[q][d2];
+        const uint32_t jm = p.dev[d2].joint_mask;
+        if (brA && ((jm >> l) & 1u)) u0 = -kvd * mdq0;
+        if (brA && ((jm >> ((16 + l) & 31)) & 1u)) u1 = -kvd * mdq1;
+    }
+    u0 -= jt0;
+    u1 -= jt1;
+    if (p.cfgflags & IRLOSC_USE_G) {
+        u0 += (double)p.bias[(size_t)bc * N + l];
+        u1 += (double)(v1 ? p.bias + (size_t)bc * N + 16 + l : zeros)[0];
+    }
+    u0 -= kvn * mdq0;
+    u1 -= kvn * mdq1;
+    const bool bad = !t_finite(u0) || (v1 && !t_finite(u1));
+    flags |= bad ? IRLOSC_FLAG_NONFINITE : 0u;
+    // flags of the instance = OR over its 16 lanes
+#pragma unroll
+    for (int bit = 0; bit < 7; ++bit) {
+        const unsigned long long m = __ballot((flags >> bit) & 1u);
+        if ((m >> (q * 16)) & 0xffffull) flags |= 1u << bit;
+    }
+    if (live) {
+        p.u[(size_t)b * N + l] = (TIN)u0;
+        if (v1) p.u[(size_t)b * N + 16 + l] = (TIN)u1;
+        if (l == 0) {
+            p.flags[b] = flags;
+            if (giveup) x.worklist[atomicAdd(x.workcount, 1)] = b;
+        }
+    }
+}
+
+// The generic kernel over a worklist: instance ids list[0..*count); zeroes *reset for the step after.
+template <typename T>
+__global__ __launch_bounds__(64) void osc_generic_worklist_kernel(const KParams<T> p, const int32_t* __restrict__ list,
+                                                                   const int32_t* __restrict__ count, int32_t* __restrict__ reset) {
+    extern __shared__ __align__(16) unsigned char smem_raw_w[];
+    T* smem = reinterpret_cast<T*>(smem_raw_w);
+    const int n = *count;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && reset) *reset = 0;
+    for (int it = blockIdx.x; it < n; it += gridDim.x) generic_instance<T>(p, list[it], smem);
+}
+
+inline bool row16_kernel_supports(int dtype, int n, int k, int ndev) {
+    return dtype == IRLOSC_F64 && n == 25 && ((k == 13 && ndev == 3) || (k == 12 && ndev == 2) || (k == 7 && ndev == 3));
+}
+
+template <typename TIN>
+inline int launch_row16(const KParams<TIN>& p, const Row16Extra& x, hipStream_t st) {
+    if (p.B <= 0) return 0;
+    const dim3 grid((p.B + 3) / 4);
+    if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25>), grid, dim3(64), 0, st, p, x);
+    else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<12, 2, TIN, 25>), grid, dim3(64), 0, st, p, x);
+    else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<7, 3, TIN, 25>), grid, dim3(64), 0, st, p, x);
+    else return (int)hipErrorNotSupported;
+    return (int)hipGetLastError();
+}
+
+}  // namespace irlosc
