@@ -218,8 +218,8 @@ static int create_impl(irlosc_ctx* c) {
     c->dflags = c->dflags_set[0];
     HIPCHK(nullptr, hipMalloc(&c->dgains, B * nd * IRLOSC_GAIN_WORDS * e));
     HIPCHK(nullptr, hipMalloc(&c->dnullkv, B * e));
-    if (c->kernel == IRLOSC_KERNEL_GROUP && getenv("IRLOSC_PHASE_TIMING"))
-        HIPCHK(nullptr, hipMalloc((void**)&c->ddbg, (B / 16 + 1) * 10 * sizeof(unsigned long long)));
+    if (c->kernel != IRLOSC_KERNEL_GENERIC && getenv("IRLOSC_PHASE_TIMING"))     // debug aid: cycles per kernel phase
+        HIPCHK(nullptr, hipMalloc((void**)&c->ddbg, (B / 4 + 1) * 10 * sizeof(unsigned long long)));
     HIPCHK(nullptr, hipStreamSynchronize(c->stream));
     return IRLOSC_OK;
 }
@@ -255,16 +255,19 @@ extern "C" int irlosc_create(const irlosc_cfg* cfg, irlosc_ctx** out) {
         delete c;
         return fail(nullptr, IRLOSC_ERR_ARG, "row16 kernel not available for dtype=%d n=%d k=%d ndev=%d", cfg->dtype, cfg->n, k, cfg->ndev);
     }
-    // AUTO: the throughput kernel of the dtype where the shape has one (fp32: group, fp64: row16), else generic
+    // AUTO: the throughput kernel of the dtype where the shape has one (fp32 records: group kernel, fp32 arithmetic;
+    // fp64 records: row16), else generic.  IRLOSC_KERNEL_ROW16 on fp32 records = the mixed path (fp64 arithmetic).
     c->kernel = IRLOSC_KERNEL_GENERIC;
-    if (cfg->kernel != IRLOSC_KERNEL_GENERIC) {
-        if (cfg->kernel != IRLOSC_KERNEL_ROW16 && group_supported(c)) c->kernel = IRLOSC_KERNEL_GROUP;
-        else if (cfg->kernel != IRLOSC_KERNEL_GROUP && row16_supported(c)) c->kernel = IRLOSC_KERNEL_ROW16;
+    if (cfg->kernel == IRLOSC_KERNEL_ROW16) c->kernel = IRLOSC_KERNEL_ROW16;
+    else if (cfg->kernel != IRLOSC_KERNEL_GENERIC) {
+        if (group_supported(c)) c->kernel = IRLOSC_KERNEL_GROUP;
+        else if (cfg->kernel == IRLOSC_KERNEL_AUTO && cfg->dtype == IRLOSC_F64 && row16_supported(c)) c->kernel = IRLOSC_KERNEL_ROW16;
     }
     char nm[96];
+    const bool mixed = c->kernel == IRLOSC_KERNEL_ROW16 && cfg->dtype == IRLOSC_F32;
     snprintf(nm, sizeof nm, "%s_%s_n%d_k%d",
              c->kernel == IRLOSC_KERNEL_GROUP ? "osc_group" : c->kernel == IRLOSC_KERNEL_ROW16 ? "osc_row16" : "osc_generic",
-             cfg->dtype == IRLOSC_F64 ? "f64" : "f32", cfg->n, k);
+             mixed ? "f32in_f64" : cfg->dtype == IRLOSC_F64 ? "f64" : "f32", cfg->n, k);
     c->kernel_name = nm;
     rc = create_impl(c);
     if (rc) {
@@ -594,22 +597,19 @@ static int launch_t(irlosc_ctx* c, int B, const void* M, const void* J, const vo
         }
     }
     if (c->kernel == IRLOSC_KERNEL_ROW16) {
-        if constexpr (sizeof(T) == 8) {
-            // all instances on the row16 kernel; those it cannot certify as the reference's inverse branch are
-            // recomputed by the generic kernel (Jacobi) from the worklist it leaves behind
-            int32_t* cnt = c->dr16_count + c->r16_parity;
-            int32_t* nxt = c->dr16_count + (c->r16_parity ^ 1);
-            c->r16_parity ^= 1;
-            const Row16Extra x{c->dzeros, c->dr16_list, cnt};
-            int rc = launch_row16<T>(p, x, st);
-            if (rc) return fail(c, IRLOSC_ERR_HIP, "row16 kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-            hipLaunchKernelGGL(osc_generic_worklist_kernel<T>, dim3(std::min(B, 2048)), dim3(64),
-                               generic_smem_bytes<T>(p.n, p.k, p.ndev), st, p, c->dr16_list, cnt, nxt);
-            HIPCHK(c, hipGetLastError());
-            return IRLOSC_OK;
-        } else {
-            return fail(c, IRLOSC_ERR_ARG, "no fp32 row16 kernel");
-        }
+        // fp64 arithmetic whatever the storage type T of the records.  All instances on the row16 kernel; the few it
+        // gives up on (more than three eigenvalues under the pinv cut, degenerate A) are recomputed by the generic
+        // kernel (Jacobi, fp64 arithmetic) from the worklist it leaves behind.
+        int32_t* cnt = c->dr16_count + c->r16_parity;
+        int32_t* nxt = c->dr16_count + (c->r16_parity ^ 1);
+        c->r16_parity ^= 1;
+        const Row16Extra x{c->dzeros, c->dr16_list, cnt};
+        int rc = launch_row16<T>(p, x, st);
+        if (rc) return fail(c, IRLOSC_ERR_HIP, "row16 kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        hipLaunchKernelGGL((osc_generic_worklist_kernel<double, T>), dim3(std::min(B, 256)), dim3(64),
+                           generic_smem_bytes<double>(p.n, p.k, p.ndev), st, p, c->dr16_list, cnt, nxt);
+        HIPCHK(c, hipGetLastError());
+        return IRLOSC_OK;
     }
     size_t smem = generic_smem_bytes<T>(p.n, p.k, p.ndev);
     hipLaunchKernelGGL(osc_generic_kernel<T>, dim3(B), dim3(64), smem, st, p);
@@ -641,11 +641,14 @@ extern "C" int irlosc_download(irlosc_ctx* c, int32_t B, void* u_host, uint32_t*
     if (u_host && B) HIPCHK(c, hipMemcpyAsync(u_host, c->du, (size_t)B * c->cfg.n * c->esz, hipMemcpyDeviceToHost, c->stream));
     if (flags_host && B) HIPCHK(c, hipMemcpyAsync(flags_host, c->dflags, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->ddbg && B >= 16) {   // debug: mean cycles per stage-1 phase over all waves
-        const int tiles = B / 16;
+    if (c->ddbg && B >= 16) {   // debug: mean cycles per phase over all waves
+        const bool r16 = c->kernel == IRLOSC_KERNEL_ROW16;
+        const int tiles = r16 ? B / 4 : B / 16;
         std::vector<unsigned long long> h((size_t)tiles * 10);
         HIPCHK(c, hipMemcpy(h.data(), c->ddbg, h.size() * 8, hipMemcpyDeviceToHost));
-        static const char* nm[7] = {"vec-wait", "M-stream+Cholesky", "J+fwd-subst", "task-error", "A=YtY", "kxk", "torques+store"};
+        static const char* nm_g[7] = {"vec-wait", "M-stream+Cholesky", "J+fwd-subst", "task-error", "A=YtY", "kxk", "torques+store"};
+        static const char* nm_r[7] = {"loads+task-error", "J->LDS", "main-loop", "A=YtY", "kxk", "eigen", "torques+store"};
+        const char* const* nm = r16 ? nm_r : nm_g;
         double acc[7] = {0}, rt = 0;
         unsigned long long rmin = ~0ull, rmax = 0;
         for (int t = 0; t < tiles; ++t) {
@@ -655,7 +658,7 @@ extern "C" int irlosc_download(irlosc_ctx* c, int32_t B, void* u_host, uint32_t*
             rmin = std::min(rmin, r0);
             rmax = std::max(rmax, h[(size_t)t * 10 + 9]);
         }
-        {   // where do blocks land?  XCC of tile t vs t % 8, and vs the XCC of tile t + 2048; start order of the second round
+        if (!r16) {   // where do blocks land?  XCC of tile t vs t % 8, and vs the XCC of tile t + 2048; start order of the second round
             int same_mod = 0, same_next = 0, cnt_next = 0;
             for (int t = 0; t < tiles; ++t) {
                 const int x = (int)(h[(size_t)t * 10 + 8] >> 60);

@@ -76,8 +76,8 @@ __device__ __forceinline__ void generic_instance(const P& p, const int b, T* sme
     T* tk = zk + k;               // k
     int* brA = reinterpret_cast<int*>(tk + k);  // ndev: 1 = damping branch A, 0 = branch B
 
-    const T* Mg = p.M + (size_t)b * n * n;
-    const T* Jg = p.J + (size_t)b * k * n;
+    const auto* Mg = p.M + (size_t)b * n * n;      // storage type of the records may be narrower than T (mixed path)
+    const auto* Jg = p.J + (size_t)b * k * n;
     for (int e = lane; e < n * n; e += 64) Ms[(e / n) * ldn + (e % n)] = Mg[e];
     for (int e = lane; e < k * n; e += 64) Js[(e / n) * ldn + (e % n)] = Jg[e];
     if (lane < n) dqs[lane] = p.dq[(size_t)b * n + lane];
@@ -98,15 +98,20 @@ __device__ __forceinline__ void generic_instance(const P& p, const int b, T* sme
     __syncthreads();
 
     uint32_t flags = 0;
-    const T* gbase = p.gains + (p.gains_per_instance ? (size_t)b * ndev * IRLOSC_GAIN_WORDS : 0);
+    const auto* gbase = p.gains + (p.gains_per_instance ? (size_t)b * ndev * IRLOSC_GAIN_WORDS : 0);
     const T kvn = (p.cfgflags & IRLOSC_NULLSPACE) ? p.null_kv[p.gains_per_instance ? b : 0] : T(0);
 
     // ---- per-device task-space signal (osc.py:156-181): lane d handles device d -----------------
     if (lane < ndev) {
         const DevMeta dm = pod_copy<DevMeta>(p.dev[lane]);
-        const T* g = gbase + lane * IRLOSC_GAIN_WORDS;
-        const T* ee = p.ee + ((size_t)b * ndev + lane) * 7;
-        const T* tg = p.tgt + ((size_t)b * ndev + lane) * 7;
+        T g[IRLOSC_GAIN_WORDS], ee[7], tg[7];
+#pragma unroll
+        for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) g[i] = gbase[lane * IRLOSC_GAIN_WORDS + i];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            ee[i] = p.ee[((size_t)b * ndev + lane) * 7 + i];
+            tg[i] = p.tgt[((size_t)b * ndev + lane) * 7 + i];
+        }
         T e[6];
         task_error6<T>(ee, tg, dm.calc & 1u, dm.calc & 2u, e);
         apply_gains6<T>(g, e);
@@ -293,7 +298,7 @@ __device__ __forceinline__ void generic_instance(const P& p, const int b, T* sme
         T u = T(0);
         for (int d = 0; d < ndev; ++d) {  // branch A damping, osc.py:174 (assignment, device order)
             if (brA[d] && (p.dev[d].joint_mask & (1u << lane)))
-                u = -gbase[d * IRLOSC_GAIN_WORDS + 1] * mdq[lane];
+                u = -T(gbase[d * IRLOSC_GAIN_WORDS + 1]) * mdq[lane];
         }
         T s = T(0);
         for (int r = 0; r < k; ++r) s += Js[r * ldn + lane] * tk[r];

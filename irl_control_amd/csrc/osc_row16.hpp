@@ -193,17 +193,15 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
     double sigma = 0.0;
     giveup = flagged && !(hi > 0.0 && t_finite(hi));
     if (__any(flagged && !pdA)) {
-        double A2[K], F2[K], G2[K], invd2, det2;
+        // Some instance's plain factorisation broke down (exactly singular J): the wave factors again, that instance
+        // with sigma = 2^-40 ||A||_F on the diagonal, the others with sigma = 0 (which reproduces their factors).
+        double A2[K], det2;
         bool pd2;
 #pragma unroll
         for (int r = 0; r < K; ++r) A2[r] = Ac[r];
-        const double sg = hi * 0x1p-40;
-        ldl16<K>(A2, l, sg, F2, G2, invd2, pd2, det2);
         const bool use = flagged && !pdA;
-#pragma unroll
-        for (int r = 0; r < K; ++r) { F[r] = use ? F2[r] : F[r]; G[r] = use ? G2[r] : G[r]; }
-        invd_own = use ? invd2 : invd_own;
-        sigma = use ? sg : 0.0;
+        sigma = use ? hi * 0x1p-40 : 0.0;
+        ldl16<K>(A2, l, sigma, F, G, invd_own, pd2, det2);
         giveup = giveup || (use && !pd2);
     }
     // lambda_max
@@ -275,6 +273,36 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
     fl = m > 0 ? IRLOSC_FLAG_TRUNCATED : 0u;
 }
 
+// Velocity limiting + gains + stiffness (osc.py:70-99,160-168) like apply_gains6 (osc_common.hpp), with the divisions
+// and square roots on the refined hardware seeds (a few ulp from the IEEE results; the IEEE sequences cost 15-25
+// instructions each and this runs on every lane).
+__device__ __forceinline__ double sqrt_fast(double x) { return x > 0.0 ? x * rsq_refined(x) : 0.0; }
+__device__ __forceinline__ void apply_gains6_fast(const double* __restrict__ g, double e[6]) {
+    const double kp = g[0], kv = g[1], ko = g[2];
+    if (g[11] != 0.0) {
+        double sx = 1.0, sa = 1.0;
+        const double rkv = rcp_refined(kv);
+        const double nx = sqrt_fast(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+        const double satx = g[9] * rcp_refined(kp) * kv;
+        if (nx > satx) sx = satx * rcp_refined(nx);
+        const double na = sqrt_fast(e[3] * e[3] + e[4] * e[4] + e[5] * e[5]);
+        const double sata = g[10] * rcp_refined(ko) * kv;
+        if (na > sata) sa = sata * rcp_refined(na);
+        const double lp = kp * rkv, lo = ko * rkv;  // lamb (osc.py:39)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            e[i] = kv * sx * lp * e[i] * g[3 + i];  // stiffness k; abg entries are 1
+            e[3 + i] = kv * sa * lo * e[3 + i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            e[i] *= kp * g[3 + i];
+            e[3 + i] *= ko;
+        }
+    }
+}
+
 }  // namespace r16
 
 // What the row16 kernel needs beyond KParams: a page of zeros (padding lanes load from it instead of being masked),
@@ -291,7 +319,7 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
     using namespace r16;
     static_assert(N > 16 && N <= 32 && K >= 1 && K <= 16 && NDEV >= 1 && NDEV <= 4, "shape");
     constexpr int N1 = N - 16;                 // real rows in slot 1
-    constexpr int PF = 4;                      // rows of M in flight ahead of the column being eliminated
+    constexpr int PF = 8;                      // rows of M in flight ahead of the column being eliminated
     __shared__ double Jl[4 * (K + 1) * N + 16];   // [q][r][i]; row K of each instance is zeros (lanes >= K read it)
     __shared__ double Wl[4][16];               // task vector, written by the device lanes
     __shared__ double Dxl[4][16];              // dx for the target-velocity branch
@@ -308,30 +336,26 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
     const TIN* __restrict__ m1p = v1 ? p.M + (size_t)bc * (N * N) + 16 + l : zeros;
     double* Jq = Jl + q * ((K + 1) * N);
     uint32_t flags = 0;
+    // IRLOSC_PHASE_TIMING=1 debug runs: cycle stamps per phase and the wall clock of the wave (p.dbg != nullptr)
+    unsigned long long ts[8];
+    const unsigned long long rt0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#define IRLOSC_TS(i) ts[i] = p.dbg ? __builtin_readcyclecounter() : 0ull
+    IRLOSC_TS(0);
 
     // ---- prologue: first rows of M in flight, J (coalesced) into LDS, dq ------------------------------------------
     TIN pm0[N], pm1[N];
     static_for<0, PF>([&](auto jc) { constexpr int j = decltype(jc)::value; pm0[j] = m0p[j * N]; pm1[j] = m1p[j * N]; });
-    {
-        const TIN* __restrict__ Jb = p.J + (size_t)bc * (K * N);
-        TIN j0[K], j1[K];
+    const TIN* __restrict__ Jb = p.J + (size_t)bc * (K * N);
+    const TIN* __restrict__ Jb1 = v1 ? Jb + 16 + l : zeros;
+    TIN jl0[K], jl1[K];
 #pragma unroll
-        for (int r = 0; r < K; ++r) j0[r] = Jb[r * N + l];
-        const TIN* __restrict__ Jb1 = v1 ? Jb + 16 + l : zeros;
-#pragma unroll
-        for (int r = 0; r < K; ++r) j1[r] = Jb1[r * N];
-#pragma unroll
-        for (int r = 0; r < K; ++r) Jq[r * N + l] = (double)j0[r];
-        Jq[K * N + l] = 0.0;
-        if (v1) {
-#pragma unroll
-            for (int r = 0; r < K; ++r) Jq[r * N + 16 + l] = (double)j1[r];
-            Jq[K * N + 16 + l] = 0.0;
-        }
-        Wl[q][l] = 0.0;
-    }
-    const double dq0 = (double)p.dq[(size_t)bc * N + l];
-    const double dq1 = (double)(v1 ? p.dq + (size_t)bc * N + 16 + l : zeros)[0];
+    for (int r = 0; r < K; ++r) { jl0[r] = Jb[r * N + l]; jl1[r] = Jb1[r * N]; }
+    const TIN dq0_in = p.dq[(size_t)bc * N + l];
+    const TIN dq1_in = (v1 ? p.dq + (size_t)bc * N + 16 + l : zeros)[0];
+    const bool use_g = (p.cfgflags & IRLOSC_USE_G) != 0;
+    const TIN bias0_in = (use_g ? p.bias + (size_t)bc * N + l : zeros)[0];
+    const TIN bias1_in = (use_g && v1 ? p.bias + (size_t)bc * N + 16 + l : zeros)[0];
+    Wl[q][l] = 0.0;
     __syncthreads();
 
     // ---- task-space signal, part 1 (osc.py:101-118,70-99,160-168): quad d of the row = device d -------------------
@@ -358,8 +382,8 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
         if (dm.calc & 2u) {
             // transforms3d calls of osc.py:115-117, same formulas as task_error6 (osc_common.hpp)
             const double tw = tg[3], tx = tg[4], ty = tg[5], tz = tg[6];
-            const double nrm = sqrt(tw * tw + tx * tx + ty * ty + tz * tz);
-            const double w1 = tw / nrm, x1 = tx / nrm, y1 = ty / nrm, z1 = tz / nrm;
+            const double rnrm = rsq_refined(tw * tw + tx * tx + ty * ty + tz * tz);
+            const double w1 = tw * rnrm, x1 = tx * rnrm, y1 = ty * rnrm, z1 = tz * rnrm;
             const double w2 = ee[3], x2 = -ee[4], y2 = -ee[5], z2 = -ee[6];
             const double rw = w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2;
             const double rx = w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2;
@@ -369,7 +393,7 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
             const double Nq = w * w + xq * xq + yq * yq + zq * zq;
             double r00 = 1.0, r10 = 0.0, r20 = 0.0, r21 = 0.0, r22 = 1.0, r11 = 1.0, r12 = 0.0;
             if (!(Nq < 2.220446049250313e-16)) {
-                const double s = 2.0 / Nq;
+                const double s = 2.0 * rcp_refined(Nq);
                 const double X = xq * s, Y = yq * s, Z = zq * s;
                 const double wX = w * X, wY = w * Y, wZ = w * Z;
                 const double xX = xq * X, xY = xq * Y, xZ = xq * Z;
@@ -377,7 +401,7 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
                 r00 = 1.0 - (yY + zZ); r10 = xY + wZ; r20 = xZ - wY; r21 = yZ + wX;
                 r22 = 1.0 - (xX + yY); r11 = 1.0 - (xX + zZ); r12 = yZ - wX;
             }
-            const double cy = sqrt(r00 * r00 + r10 * r10);
+            const double cy = sqrt_fast(r00 * r00 + r10 * r10);
             const bool gimbal = !(cy > 4.0 * 2.220446049250313e-16);
             double ay = 0.0, ax = 1.0;             // atan2(0, 1) = 0: the idle lane and the gimbal-lock az
             if (ang_id == 0) { ay = gimbal ? -r12 : r21; ax = gimbal ? r11 : r22; }
@@ -388,7 +412,7 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
             e[4] = quad_bcast(ang, 1);
             e[5] = quad_bcast(ang, 2);
         }
-        apply_gains6<double>(g, e);
+        apply_gains6_fast(g, e);
         bool all_nonzero = has_tv;
         if (has_tv) {
 #pragma unroll
@@ -408,18 +432,33 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
             if (dm.jidx0 + dm.rows > K) flags |= IRLOSC_FLAG_BAD_JIDX;
         }
     }
+    IRLOSC_TS(1);
+    // J into LDS (its loads have been in flight since the top of the kernel)
+#pragma unroll
+    for (int r = 0; r < K; ++r) Jq[r * N + l] = (double)jl0[r];
+    Jq[K * N + l] = 0.0;
+    if (v1) {
+#pragma unroll
+        for (int r = 0; r < K; ++r) Jq[r * N + 16 + l] = (double)jl1[r];
+        Jq[K * N + 16 + l] = 0.0;
+    }
+    const double dq0 = (double)dq0_in, dq1 = (double)dq1_in;
+    __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
 
+    IRLOSC_TS(2);
     // ---- main loop: Cholesky of M, Y = L^-1 J^T (as T), M dq, J dq ------------------------------------------------
     double L0[15], L1[24], T[N];
     double mdq0 = 0.0, mdq1 = 0.0, dx = 0.0;
     const double* trow = Jq + (l < K ? l : K) * N;
+    double tnext = trow[0];
     static_for<0, N>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int sj = j >> 4, gj = j & 15;
         if constexpr (j + PF < N) { pm0[j + PF] = m0p[(j + PF) * N]; pm1[j + PF] = m1p[(j + PF) * N]; }
         double m0 = (double)pm0[j], m1 = (double)pm1[j];
-        double tj = trow[j];
+        double tj = tnext;
+        if constexpr (j + 1 < N) tnext = trow[j + 1];
         const double dqs = sj ? dq1 : dq0;
         __builtin_amdgcn_sched_barrier(0);
         fmac_bc_nop<gj>(mdq0, dqs, m0);
@@ -446,6 +485,7 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
         __builtin_amdgcn_sched_barrier(0);
     });
 
+    IRLOSC_TS(3);
     // ---- A = Y^T Y: lane c ends up with A[r][c], r = 0..K-1 -------------------------------------------------------
     double A[K];
 #pragma unroll
@@ -460,6 +500,7 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
     });
     __builtin_amdgcn_sched_barrier(0);
 
+    IRLOSC_TS(4);
     // ---- task-space signal, part 2: target-velocity branch B and the admittance wrench (osc.py:173-185) -----------
     Dxl[q][l] = dx;
     __syncthreads();
@@ -517,7 +558,7 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
 #pragma unroll
     for (int m = 0; m < K; ++m) trA = fma(X[m], X[m], trA);
     trA = row_sum(trA * invd_own);                     // trace(A^-1) >= 1 / lambda_min
-    const bool small_det = !(fabs(detA) >= 1e-4);
+    const bool small_det = !pdA || !(fabs(detA) >= 1e-4);      // a non-positive pivot: A is singular to working precision
     const double cond_bound = sqrt(nA2) * trA;         // >= cond_2(A) for SPD A
     const bool plain = pdA && t_finite(cond_bound) && (!small_det || cond_bound < 0.99e5);
     flags |= small_det ? IRLOSC_FLAG_PINV_BRANCH : 0u;
@@ -536,6 +577,7 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
         constexpr int i = decltype(ic)::value;
         fmac_bc_n_nop<i>(t, t, G[i]);
     });
+    IRLOSC_TS(5);
     // Instances that are not certifiably on the reference's inverse branch: truncated pseudo-inverse (osc.py:55).
     // Wave-uniform branch: the whole wave runs it (DPP sources must be active lanes), the others keep their t.
     bool giveup = false;
@@ -547,6 +589,7 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
         flags |= plain ? 0u : f2;
     }
 
+    IRLOSC_TS(6);
     // ---- joint torques of the own rows: u = u0 + bias - kvn * Mdq - J^T t (osc.py:174,184-200) --------------------
     double jt0 = 0.0, jt1 = 0.0;
     {
@@ -572,10 +615,8 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
     }
     u0 -= jt0;
     u1 -= jt1;
-    if (p.cfgflags & IRLOSC_USE_G) {
-        u0 += (double)p.bias[(size_t)bc * N + l];
-        u1 += (double)(v1 ? p.bias + (size_t)bc * N + 16 + l : zeros)[0];
-    }
+    u0 += (double)bias0_in;          // zeros unless IRLOSC_USE_G
+    u1 += (double)bias1_in;
     u0 -= kvn * mdq0;
     u1 -= kvn * mdq1;
     const bool bad = !t_finite(u0) || (v1 && !t_finite(u1));
@@ -594,11 +635,20 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
             if (giveup) x.worklist[atomicAdd(x.workcount, 1)] = b;
         }
     }
+    IRLOSC_TS(7);
+    if (p.dbg && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p.dbg[(size_t)blockIdx.x * 10 + i] = ts[i];
+        p.dbg[(size_t)blockIdx.x * 10 + 8] = rt0;
+        p.dbg[(size_t)blockIdx.x * 10 + 9] = __builtin_amdgcn_s_memrealtime();
+    }
+#undef IRLOSC_TS
 }
 
 // The generic kernel over a worklist: instance ids list[0..*count); zeroes *reset for the step after.
-template <typename T>
-__global__ __launch_bounds__(64) void osc_generic_worklist_kernel(const KParams<T> p, const int32_t* __restrict__ list,
+// T = arithmetic type, S = storage type of the records (S = float, T = double on the mixed path).
+template <typename T, typename S>
+__global__ __launch_bounds__(64) void osc_generic_worklist_kernel(const KParams<S> p, const int32_t* __restrict__ list,
                                                                    const int32_t* __restrict__ count, int32_t* __restrict__ reset) {
     extern __shared__ __align__(16) unsigned char smem_raw_w[];
     T* smem = reinterpret_cast<T*>(smem_raw_w);
@@ -608,7 +658,8 @@ __global__ __launch_bounds__(64) void osc_generic_worklist_kernel(const KParams<
 }
 
 inline bool row16_kernel_supports(int dtype, int n, int k, int ndev) {
-    return dtype == IRLOSC_F64 && n == 25 && ((k == 13 && ndev == 3) || (k == 12 && ndev == 2) || (k == 7 && ndev == 3));
+    (void)dtype;     // fp64 records, or fp32 records with fp64 arithmetic (mixed path)
+    return n == 25 && ((k == 13 && ndev == 3) || (k == 12 && ndev == 2) || (k == 7 && ndev == 3));
 }
 
 template <typename TIN>

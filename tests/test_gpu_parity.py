@@ -530,3 +530,101 @@ def test_call_order_and_argument_errors():
     with pytest.raises(_lib.IrloscError):
         BatchedOSC(lay, 32, dtype=np.float64, kernel=_lib.KERNEL_GROUP)            # no fp64 group kernel
     osc.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# fp64-arithmetic throughput (row16) path: fp64 records, and fp32 records with fp64 arithmetic (mixed)
+# ------------------------------------------------------------------------------------------------
+def _round32(g):
+    return {k: (v.astype(np.float32).astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float64 else v)
+            for k, v in g.items()}
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_mixed_path_meets_1e5_on_fp32_rounded_goldens(name):
+    """north_star's 1e-5 on float32 RECORDS: the reference-minted fixtures rounded to float32, run through the row16
+    kernel (fp32 storage, fp64 arithmetic), against the float64 oracle on the same rounded inputs.  Gate 1e-5 flat
+    on the parity domain of the rounded problem (no condition-number allowance).  Layouts the row16 kernel does not
+    cover fall back to the generic fp32 kernel and are skipped here."""
+    g = load_golden(name)
+    lay = OSCLayout.from_dict(g["layout"])
+    if not (lay.n == 25 and (lay.k, lay.ndev) in ((13, 3), (12, 2), (7, 3))):
+        pytest.skip("no row16 instantiation for this layout")
+    g32 = _round32(g)
+    u, fl, kname = run_gpu(lay, golden_gains(g), g32, np.float32, _lib.KERNEL_ROW16)
+    assert "row16_f32in_f64" in kname
+    ref = osc_oracle.generate_batch(g["layout"], golden_gains(g), g32["M"], g32["J"], g32["dq"], g32["bias"],
+                                    g32["ee_pose"], g32["tgt_pose"], g32["wrench"], g32["tgt_vel"])
+    dom = np.array([in_parity_domain(*osc_oracle.task_inertia(g32["J"][b], g32["M"][b])[2:])
+                    for b in range(g["M"].shape[0])])
+    if name == "k13_gimbal":       # the float32-rounded poses are no longer at gimbal lock; nothing else changes
+        assert dom.sum() > 0
+    err = rel_err(u, ref)
+    assert dom.sum() >= 0.6 * len(dom)
+    assert err[dom].max() <= TOL64, (kname, name, float(err[dom].max()))
+    assert not np.any(fl[dom] & (_lib.FLAG_NONFINITE | _lib.FLAG_M_NOT_PD))
+
+
+@pytest.mark.parametrize("cfg", ["k13", "k7", "k12_admit"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_row16_vs_oracle_flat_1e5(cfg, dtype):
+    """1 024 synthetic instances per layout (11 % of them on the truncated-pinv path) on the row16 kernel, float64
+    records and float32 records (mixed): every in-domain instance within 1e-5, flags consistent with the reference's
+    branch (osc.py:52) and with the singular values it would cut."""
+    B = 1024
+    lay, gains, g = synth.make_batch(cfg, B, seed=99)
+    gin = _round32(g) if dtype == np.float32 else g
+    u, fl, kname = run_gpu(lay, gains, gin, dtype, _lib.KERNEL_ROW16)
+    assert "row16" in kname
+    idx = np.arange(0, B, 2)
+    ref = osc_oracle.generate_batch(lay.as_oracle_dict(), gains, gin["M"], gin["J"], gin["dq"], gin["bias"],
+                                    gin["ee_pose"], gin["tgt_pose"], gin.get("wrench"), gin.get("tgt_vel"), idx=idx)
+    dom, small_det, cut = [], [], []
+    for b in idx:
+        Mx, Minv, Mxi, det = osc_oracle.task_inertia(gin["J"][b], gin["M"][b])
+        s = np.linalg.svd(Mxi, compute_uv=False)
+        dom.append(in_parity_domain(Mxi, det))
+        small_det.append(abs(det) < 1e-4)
+        cut.append(abs(det) < 1e-4 and s[-1] <= 1e-5 * s[0])
+    dom, small_det, cut = np.array(dom), np.array(small_det), np.array(cut)
+    err = rel_err(u[idx], ref[idx])
+    assert dom.mean() > 0.9
+    assert err[dom].max() <= TOL64, (kname, float(err[dom].max()))
+    assert np.array_equal((fl[idx][dom] & _lib.FLAG_PINV_BRANCH) != 0, small_det[dom])
+    assert np.array_equal((fl[idx][dom] & _lib.FLAG_TRUNCATED) != 0, cut[dom])
+    assert np.all(np.isfinite(u))
+
+
+@pytest.mark.parametrize("B", [1, 3, 4, 5, 17, 100])
+def test_row16_ragged_batches_and_sharding_bit_exact(B):
+    """A wave carries four instances: batch sizes around that, and a split at an offset that changes every
+    instance's wave-mates.  Each instance must come out bit-identical to what the large batch gives (the eigen path
+    freezes an instance at its own convergence, so nothing depends on its neighbours)."""
+    lay, gains, g = synth.make_batch("k13", 512, seed=21)
+    full, ffull, name = run_gpu(lay, gains, g, np.float64, _lib.KERNEL_ROW16)
+    assert "row16" in name and (ffull & _lib.FLAG_EIGEN_PATH).any()
+    sub = {k: (v[:B] if isinstance(v, np.ndarray) else v) for k, v in g.items()}
+    part, fl, _ = run_gpu(lay, gains, sub, np.float64, _lib.KERNEL_ROW16)
+    assert np.array_equal(part, full[:B]) and np.array_equal(fl, ffull[:B])
+    off = 257 + B % 3
+    tail = {k: (v[off:] if isinstance(v, np.ndarray) else v) for k, v in g.items()}
+    ut, ft, _ = run_gpu(lay, gains, tail, np.float64, _lib.KERNEL_ROW16)
+    assert np.array_equal(ut, full[off:]) and np.array_equal(ft, ffull[off:])
+
+
+@pytest.mark.parametrize("lost", [1, 2, 3, 5])
+def test_row16_rank_deficient_jacobians(lost):
+    """Exactly singular task Jacobians (duplicated rows: `lost` zero eigenvalues of J M^-1 J^T): the plain
+    factorisation breaks down, the shifted one takes over, up to three null vectors are deflated in the kernel and
+    more than three go through the give-up list to the Jacobi kernel.  The reference answer (pinv) is well defined."""
+    B = 256
+    lay, gains, g = synth.make_batch("k13", B, seed=55)
+    bad = np.arange(0, B, 3)
+    g["J"][bad, 13 - lost:13] = g["J"][bad, 0:lost]
+    u, fl, name = run_gpu(lay, gains, g, np.float64, _lib.KERNEL_ROW16)
+    assert "row16" in name
+    ref = osc_oracle.generate_batch(lay.as_oracle_dict(), gains, g["M"], g["J"], g["dq"], g["bias"], g["ee_pose"],
+                                    g["tgt_pose"], g.get("wrench"), g.get("tgt_vel"), idx=bad)
+    assert np.all(fl[bad] & _lib.FLAG_TRUNCATED) and np.all(fl[bad] & _lib.FLAG_PINV_BRANCH)
+    err = rel_err(u[bad], ref[bad])
+    assert err.max() <= TOL64, (lost, float(err.max()))

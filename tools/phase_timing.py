@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Mean cycles per kernel phase (IRLOSC_PHASE_TIMING=1 debug aid of libirlosc).  usage: phase_timing.py [f32|f64] [layout] [B]"""
+import os
+import sys
+os.environ["IRLOSC_PHASE_TIMING"] = "1"
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+from irl_control_amd import BatchedOSC, synth
+
+dt = np.float64 if (len(sys.argv) < 2 or sys.argv[1] == "f64") else np.float32
+cfg = sys.argv[2] if len(sys.argv) > 2 else "k13"
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
+lay, gains, arr = synth.make_batch(cfg, B, seed=7, dtype=dt)
+osc = BatchedOSC(lay, B, dtype=dt)
+osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+osc.upload(arr["M"], arr["J"], arr["dq"], arr["bias"], arr["ee_pose"], arr.get("wrench"))
+osc.set_targets(arr["tgt_pose"], arr.get("tgt_vel"))
+for _ in range(3):
+    osc.step_resident(50)
+    osc.download(B)       # prints the phase table to stderr
+print(osc.kernel_name)
