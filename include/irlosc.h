@@ -171,7 +171,16 @@ int irlosc_assemble_device(irlosc_ctx* ctx, int32_t slot, int32_t B, const irlos
                            const void* d_sensordata, void* hip_stream);
 
 int irlosc_download(irlosc_ctx* ctx, int32_t B, void* u_host, uint32_t* flags_host);
-int irlosc_sync(irlosc_ctx* ctx);
+int irlosc_sync(irlosc_ctx* ctx);          /* waits for the context's stream */
+int irlosc_device_sync(irlosc_ctx* ctx);   /* hipDeviceSynchronize on the context's GPU (bench bracket) */
+
+/* One control tick in ONE call (what OSC.generate does per tick for B robots, osc.py:120-210): the records are packed
+ * into a pinned staging block, cross PCIe in one copy, the step runs on them in place, u[B][n] and flags[B] come back
+ * in one copy, and the call synchronises once.  Same record layouts as irlosc_upload / irlosc_set_targets; wrench and
+ * tgt_vel may be NULL.  Does not touch the resident slots. */
+int irlosc_tick(irlosc_ctx* ctx, int32_t B, const void* M, const void* J, const void* dq, const void* bias,
+                const void* ee_pose, const void* wrench, const void* tgt_pose, const void* tgt_vel, void* u_host,
+                uint32_t* flags_host);
 
 /* Raw-device-pointer form for callers that already hold the state in HBM (e.g. an on-GPU
  * simulator): same layouts as above, all pointers are device pointers, hip_stream is a
@@ -180,6 +189,25 @@ int irlosc_step_device(irlosc_ctx* ctx, int32_t B, const void* dM, const void* d
                        const void* dbias, const void* dee_pose, const void* dtgt_pose,
                        const void* dtgt_vel, const void* dwrench, void* du, uint32_t* dflags,
                        void* hip_stream);
+
+/* ---- multi-GPU: the final throughput reduction -----------------------------------------------
+ * Instances are independent (osc.py:120-210 touches one robot), so a node runs one process per GPU on its own shard
+ * and NOTHING is exchanged per tick.  RCCL (over xGMI) is used once per benchmark: sum of the steps done, max of the
+ * elapsed time, and an all-gather of per-rank output checksums.  librccl is loaded on first use (dlopen), so a
+ * single-GPU deployment does not depend on it.  The 128-byte unique id is made by rank 0 (irlosc_comm_unique_id) and
+ * handed to the other ranks by the host program (irl_control_amd/sharding.py: a file next to MASTER_PORT). */
+typedef struct irlosc_comm irlosc_comm;
+#define IRLOSC_COMM_ID_BYTES 128
+int irlosc_comm_unique_id(uint8_t id_out[IRLOSC_COMM_ID_BYTES]);
+int irlosc_comm_create(int32_t hip_device, int32_t rank, int32_t world, const uint8_t id[IRLOSC_COMM_ID_BYTES],
+                       irlosc_comm** out);
+void irlosc_comm_destroy(irlosc_comm* comm);
+const char* irlosc_comm_last_error(const irlosc_comm* comm);   /* comm may be NULL: last create()/unique_id() error */
+/* In place: *steps_sum <- sum over ranks, *elapsed_max <- max over ranks (two ncclAllReduce on the comm's stream,
+ * then a stream sync).  Doubles as the barrier of the benchmark bracket. */
+int irlosc_bench_allreduce(irlosc_comm* comm, double* steps_sum, double* elapsed_max);
+/* all[r] <- rank r's `mine` (ncclAllGather): per-shard output checksums, to show that sharding changes no bit. */
+int irlosc_comm_allgather_u64(irlosc_comm* comm, uint64_t mine, uint64_t* all);
 
 #ifdef __cplusplus
 }

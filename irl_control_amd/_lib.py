@@ -19,7 +19,10 @@ EXPORTS = ["irlosc_abi_version", "irlosc_device_count", "irlosc_create", "irlosc
            "irlosc_last_error", "irlosc_kernel_name", "irlosc_set_gains", "irlosc_upload",
            "irlosc_set_targets", "irlosc_step", "irlosc_step_resident", "irlosc_download",
            "irlosc_sync", "irlosc_step_device", "irlosc_time_dominant_kernel",
-           "irlosc_steps_per_launch", "irlosc_upload_raw", "irlosc_assemble_device"]
+           "irlosc_steps_per_launch", "irlosc_upload_raw", "irlosc_assemble_device", "irlosc_device_sync",
+           "irlosc_tick", "irlosc_comm_unique_id", "irlosc_comm_create", "irlosc_comm_destroy",
+           "irlosc_comm_last_error", "irlosc_bench_allreduce", "irlosc_comm_allgather_u64"]
+COMM_ID_BYTES = 128
 
 
 class RawDesc(C.Structure):
@@ -76,6 +79,16 @@ def load():
     lib.irlosc_download.argtypes = [vp, i32, vp, vp]
     lib.irlosc_sync.argtypes = [vp]
     lib.irlosc_step_device.argtypes = [vp, i32] + [vp] * 11
+    lib.irlosc_device_sync.argtypes = [vp]
+    lib.irlosc_tick.argtypes = [vp, i32] + [vp] * 10
+    lib.irlosc_comm_unique_id.argtypes = [vp]
+    lib.irlosc_comm_create.argtypes = [i32, i32, i32, vp, C.POINTER(vp)]
+    lib.irlosc_comm_destroy.argtypes = [vp]
+    lib.irlosc_comm_destroy.restype = None
+    lib.irlosc_comm_last_error.argtypes = [vp]
+    lib.irlosc_comm_last_error.restype = C.c_char_p
+    lib.irlosc_bench_allreduce.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.irlosc_comm_allgather_u64.argtypes = [vp, C.c_uint64, vp]
     for name in EXPORTS:
         getattr(lib, name)
     _lib = lib

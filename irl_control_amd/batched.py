@@ -145,6 +145,29 @@ class BatchedOSC:
     def sync(self):
         self._chk(self.lib.irlosc_sync(self._h))
 
+    def device_sync(self):
+        """hipDeviceSynchronize on this context's GPU (the bench bracket)."""
+        self._chk(self.lib.irlosc_device_sync(self._h))
+
+    def tick(self, M, J, dq, bias, ee_pose, tgt_pose, tgt_vel=None, wrench=None, return_flags: bool = False):
+        """One control tick for B instances in ONE library call (irlosc_tick): one host-to-device copy, the step, one
+        copy back, one synchronisation.  Does not touch the resident slots."""
+        L = self.layout
+        B = int(np.shape(M)[0])
+        M = self._arr(M, (B, L.n, L.n), "M")
+        J = self._arr(J, (B, L.k, L.n), "J")
+        dq = self._arr(dq, (B, L.n), "dq")
+        bias = self._arr(bias, (B, L.n), "bias")
+        ee = self._arr(ee_pose, (B, L.ndev, 7), "ee_pose")
+        wr = self._arr(wrench, (B, L.ndev, 6), "wrench")
+        tp = self._arr(tgt_pose, (B, L.ndev, 7), "tgt_pose")
+        tv = self._arr(tgt_vel, (B, L.ndev, 6), "tgt_vel")
+        u = np.empty((B, L.n), dtype=self.dtype)
+        fl = np.empty(B, dtype=np.uint32)
+        self._chk(self.lib.irlosc_tick(self._h, B, _lib.ptr(M), _lib.ptr(J), _lib.ptr(dq), _lib.ptr(bias), _lib.ptr(ee),
+                                       _lib.ptr(wr), _lib.ptr(tp), _lib.ptr(tv), _lib.ptr(u), _lib.ptr(fl)))
+        return (u, fl) if return_flags else u
+
     def generate_batched(self, M, J, dq, bias, ee_pose, tgt_pose, tgt_vel=None, wrench=None,
                          return_flags: bool = False):
         """One tick for B instances: upload, step, download."""

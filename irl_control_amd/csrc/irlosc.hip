@@ -1,6 +1,8 @@
 // libirlosc.so — C ABI (include/irlosc.h) over the gfx950 OSC kernels.  No CPU fallback: every
 // compute entry point needs a HIP device and reports IRLOSC_ERR_HIP otherwise.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types only: the library is dlopen()ed on first use
+#include <dlfcn.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -63,6 +65,9 @@ struct irlosc_ctx {
     int32_t* dr16_list = nullptr;
     int32_t* dr16_count = nullptr;
     int r16_parity = 0;
+    // irlosc_tick: one pinned host block and one device block per direction, grown on demand
+    void* tick_hin = nullptr; void* tick_din = nullptr; size_t tick_in_bytes = 0;
+    void* tick_hout = nullptr; void* tick_dout = nullptr; size_t tick_out_bytes = 0;
     void* dgains = nullptr;   // [nb][ndev][12] in dtype
     void* dnullkv = nullptr;  // [nb]
     int gains_nb = 0;
@@ -149,6 +154,10 @@ static void free_all(irlosc_ctx* c) {
     for (int k = 0; k < irlosc_ctx::NTABLES; ++k)
         if (c->dtable[k]) (void)hipFree(c->dtable[k]);
     if (c->draw) (void)hipFree(c->draw);
+    if (c->tick_hin) (void)hipHostFree(c->tick_hin);
+    if (c->tick_din) (void)hipFree(c->tick_din);
+    if (c->tick_hout) (void)hipHostFree(c->tick_hout);
+    if (c->tick_dout) (void)hipFree(c->tick_dout);
     if (c->dzeros) (void)hipFree(c->dzeros);
     if (c->dr16_list) (void)hipFree(c->dr16_list);
     if (c->dr16_count) (void)hipFree(c->dr16_count);
@@ -804,6 +813,213 @@ extern "C" int irlosc_sync(irlosc_ctx* c) {
     if (!c) return IRLOSC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.hip_device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return IRLOSC_OK;
+}
+
+extern "C" int irlosc_device_sync(irlosc_ctx* c) {
+    if (!c) return IRLOSC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    HIPCHK(c, hipDeviceSynchronize());
+    return IRLOSC_OK;
+}
+
+extern "C" int irlosc_tick(irlosc_ctx* c, int32_t B, const void* M, const void* J, const void* dq, const void* bias,
+                           const void* ee_pose, const void* wrench, const void* tgt_pose, const void* tgt_vel, void* u_host,
+                           uint32_t* flags_host) {
+    if (!c) return IRLOSC_ERR_ARG;
+    if (B < 0 || B > c->cfg.max_batch) return fail(c, IRLOSC_ERR_ARG, "B=%d out of [0,%d]", B, c->cfg.max_batch);
+    if (B == 0) return IRLOSC_OK;
+    if (!M || !J || !dq || !ee_pose || !tgt_pose || !u_host) return fail(c, IRLOSC_ERR_ARG, "M, J, dq, ee_pose, tgt_pose and u_host are required");
+    if ((c->cfg.flags & IRLOSC_USE_G) && !bias) return fail(c, IRLOSC_ERR_ARG, "bias required with IRLOSC_USE_G");
+    if (c->gains_nb == 0) return fail(c, IRLOSC_ERR_STATE, "irlosc_set_gains has not been called");
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    const size_t b = (size_t)B, n = (size_t)c->cfg.n, k = (size_t)c->k, nd = (size_t)c->cfg.ndev, e = c->esz;
+    // input block: M | J | dq | bias | ee | tgt | wrench | tvel, each piece 256-byte aligned
+    const void* src[8] = {M, J, dq, bias, ee_pose, tgt_pose, wrench, tgt_vel};
+    const size_t sz[8] = {b * n * n * e, b * k * n * e, b * n * e, bias ? b * n * e : 0, b * nd * 7 * e, b * nd * 7 * e,
+                          wrench ? b * nd * 6 * e : 0, tgt_vel ? b * nd * 6 * e : 0};
+    size_t off[8], total = 0;
+    for (int i = 0; i < 8; ++i) { off[i] = total; total += (sz[i] + 255) & ~(size_t)255; }
+    if (total > c->tick_in_bytes) {
+        if (c->tick_hin) HIPCHK(c, hipHostFree(c->tick_hin));
+        if (c->tick_din) HIPCHK(c, hipFree(c->tick_din));
+        c->tick_hin = c->tick_din = nullptr; c->tick_in_bytes = 0;
+        HIPCHK(c, hipHostMalloc(&c->tick_hin, total, hipHostMallocDefault));
+        HIPCHK(c, hipMalloc(&c->tick_din, total));
+        c->tick_in_bytes = total;
+    }
+    const size_t ub = b * n * e, out_total = ((ub + 255) & ~(size_t)255) + b * sizeof(uint32_t);
+    if (out_total > c->tick_out_bytes) {
+        if (c->tick_hout) HIPCHK(c, hipHostFree(c->tick_hout));
+        if (c->tick_dout) HIPCHK(c, hipFree(c->tick_dout));
+        c->tick_hout = c->tick_dout = nullptr; c->tick_out_bytes = 0;
+        HIPCHK(c, hipHostMalloc(&c->tick_hout, out_total, hipHostMallocDefault));
+        HIPCHK(c, hipMalloc(&c->tick_dout, out_total));
+        c->tick_out_bytes = out_total;
+    }
+    unsigned char* hin = (unsigned char*)c->tick_hin;
+    unsigned char* din = (unsigned char*)c->tick_din;
+    for (int i = 0; i < 8; ++i) if (sz[i]) memcpy(hin + off[i], src[i], sz[i]);
+    HIPCHK(c, hipMemcpyAsync(din, hin, total, hipMemcpyHostToDevice, c->stream));
+    unsigned char* dout = (unsigned char*)c->tick_dout;
+    uint32_t* dfl = (uint32_t*)(dout + ((ub + 255) & ~(size_t)255));
+    int rc = launch(c, B, din + off[0], din + off[1], din + off[2], sz[3] ? din + off[3] : nullptr, din + off[4], din + off[5],
+                    sz[7] ? din + off[7] : nullptr, sz[6] ? din + off[6] : nullptr, dout, dfl, c->stream);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->tick_hout, dout, out_total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(u_host, c->tick_hout, ub);
+    if (flags_host) memcpy(flags_host, (unsigned char*)c->tick_hout + ((ub + 255) & ~(size_t)255), b * sizeof(uint32_t));
+    return IRLOSC_OK;
+}
+
+// ---- multi-GPU throughput reduction over RCCL (dlopen: a single-GPU deployment never loads librccl) ---------------
+namespace {
+struct RcclApi {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+thread_local std::string g_comm_error;
+
+int comm_fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_comm_error = buf;
+    return code;
+}
+
+int rccl_load() {
+    if (g_rccl.h) return IRLOSC_OK;
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return comm_fail(IRLOSC_ERR_HIP, "cannot load librccl.so: %s", dlerror());
+    RcclApi a;
+    a.h = h;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
+    a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.AllGather || !a.GetErrorString)
+        return comm_fail(IRLOSC_ERR_HIP, "librccl.so lacks an expected symbol");
+    g_rccl = a;
+    return IRLOSC_OK;
+}
+}  // namespace
+
+struct irlosc_comm {
+    int device = 0, rank = 0, world = 1;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    double* dbuf = nullptr;          // 2 doubles in, 2 doubles out, then `world` uint64 for the all-gather
+    std::string err;
+};
+
+#define COMMCHK(cm, expr)                                                                                     \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) {                                                                               \
+            int rc_ = comm_fail(IRLOSC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));               \
+            if (cm) (cm)->err = g_comm_error;                                                                 \
+            return rc_;                                                                                       \
+        }                                                                                                     \
+    } while (0)
+#define NCCLCHK(cm, expr)                                                                                     \
+    do {                                                                                                      \
+        ncclResult_t r_ = (expr);                                                                             \
+        if (r_ != ncclSuccess) {                                                                              \
+            int rc_ = comm_fail(IRLOSC_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));           \
+            if (cm) (cm)->err = g_comm_error;                                                                 \
+            return rc_;                                                                                       \
+        }                                                                                                     \
+    } while (0)
+
+extern "C" const char* irlosc_comm_last_error(const irlosc_comm* cm) { return cm ? cm->err.c_str() : g_comm_error.c_str(); }
+
+extern "C" int irlosc_comm_unique_id(uint8_t id_out[IRLOSC_COMM_ID_BYTES]) {
+    static_assert(sizeof(ncclUniqueId) == IRLOSC_COMM_ID_BYTES, "unique id size");
+    if (!id_out) return comm_fail(IRLOSC_ERR_ARG, "id_out is NULL");
+    int rc = rccl_load();
+    if (rc) return rc;
+    ncclUniqueId id;
+    NCCLCHK((irlosc_comm*)nullptr, g_rccl.GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return IRLOSC_OK;
+}
+
+extern "C" int irlosc_comm_create(int32_t hip_device, int32_t rank, int32_t world, const uint8_t id[IRLOSC_COMM_ID_BYTES],
+                                  irlosc_comm** out) {
+    if (!out) return comm_fail(IRLOSC_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!id) return comm_fail(IRLOSC_ERR_ARG, "id is NULL");
+    if (world < 1 || rank < 0 || rank >= world) return comm_fail(IRLOSC_ERR_ARG, "rank %d outside world of %d", rank, world);
+    int ndevs = 0;
+    if (hipGetDeviceCount(&ndevs) != hipSuccess || ndevs < 1) return comm_fail(IRLOSC_ERR_HIP, "no HIP device available");
+    if (hip_device < 0 || hip_device >= ndevs) return comm_fail(IRLOSC_ERR_ARG, "hip_device=%d but %d device(s) visible", hip_device, ndevs);
+    int rc = rccl_load();
+    if (rc) return rc;
+    irlosc_comm* cm = new (std::nothrow) irlosc_comm();
+    if (!cm) return comm_fail(IRLOSC_ERR_HIP, "out of host memory");
+    cm->device = hip_device; cm->rank = rank; cm->world = world;
+    auto body = [&]() -> int {
+        COMMCHK(cm, hipSetDevice(hip_device));
+        COMMCHK(cm, hipStreamCreateWithFlags(&cm->stream, hipStreamNonBlocking));
+        COMMCHK(cm, hipMalloc((void**)&cm->dbuf, (4 + (size_t)world + 1) * sizeof(double)));
+        ncclUniqueId uid;
+        memcpy(&uid, id, sizeof uid);
+        NCCLCHK(cm, g_rccl.CommInitRank(&cm->comm, world, uid, rank));
+        return IRLOSC_OK;
+    };
+    rc = body();
+    if (rc) { irlosc_comm_destroy(cm); return rc; }
+    *out = cm;
+    return IRLOSC_OK;
+}
+
+extern "C" void irlosc_comm_destroy(irlosc_comm* cm) {
+    if (!cm) return;
+    (void)hipSetDevice(cm->device);
+    if (cm->stream) (void)hipStreamSynchronize(cm->stream);
+    if (cm->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(cm->comm);
+    if (cm->dbuf) (void)hipFree(cm->dbuf);
+    if (cm->stream) (void)hipStreamDestroy(cm->stream);
+    delete cm;
+}
+
+extern "C" int irlosc_bench_allreduce(irlosc_comm* cm, double* steps_sum, double* elapsed_max) {
+    if (!cm || !steps_sum || !elapsed_max) return comm_fail(IRLOSC_ERR_ARG, "NULL argument");
+    COMMCHK(cm, hipSetDevice(cm->device));
+    const double in[2] = {*steps_sum, *elapsed_max};
+    COMMCHK(cm, hipMemcpyAsync(cm->dbuf, in, sizeof in, hipMemcpyHostToDevice, cm->stream));
+    NCCLCHK(cm, g_rccl.AllReduce(cm->dbuf, cm->dbuf + 2, 1, ncclFloat64, ncclSum, cm->comm, cm->stream));
+    NCCLCHK(cm, g_rccl.AllReduce(cm->dbuf + 1, cm->dbuf + 3, 1, ncclFloat64, ncclMax, cm->comm, cm->stream));
+    double outv[2];
+    COMMCHK(cm, hipMemcpyAsync(outv, cm->dbuf + 2, sizeof outv, hipMemcpyDeviceToHost, cm->stream));
+    COMMCHK(cm, hipStreamSynchronize(cm->stream));
+    *steps_sum = outv[0];
+    *elapsed_max = outv[1];
+    return IRLOSC_OK;
+}
+
+extern "C" int irlosc_comm_allgather_u64(irlosc_comm* cm, uint64_t mine, uint64_t* all) {
+    if (!cm || !all) return comm_fail(IRLOSC_ERR_ARG, "NULL argument");
+    COMMCHK(cm, hipSetDevice(cm->device));
+    uint64_t* d = (uint64_t*)(cm->dbuf + 4);
+    COMMCHK(cm, hipMemcpyAsync(d + cm->world, &mine, sizeof mine, hipMemcpyHostToDevice, cm->stream));
+    NCCLCHK(cm, g_rccl.AllGather(d + cm->world, d, 1, ncclUint64, cm->comm, cm->stream));
+    COMMCHK(cm, hipMemcpyAsync(all, d, (size_t)cm->world * sizeof(uint64_t), hipMemcpyDeviceToHost, cm->stream));
+    COMMCHK(cm, hipStreamSynchronize(cm->stream));
     return IRLOSC_OK;
 }
 

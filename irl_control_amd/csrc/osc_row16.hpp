@@ -117,6 +117,7 @@ __device__ __forceinline__ double rcp_refined(double d) {
     const double e = fma(-d, r, 1.0);
     return fma(r * e, 1.0 + e, r);
 }
+__device__ __forceinline__ double sqrt_fast(double x) { return x > 0.0 ? x * rsq_refined(x) : 0.0; }
 
 // ---- k x k building blocks: lane c of a row holds column c (= row c) of a symmetric K x K matrix in K registers -----
 
@@ -217,66 +218,133 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
     };
     double lmax = rayleigh(xp);
     double cutoff = 1e-5 * lmax;
-    // sub-threshold eigenpairs
-    double v[3] = {0.0, 0.0, 0.0};
+    // Candidate eigenpairs: everything under FOUR times the cut, one at a time by deflated inverse iteration.  The net
+    // is wider than the cut on purpose: two eigenvalues straddling the cut converge towards each other's mixtures
+    // (ratio close to 1), but the SPAN of the candidates converges at the rate of the gap to the first eigenvalue
+    // outside the net (<= 1/4 per iteration), and the Rayleigh-Ritz step below then separates them exactly.
+    constexpr int NV = 4;
+    double v[NV] = {0.0, 0.0, 0.0, 0.0};
+    double th[NV] = {0.0, 0.0, 0.0, 0.0};      // Ritz value of v[i]
+    bool has[NV] = {false, false, false, false};
     int m = 0;
     bool active = flagged && !giveup;
 #pragma unroll
-    for (int slot = 0; slot < 4; ++slot) {
+    for (int slot = 0; slot < NV; ++slot) {
         if (!__any(active)) break;
         double x = l < K ? 0.3 + 0.1 * (double)(((l + 3 * slot) * 5) % 7) - 0.05 * (double)slot : 0.0;
         double lam = 0.0, lam_prev = -1.0;
         bool fin = !active;
-        for (int it = 0; it < 16; ++it) {
+        for (int it = 0; it < 12; ++it) {
             double xn = x;
 #pragma unroll
-            for (int s0 = 0; s0 < 3; ++s0) {
+            for (int s0 = 0; s0 < NV - 1; ++s0) {
                 if (s0 < slot) xn = fma(-row_sum(v[s0] * xn), v[s0], xn);     // unused v are exact zeros
             }
             solve16<K>(xn, F, G, invd_own);
             const double n2 = row_sum(xn * xn);
             const double rn = rsq_refined(n2 > 0.0 ? n2 : 1.0);
             const double lamn = rn - sigma;                 // 1 / ||(A + sigma)^-1 x|| -> lambda + sigma (from above)
-            const bool settled = fabs(lamn - lam_prev) <= 1e-11 * fabs(lamn) || lamn > 4.0 * cutoff;
+            const bool settled = fabs(lamn - lam_prev) <= 1e-10 * fabs(lamn) || lamn > 16.0 * cutoff;
             x = fin ? x : xn * rn;
             lam = fin ? lam : lamn;
             lam_prev = lam;
             fin = fin || (it >= 3 && settled);
             if (!__any(!fin)) break;
         }
-        // a candidate within 2 % of the cut: sharpen lambda_max before deciding (rare; only those instances move)
-        const bool amb = active && fabs(lam - cutoff) < 0.02 * cutoff;
-        if (__any(amb)) {
-            for (int it = 0; it < 200; ++it) xp = matvec16<K>(xp, Ac) * sc;
-            double xq2 = xp;
-            const double lm2 = rayleigh(xq2);
-            lmax = (amb && lm2 > lmax) ? lm2 : lmax;
-            cutoff = 1e-5 * lmax;
+        const bool cand = active && (lam <= 4.0 * cutoff);
+        // final clean-up against the earlier vectors (the last solve re-introduced rounding-level components)
+#pragma unroll
+        for (int s0 = 0; s0 < NV - 1; ++s0) {
+            if (s0 < slot) x = fma(-row_sum(v[s0] * x), v[s0], x);
         }
-        const bool below = active && (lam <= cutoff);
-        if (slot < 3) {
-            v[slot] = below ? x : 0.0;
-            m += below ? 1 : 0;
-        } else {
-            giveup = giveup || below;              // a 4th sub-threshold eigenvalue: not handled here
+        {
+            const double n2 = row_sum(x * x);
+            x *= rsq_refined(n2 > 0.0 ? n2 : 1.0);
         }
-        active = below;
+        v[slot] = cand ? x : 0.0;
+        th[slot] = cand ? lam : 0.0;
+        has[slot] = cand;
+        m += cand ? 1 : 0;
+        active = cand;
+    }
+    giveup = giveup || (m == NV);               // the net is full: there may be more under it (-> Jacobi)
+    // Rayleigh-Ritz on the span of the candidates whenever an instance has more than one: H = V^T A V (4 x 4, the
+    // unused vectors are zero), cyclic Jacobi on H with the rotations applied to V.  Rare, wave-uniform branch.
+    if (__any(m >= 2)) {
+        double av[NV], h[NV][NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) av[i] = matvec16<K>(v[i], Ac);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+#pragma unroll
+            for (int j = i; j < NV; ++j) { h[i][j] = row_sum(v[i] * av[j]); h[j][i] = h[i][j]; }
+        }
+        for (int sweep = 0; sweep < 6; ++sweep) {
+#pragma unroll
+            for (int p2 = 0; p2 < NV - 1; ++p2) {
+#pragma unroll
+                for (int q2 = p2 + 1; q2 < NV; ++q2) {
+                    const double hpq = h[p2][q2], hpp = h[p2][p2], hqq = h[q2][q2];
+                    const bool rot = has[p2] && has[q2] && fabs(hpq) > 1e-300 && fabs(hpq) > 1e-18 * (fabs(hpp) + fabs(hqq));
+                    double theta = (hqq - hpp) * rcp_refined(rot ? 2.0 * hpq : 1.0);
+                    theta = fmin(fmax(theta, -1e100), 1e100);      // theta^2 must stay finite (then t ~ 1 / (2 theta) ~ 0)
+                    const double tq = (theta >= 0.0 ? 1.0 : -1.0) * rcp_refined(fabs(theta) + sqrt_fast(theta * theta + 1.0));
+                    const double cs = rot ? rsq_refined(tq * tq + 1.0) : 1.0;
+                    const double sn = rot ? tq * cs : 0.0;
+                    h[p2][p2] = rot ? hpp - tq * hpq : hpp;
+                    h[q2][q2] = rot ? hqq + tq * hpq : hqq;
+                    h[p2][q2] = rot ? 0.0 : hpq;
+                    h[q2][p2] = h[p2][q2];
+#pragma unroll
+                    for (int r = 0; r < NV; ++r) {
+                        if (r != p2 && r != q2) {
+                            const double hrp = h[r][p2], hrq = h[r][q2];
+                            h[r][p2] = cs * hrp - sn * hrq; h[p2][r] = h[r][p2];
+                            h[r][q2] = sn * hrp + cs * hrq; h[q2][r] = h[r][q2];
+                        }
+                    }
+                    const double vp = v[p2], vq = v[q2];
+                    v[p2] = cs * vp - sn * vq;
+                    v[q2] = sn * vp + cs * vq;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) th[i] = (m >= 2 && has[i]) ? h[i][i] - 0.0 : th[i];
+    }
+    // a Ritz value within 2 % of the cut: sharpen lambda_max before deciding (rare; only those instances move)
+    bool amb = false;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) amb = amb || (has[i] && fabs(th[i] - cutoff) < 0.02 * cutoff);
+    if (__any(amb)) {
+        for (int it = 0; it < 200; ++it) xp = matvec16<K>(xp, Ac) * sc;
+        double xq2 = xp;
+        const double lm2 = rayleigh(xq2);
+        lmax = (amb && lm2 > lmax) ? lm2 : lmax;
+        cutoff = 1e-5 * lmax;
+    }
+    // the pinv cut (osc.py:55): drop the Ritz pairs at or under 1e-5 lambda_max
+    int ncut = 0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const bool cut = has[i] && th[i] <= cutoff;
+        v[i] = cut ? v[i] : 0.0;
+        ncut += cut ? 1 : 0;
     }
     // t = P (A + sigma)^-1 P w
     double tt = w;
 #pragma unroll
-    for (int s0 = 0; s0 < 3; ++s0) tt = fma(-row_sum(v[s0] * tt), v[s0], tt);
+    for (int s0 = 0; s0 < NV; ++s0) tt = fma(-row_sum(v[s0] * tt), v[s0], tt);
     solve16<K>(tt, F, G, invd_own);
 #pragma unroll
-    for (int s0 = 0; s0 < 3; ++s0) tt = fma(-row_sum(v[s0] * tt), v[s0], tt);
+    for (int s0 = 0; s0 < NV; ++s0) tt = fma(-row_sum(v[s0] * tt), v[s0], tt);
     t = tt;
-    fl = m > 0 ? IRLOSC_FLAG_TRUNCATED : 0u;
+    fl = ncut > 0 ? IRLOSC_FLAG_TRUNCATED : 0u;
 }
 
 // Velocity limiting + gains + stiffness (osc.py:70-99,160-168) like apply_gains6 (osc_common.hpp), with the divisions
 // and square roots on the refined hardware seeds (a few ulp from the IEEE results; the IEEE sequences cost 15-25
 // instructions each and this runs on every lane).
-__device__ __forceinline__ double sqrt_fast(double x) { return x > 0.0 ? x * rsq_refined(x) : 0.0; }
 __device__ __forceinline__ void apply_gains6_fast(const double* __restrict__ g, double e[6]) {
     const double kp = g[0], kv = g[1], ko = g[2];
     if (g[11] != 0.0) {

@@ -1,12 +1,22 @@
-"""Multi-GPU sharding of a batch of independent robot instances (SURVEY.md §8e).
+"""Multi-GPU sharding of a batch of independent robot instances (SURVEY.md section 8e).
 
 The OSC path has no cross-instance term (/root/reference/irl_control/osc.py:120-210 touches one
 robot), so a node runs one process per GPU, each owning a contiguous slice of the batch; there is
-NO data-path collective.  torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo"
-in CPU tests) is used only to agree on the elapsed time (max over ranks) and to sum the processed
-steps — the "final throughput reduction" of BASELINE.json.
+NO data-path collective.  RCCL (over xGMI), driven through the C ABI (`irlosc_comm_*`,
+`irlosc_bench_allreduce`: include/irlosc.h), is used only for the "final throughput reduction" of
+BASELINE.json: sum of the steps done, max of the elapsed time, and an all-gather of per-shard output
+checksums.  No PyTorch: the launcher (`python -m torch.distributed.run`) only provides RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment.
 """
-from typing import Tuple
+import ctypes as C
+import os
+import time
+import zlib
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
 
 
 def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
@@ -18,14 +28,105 @@ def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def reduce_throughput(steps_done: float, elapsed_s: float, device=None):
-    """-> (total steps over all ranks, max elapsed over ranks, whole-job steps/s)."""
-    import torch
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+def env_world() -> Tuple[int, int, int]:
+    """(rank, world, local_rank) as the launcher exports them; (0, 1, 0) when run directly."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def checksum_u64(a: np.ndarray) -> int:
+    """Order-sensitive 64-bit checksum of an array's bytes (two CRC32 halves): equal iff bit-identical in practice."""
+    b = np.ascontiguousarray(a).view(np.uint8)
+    h = len(b) // 2
+    return (zlib.crc32(b[:h].tobytes()) << 32) | zlib.crc32(b[h:].tobytes())
+
+
+def rendezvous_path(tag: Optional[str] = None) -> str:
+    """Where rank 0 leaves the RCCL unique id for the other ranks of THIS launch: every worker of one launcher shares
+    its parent process and MASTER_PORT, so both go into the name."""
+    tag = tag or f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"irlosc_rccl_id_{tag}")
+
+
+def exchange_bytes(rank: int, payload: Optional[bytes], nbytes: int, path: str, timeout_s: float = 120.0) -> bytes:
+    """Rank 0 publishes `payload` (atomic rename), every other rank waits for it.  One node only (shared /tmp)."""
+    if rank == 0:
+        assert payload is not None and len(payload) == nbytes
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(payload)
+        os.replace(tmp, path)
+        return payload
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                data = f.read()
+            if len(data) == nbytes:
+                return data
+        except OSError:
+            pass
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError(f"rank {rank}: no rendezvous file {path} after {timeout_s:.0f} s")
+        time.sleep(0.01)
+
+
+class RcclComm:
+    """RCCL communicator of one process-per-GPU job, through libirlosc (no torch)."""
+
+    def __init__(self, rank: int, world: int, hip_device: int, tag: Optional[str] = None):
+        self.lib = _lib.load()
+        self.rank, self.world = rank, world
+        path = rendezvous_path(tag)
+        uid = None
+        if rank == 0:
+            buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+            rc = self.lib.irlosc_comm_unique_id(buf)
+            if rc != 0:
+                raise _lib.IrloscError(f"irlosc_comm_unique_id failed ({rc}): {self.lib.irlosc_comm_last_error(None).decode()}")
+            uid = bytes(buf)
+        uid = exchange_bytes(rank, uid, _lib.COMM_ID_BYTES, path)
+        h = C.c_void_p()
+        idbuf = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(uid)
+        rc = self.lib.irlosc_comm_create(hip_device, rank, world, idbuf, C.byref(h))
+        if rc != 0:
+            raise _lib.IrloscError(f"irlosc_comm_create failed ({rc}): {self.lib.irlosc_comm_last_error(None).decode()}")
+        self._h = h
+        self._path = path
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise _lib.IrloscError(f"RCCL error {rc}: {self.lib.irlosc_comm_last_error(self._h).decode()}")
+
+    def reduce(self, steps_done: float, elapsed_s: float) -> Tuple[float, float]:
+        """-> (sum of steps over ranks, max elapsed over ranks); also a barrier."""
+        s, e = C.c_double(float(steps_done)), C.c_double(float(elapsed_s))
+        self._chk(self.lib.irlosc_bench_allreduce(self._h, C.byref(s), C.byref(e)))
+        return s.value, e.value
+
+    def barrier(self):
+        self.reduce(0.0, 0.0)
+
+    def allgather_u64(self, mine: int) -> List[int]:
+        out = (C.c_uint64 * self.world)()
+        self._chk(self.lib.irlosc_comm_allgather_u64(self._h, C.c_uint64(mine & (2 ** 64 - 1)), out))
+        return [int(v) for v in out]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.irlosc_comm_destroy(self._h)
+            self._h = None
+            if self.rank == 0:
+                try:
+                    os.remove(self._path)
+                except OSError:
+                    pass
+
+
+def reduce_throughput(steps_done: float, elapsed_s: float, comm=None):
+    """-> (total steps over all ranks, max elapsed over ranks, whole-job steps/s).  `comm` = anything with
+    reduce(steps, elapsed) -> (sum, max) (RcclComm on the GPU box); None = single process."""
+    if comm is None:
         return float(steps_done), float(elapsed_s), float(steps_done) / float(elapsed_s)
-    t = torch.tensor([float(steps_done)], dtype=torch.float64, device=device)
-    e = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    dist.all_reduce(e, op=dist.ReduceOp.MAX)
-    return float(t[0]), float(e[0]), float(t[0]) / float(e[0])
+    total, worst = comm.reduce(steps_done, elapsed_s)
+    return float(total), float(worst), float(total) / float(worst)

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     txt = open(os.path.join(ROOT, "include", "irlosc.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(irlosc_[a-z_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(irlosc_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -83,3 +83,20 @@ def test_pack_gains_shapes():
     g, nk, nb = pack_gains(lay, np.full((4, 2), 200.), np.full((4, 2), 50.), np.full((4, 2), 200.),
                            [[1, 2, 3]] * 2, [[.5, 1, 1]] * 2, [[1, 5]] * 2, np.full(4, 10.0))
     assert g.shape == (4, 2, 12) and nb == 4
+
+
+def test_comm_entry_points_validate_and_need_a_gpu():
+    """irlosc_comm_* / irlosc_bench_allreduce (the RCCL throughput reduction): argument checks work without a GPU and
+    creating a communicator without one fails loudly."""
+    lib = _lib.load()
+    h = C.c_void_p()
+    idbuf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+    assert lib.irlosc_comm_create(0, 2, 2, idbuf, C.byref(h)) == -1          # rank outside world
+    assert b"rank" in lib.irlosc_comm_last_error(None)
+    assert lib.irlosc_comm_create(0, 0, 1, None, C.byref(h)) == -1
+    if lib.irlosc_device_count() < 1:
+        assert lib.irlosc_comm_create(0, 0, 1, idbuf, C.byref(h)) == -2
+        assert b"no HIP device" in lib.irlosc_comm_last_error(None)
+    s, e = C.c_double(1.0), C.c_double(1.0)
+    assert lib.irlosc_bench_allreduce(None, C.byref(s), C.byref(e)) == -1
+    lib.irlosc_comm_destroy(None)

@@ -628,3 +628,30 @@ def test_row16_rank_deficient_jacobians(lost):
     assert np.all(fl[bad] & _lib.FLAG_TRUNCATED) and np.all(fl[bad] & _lib.FLAG_PINV_BRANCH)
     err = rel_err(u[bad], ref[bad])
     assert err.max() <= TOL64, (lost, float(err.max()))
+
+
+def test_rccl_throughput_reduction_single_rank():
+    """irlosc_comm_* / irlosc_bench_allreduce on the one GPU of this box: unique id, communicator of world size 1,
+    sum / max reduction and checksum all-gather through RCCL (the N > 1 bookkeeping is covered by the gloo test)."""
+    from irl_control_amd import sharding
+    comm = sharding.RcclComm(0, 1, 0, tag=f"gputest_{__import__('os').getpid()}")
+    assert comm.reduce(123.0, 4.5) == (123.0, 4.5)
+    assert comm.allgather_u64(0xDEADBEEF12345678) == [0xDEADBEEF12345678]
+    assert sharding.reduce_throughput(100.0, 4.0, comm) == (100.0, 4.0, 25.0)
+    comm.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_tick_equals_upload_targets_step(dtype):
+    """irlosc_tick (one call, one sync) gives bit for bit what upload + set_targets + step give."""
+    lay, gains, g = synth.make_batch("k12_admit", 37, seed=3, dtype=dtype)
+    osc = BatchedOSC(lay, 64, dtype=dtype)
+    osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+    ref, fref = osc.generate_batched(g["M"], g["J"], g["dq"], g["bias"], g["ee_pose"], g["tgt_pose"], None, g["wrench"],
+                                     return_flags=True)
+    u, fl = osc.tick(g["M"], g["J"], g["dq"], g["bias"], g["ee_pose"], g["tgt_pose"], None, g["wrench"], return_flags=True)
+    assert np.array_equal(u, ref) and np.array_equal(fl, fref)
+    one = [g[k][:1] for k in ("M", "J", "dq", "bias", "ee_pose", "tgt_pose")]
+    u1 = osc.tick(*one, None, g["wrench"][:1])
+    assert np.array_equal(u1, osc.generate_batched(*one, None, g["wrench"][:1]))
+    osc.close()

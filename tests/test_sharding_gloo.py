@@ -1,7 +1,10 @@
-"""N > 1 path on CPU: two gloo ranks shard one batch, each computes its slice, and the gathered
-result equals the unsharded one bit for bit; the throughput reduction takes sum(steps) / max(time).
-(The per-slice compute here is the oracle — this test is about the sharding logic, which is what
-bench.py --gpus N uses around the HIP path.)"""
+"""N > 1 path on CPU: two ranks shard one batch, each computes its slice, and the gathered result
+equals the unsharded one bit for bit; the throughput reduction takes sum(steps) / max(time); the
+RCCL unique id travels from rank 0 to the others through the rendezvous file.  The collective itself
+is RCCL on the GPU box (irlosc_bench_allreduce, tests/test_gpu_parity.py); here a gloo communicator
+with the same reduce() contract stands in, so that sharding.reduce_throughput and bench.py's N > 1
+bookkeeping run with world_size 2.  (The per-slice compute here is the oracle: the HIP path under a
+shard is checked bit for bit on the GPU box, test_row16_ragged_batches_and_sharding_bit_exact.)"""
 import os
 import socket
 
@@ -27,6 +30,22 @@ def test_shard_range_partitions_exactly():
         sharding.shard_range(10, 2, 2)
 
 
+class GlooComm:
+    """Same contract as sharding.RcclComm.reduce / allgather_u64, over torch.distributed gloo (test stand-in)."""
+
+    def reduce(self, steps, elapsed):
+        t = torch.tensor([float(steps)], dtype=torch.float64)
+        e = torch.tensor([float(elapsed)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        return float(t[0]), float(e[0])
+
+    def allgather_u64(self, mine):
+        out = [torch.zeros(1, dtype=torch.int64) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, torch.tensor([mine - (1 << 64) if mine >= (1 << 63) else mine], dtype=torch.int64))
+        return [int(v[0]) % (1 << 64) for v in out]
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -43,8 +62,15 @@ def _worker(rank, world, port, B, out_dir):
     sizes = [sharding.shard_range(B, world, r) for r in range(world)]
     parts = [torch.zeros((h - l, 25), dtype=torch.float64) for l, h in sizes]
     dist.all_gather(parts, torch.from_numpy(np.ascontiguousarray(u))) if len(set(h - l for l, h in sizes)) == 1 else None
-    steps, elapsed, rate = sharding.reduce_throughput(hi - lo, 1.0 + rank)   # rank 1 is "slower"
+    comm = GlooComm()
+    steps, elapsed, rate = sharding.reduce_throughput(hi - lo, 1.0 + rank, comm)   # rank 1 is "slower"
+    sums = comm.allgather_u64(sharding.checksum_u64(u))
+    # the unique-id hand-over bench.py uses before irlosc_comm_create: rank 0 publishes 128 bytes, the others wait
+    uid = sharding.exchange_bytes(rank, bytes(range(128)) if rank == 0 else None, 128,
+                                  sharding.rendezvous_path(f"test_{port}"))
+    assert uid == bytes(range(128))
     if rank == 0:
+        np.save(os.path.join(out_dir, "sums.npy"), np.array(sums, dtype=np.uint64))
         np.save(os.path.join(out_dir, "gathered.npy"), torch.cat(parts).numpy())
         np.save(os.path.join(out_dir, "rate.npy"), np.array([steps, elapsed, rate]))
     dist.barrier()
@@ -61,3 +87,12 @@ def test_two_rank_sharding_is_bit_identical(tmp_path):
     assert np.array_equal(got, ref)
     steps, elapsed, rate = np.load(tmp_path / "rate.npy")
     assert steps == B and elapsed == 2.0 and rate == B / 2.0
+    sums = np.load(tmp_path / "sums.npy")
+    assert [int(v) for v in sums] == [sharding.checksum_u64(ref[lo:hi]) for lo, hi in
+                                      (sharding.shard_range(B, world, r) for r in range(world))]
+
+
+def test_reduce_throughput_single_process_and_env_defaults():
+    assert sharding.reduce_throughput(10, 2.0) == (10.0, 2.0, 5.0)
+    a = np.arange(12, dtype=np.float64)
+    assert sharding.checksum_u64(a) == sharding.checksum_u64(a.copy()) != sharding.checksum_u64(a[::-1])
