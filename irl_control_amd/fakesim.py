@@ -229,3 +229,53 @@ def randomize(sim: FakeSim, rng: np.random.Generator, wrench: bool = False):
             from .transforms import quat2mat
             d.site_xmat[s] = quat2mat(q)
     return sim
+
+
+class ToyDynamics:
+    """Deterministic stand-in for physics, for the headless tick loops (examples/headless_loops.py) and their
+    per-tick goldens: MuJoCo is in neither this image nor the GPU box.  Nothing here depends on ``ctrl``, so the state
+    trajectory is the same whichever controller drives the loop (the reference when the goldens are minted, the HIP
+    path in the tests) and the per-tick torques are comparable one to one.  Per ``sim.step()``:
+
+      * every end-effector body with a goal slides ``rate`` of the way towards it (position, and orientation along
+        the chord of the two quaternions), so the waypoint logic of gain_test has something to do;
+      * Jacobians, joint velocities and bias forces follow slow sinusoids around their initial values;
+      * the F/T sensors read the reaction to ``xfrc_applied`` on the listed bodies (the push of admit_test).
+    """
+
+    def __init__(self, rate: float = 0.05):
+        self.rate = rate
+        self.goal_xyz: Dict[str, np.ndarray] = {}
+        self.goal_quat: Dict[str, np.ndarray] = {}
+        self.ft_bodies = {"left_outer_knuckle_ur5right": 0, "left_outer_knuckle_ur5left": 6}   # body -> sensordata offset
+        self.t = 0
+        self._init = None
+
+    def __call__(self, sim, integrate: bool = False):
+        if not integrate:
+            return
+        d = sim.data
+        if self._init is None:
+            self._init = (d.body_jacp.copy(), d.body_jacr.copy(), d.qvel.copy(), d.qfrc_bias.copy(), d.sensordata.copy())
+        jp0, jr0, qv0, b0, s0 = self._init
+        self.t += 1
+        for body, xyz in self.goal_xyz.items():
+            b = sim.model.body_name2id(body)
+            d.body_xpos[b] += self.rate * (np.asarray(xyz, dtype=np.float64) - d.body_xpos[b])
+        for body, quat in self.goal_quat.items():
+            b = sim.model.body_name2id(body)
+            q, g = d.body_xquat[b], np.asarray(quat, dtype=np.float64)
+            g = g / np.linalg.norm(g)
+            if np.dot(q, g) < 0.0:
+                g = -g
+            q = q + self.rate * (g - q)
+            d.body_xquat[b] = q / np.linalg.norm(q)
+        s, c = np.sin(0.07 * self.t), np.cos(0.045 * self.t)
+        d.body_jacp[:] = jp0 * (1.0 + 0.05 * s)
+        d.body_jacr[:] = jr0 * (1.0 + 0.03 * c)
+        d.qvel[:] = qv0 * (0.98 ** self.t) + 0.05 * s
+        d.qfrc_bias[:] = b0 * (1.0 + 0.1 * c)
+        d.sensordata[:] = s0
+        for body, off in self.ft_bodies.items():
+            b = sim.model.body_name2id(body)
+            d.sensordata[off:off + 6] = s0[off:off + 6] - d.xfrc_applied[b]

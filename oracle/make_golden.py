@@ -249,6 +249,35 @@ def make_e2e_case(name, seed, B, cfg_file, target_order, dev_gain_names, nullspa
     print(f"{name:28s} B={B:3d} (end-to-end sim state) -> {os.path.getsize(path) // 1024} KiB")
 
 
+def make_loop_case(name, seed, ticks, kind, cfg_file, dev_gain_names, admittance=False, n_free_bodies=0,
+                   push_window=(0, 0)):
+    """Per-tick golden of a headless caller loop (harness rows): the REFERENCE's Device / Robot /
+    OSC driven by examples/headless_loops.py on a FakeSim with fakesim.ToyDynamics; stores the reference's forces of
+    every tick (and the waypoint indices of gain_test).  The GPU tests run the same loop on the build's classes with
+    the same seed and compare tick by tick."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import headless_loops as loops
+    rng = np.random.default_rng(seed)
+    cfg = load_cfg(cfg_file)
+    dyn = fakesim.ToyDynamics()
+    sim = fakesim.randomize(fakesim.FakeSim(n_free_bodies=n_free_bodies, dynamics=dyn), rng, wrench=admittance)
+    robot, osc = build_reference(cfg, sim, dev_gain_names, True, True, admittance)
+    if kind == "gain_test":
+        rec = loops.gain_test_loop(robot, osc, RefTarget, RefDeviceState, sim, ticks, None, dyn)
+    else:
+        rec = loops.admit_test_loop(robot, osc, RefTarget, RefDeviceState, sim, ticks, push_window, dyn)
+    meta = dict(kind=kind, seed=seed, ticks=ticks, cfg_file=cfg_file, idxs=rec["idxs"], push_window=list(push_window),
+                n_free_bodies=n_free_bodies)
+    arrays = dict(forces=np.asarray(rec["forces"], dtype=np.float64), layout_json=np.array(json.dumps(meta)))
+    if kind == "gain_test":
+        arrays["wp"] = np.asarray(rec["wp"], dtype=np.int64)
+        arrays["err"] = np.asarray(rec["err"], dtype=np.float64)
+    path = os.path.join(OUT_DIR, f"{name}.npz")
+    np.savez_compressed(path, **arrays)
+    extra = f", {int((np.diff(arrays['wp'], axis=0) != 0).sum())} waypoint switches" if kind == "gain_test" else ""
+    print(f"{name:28s} {ticks} ticks of the {kind} loop{extra} -> {os.path.getsize(path) // 1024} KiB")
+
+
 RLB = ("ur5right", "ur5left", "base")
 BRL = ("base", "ur5right", "ur5left")
 G_GAIN = [("base", "osc0"), ("ur5right", "osc2"), ("ur5left", "osc2")]
@@ -278,5 +307,9 @@ if __name__ == "__main__":
     make_e2e_case("e2e_gain_test", S + 21, 6, "default_xyz.yaml", RLB, G_GAIN)
     make_e2e_case("e2e_admit_test", S + 22, 6, "default_xyz_abg.yaml", ("ur5right", "ur5left"), G_ADMIT,
                   admittance=True, n_free_bodies=2)
+    # per-tick goldens of the two caller loops (examples/gain_test.py:98-175, examples/admit_test.py:43-80)
+    make_loop_case("loop_gain_test", 0, 160, "gain_test", "default_xyz.yaml", G_GAIN)
+    make_loop_case("loop_admit_test", 0, 120, "admit_test", "default_xyz_abg.yaml", G_ADMIT, admittance=True,
+                   n_free_bodies=2, push_window=(40, 80))
     make_case("k13_no_max_vel", S + 12, 8, "default_xyz_abg.yaml", RLB, G_GAIN, all_actuated=True,
               no_max_vel=("ur5left",))

@@ -26,7 +26,7 @@ def pytest_sessionstart(session):
 
 
 def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith("e2e_"))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith(("e2e_", "loop_")))
 
 
 def load_e2e(name):

@@ -655,3 +655,52 @@ def test_tick_equals_upload_targets_step(dtype):
     u1 = osc.tick(*one, None, g["wrench"][:1])
     assert np.array_equal(u1, osc.generate_batched(*one, None, g["wrench"][:1]))
     osc.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# Caller loops (harness rows): per-tick goldens minted by the reference
+# ------------------------------------------------------------------------------------------------
+def _load_example(name):
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", name + ".py")
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _load_loop_golden(name):
+    import json
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    return {k: z[k] for k in z.files if k != "layout_json"}, json.loads(str(z["layout_json"]))
+
+
+def test_gain_test_loop_matches_reference_tick_by_tick():
+    """examples/gain_test.py:98-175 headless: 160 ticks, the reference's forces of EVERY tick (minted by
+    oracle/make_golden.py with the reference's own OSC on the same FakeSim + ToyDynamics) against OSC.generate on the
+    HIP path; also the waypoint indices, i.e. the caller-side logic that reads Device state between ticks."""
+    g, meta = _load_loop_golden("loop_gain_test")
+    mod = _load_example("gain_test_headless")
+    rec = mod.run(ticks=meta["ticks"], demo="gain_test", seed=meta["seed"], robot_config=meta["cfg_file"], verbose=False)
+    assert rec["idxs"] == meta["idxs"]
+    assert np.array_equal(rec["wp"], g["wp"]) and (np.diff(g["wp"], axis=0) != 0).sum() >= 2
+    assert np.allclose(rec["err"], g["err"], rtol=0, atol=1e-12)
+    err = np.abs(rec["forces"] - g["forces"]).max(axis=1) / np.abs(g["forces"]).max(axis=1)
+    assert err.max() <= TOL64, float(err.max())
+
+
+def test_admit_test_loop_matches_reference_tick_by_tick():
+    """examples/admit_test.py:43-80 headless: admittance on, left arm abg = [0, -pi/2, 0], push on the left gripper
+    during ticks 40..80 of 120; every tick's forces against the reference's, and the push must be visible in them."""
+    g, meta = _load_loop_golden("loop_admit_test")
+    mod = _load_example("admit_test_headless")
+    rec = mod.run(ticks=meta["ticks"], push_window=tuple(meta["push_window"]), seed=meta["seed"], verbose=False)
+    assert rec["idxs"] == meta["idxs"]
+    err = np.abs(rec["forces"] - g["forces"]).max(axis=1) / np.abs(g["forces"]).max(axis=1)
+    assert err.max() <= TOL64, float(err.max())
+    lo, hi = meta["push_window"]
+    jump_in = np.abs(g["forces"][lo + 1] - g["forces"][lo]).max()        # first tick that sees the wrench
+    jump_before = np.abs(g["forces"][lo] - g["forces"][lo - 1]).max()
+    assert jump_in > 2 * jump_before

@@ -105,3 +105,30 @@ def test_osc_ctor_mutates_gain_dicts_like_reference():
     ic.OSC(app.get_robot("DualUR5"), app.sim, [("ur5right", g)])
     assert np.array_equal(g["task_space_gains"], [200] * 6)
     assert np.allclose(g["lamb"], np.array([200] * 6) / 50)
+
+
+def test_full_mass_matrix_dispatches_on_the_sim_object(monkeypatch):
+    """the backend is picked by what `sim` is, not by which package imports.  A mujoco_py-style sim must go
+    to mujoco_py.cymj._mj_fullM even when a module called `mujoco` is importable, and vice versa."""
+    import sys
+    import types
+    from irl_control_amd import backend
+    calls = []
+    fake_mujoco = types.ModuleType("mujoco")
+    fake_mujoco.mj_fullM = lambda model, dst, qM: (calls.append("mujoco"), dst.__setitem__(slice(None), 2.0))
+    fake_py = types.ModuleType("mujoco_py")
+    fake_py.cymj = types.SimpleNamespace(_mj_fullM=lambda model, dst, qM: (calls.append("mujoco_py"), dst.__setitem__(slice(None), 3.0)))
+    monkeypatch.setitem(sys.modules, "mujoco", fake_mujoco)
+    monkeypatch.setitem(sys.modules, "mujoco_py", fake_py)
+    PyModel = type("PyMjModel", (), {"nv": 2, "__module__": "mujoco_py.cymj"})
+    OffModel = type("MjModel", (), {"nv": 2, "__module__": "mujoco._structs"})
+    data = types.SimpleNamespace(qM=np.zeros(3))
+    out = np.zeros(4)
+    assert backend.backend_of(types.SimpleNamespace(model=PyModel(), data=data)) == "mujoco_py"
+    backend.full_mass_matrix(types.SimpleNamespace(model=PyModel(), data=data), out)
+    assert calls == ["mujoco_py"] and np.all(out == 3.0)
+    backend.full_mass_matrix(types.SimpleNamespace(model=OffModel(), data=data), out)
+    assert calls == ["mujoco_py", "mujoco"] and np.all(out == 2.0)
+    inj = types.SimpleNamespace(model=PyModel(), data=data, fullM=lambda: np.eye(2))
+    backend.full_mass_matrix(inj, out)
+    assert calls == ["mujoco_py", "mujoco"] and np.array_equal(out, np.eye(2).reshape(-1))
