@@ -190,6 +190,45 @@ int irlosc_step_device(irlosc_ctx* ctx, int32_t B, const void* dM, const void* d
                        const void* dtgt_vel, const void* dwrench, void* du, uint32_t* dflags,
                        void* hip_stream);
 
+/* ---- rigid-body front end: joint coordinates in, records assembled on the GPU -----------
+ * Replaces the per-tick reads the reference makes from MuJoCo on the host - mj_fullM (robot.py:68-72), the EE-body
+ * Jacobians jacp / jacr (device.py:115-133), qfrc_bias (osc.py:190-191), EE xpos / xquat (device.py:97-99) - by forward
+ * kinematics, Jacobians, composite-rigid-body M and recursive-Newton-Euler bias forces computed from (qpos, qvel) for the
+ * whole batch.  The model is a tree of bodies, each welded to its parent or attached by ONE hinge (MuJoCo conventions:
+ * body frame pos + quat relative to the parent, hinge axis / anchor in the body frame, inertial frame ipos + iquat with
+ * principal moments, quaternions w x y z).  Bodies must be listed parents first (MuJoCo's numbering does that);
+ * joint j of the model is position j of the n-vector (n = cfg.n).  ee_body[d] = body whose frame is target device d's
+ * end effector (targets order).  The F/T wrench is not a function of (qpos, qvel): it stays whatever irlosc_upload /
+ * irlosc_upload_raw last put into the slot (absent: zero). */
+#define IRLOSC_MAX_BODIES 64
+typedef struct irlosc_model {
+    int32_t nb;                               /* bodies, <= IRLOSC_MAX_BODIES */
+    int32_t nj;                               /* hinges, must equal cfg.n */
+    int32_t parent[IRLOSC_MAX_BODIES];        /* -1 = world */
+    int32_t joint_of_body[IRLOSC_MAX_BODIES]; /* hinge index, or -1 = welded to the parent */
+    double pos[IRLOSC_MAX_BODIES][3];
+    double quat[IRLOSC_MAX_BODIES][4];
+    double jaxis[IRLOSC_MAX_N][3];            /* unit axis, body frame */
+    double jpos[IRLOSC_MAX_N][3];             /* anchor, body frame */
+    double armature[IRLOSC_MAX_N];
+    double mass[IRLOSC_MAX_BODIES];
+    double ipos[IRLOSC_MAX_BODIES][3];
+    double iquat[IRLOSC_MAX_BODIES][4];
+    double inertia[IRLOSC_MAX_BODIES][3];     /* principal moments in the inertial frame */
+    double gravity[3];
+    int32_t ee_body[IRLOSC_MAX_DEV];
+} irlosc_model;
+int irlosc_set_model(irlosc_ctx* ctx, const irlosc_model* model);
+/* Joint positions and velocities of one batch into resident slot `slot`: qpos[B][n], qvel[B][n], always double. */
+int irlosc_upload_q(irlosc_ctx* ctx, int32_t slot, int32_t B, const double* qpos, const double* qvel);
+/* Run the front end on the slot's (qpos, qvel): fills its M, J, dq, bias, ee_pose records (asynchronous, context's
+ * stream); irlosc_set_targets + irlosc_step then work as after irlosc_upload. */
+int irlosc_frontend(irlosc_ctx* ctx, int32_t slot, int32_t B);
+/* Benchmark form of the whole path from joint coordinates: `iters` x (front end + step) on resident (qpos, qvel),
+ * slot = (first_slot + i) % n_slots; HIP-event time of the region on the library's stream. */
+int irlosc_step_resident_from_q(irlosc_ctx* ctx, int32_t first_slot, int32_t B, int32_t iters, float* ms_total,
+                                float* ms_step_avg);
+
 /* ---- multi-GPU: the final throughput reduction -----------------------------------------------
  * Instances are independent (osc.py:120-210 touches one robot), so a node runs one process per GPU on its own shard
  * and NOTHING is exchanged per tick.  RCCL (over xGMI) is used once per benchmark: sum of the steps done, max of the

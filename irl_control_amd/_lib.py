@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IRLOSC_LIB", os.path.join(_HERE, "libirlosc.so"))   # override: A/B builds only
 
-MAX_DEV, MAX_N, MAX_K, GAIN_WORDS = 4, 32, 16, 12
+MAX_DEV, MAX_N, MAX_K, GAIN_WORDS, MAX_BODIES = 4, 32, 16, 12, 64
 F32, F64 = 0, 1
 USE_G, ADMITTANCE, NULLSPACE = 1, 2, 4
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_GROUP, KERNEL_ROW16 = 0, 1, 2, 3
@@ -21,7 +21,8 @@ EXPORTS = ["irlosc_abi_version", "irlosc_device_count", "irlosc_create", "irlosc
            "irlosc_sync", "irlosc_step_device", "irlosc_time_dominant_kernel",
            "irlosc_steps_per_launch", "irlosc_upload_raw", "irlosc_assemble_device", "irlosc_device_sync",
            "irlosc_tick", "irlosc_comm_unique_id", "irlosc_comm_create", "irlosc_comm_destroy",
-           "irlosc_comm_last_error", "irlosc_bench_allreduce", "irlosc_comm_allgather_u64"]
+           "irlosc_comm_last_error", "irlosc_bench_allreduce", "irlosc_comm_allgather_u64", "irlosc_set_model",
+           "irlosc_upload_q", "irlosc_frontend", "irlosc_step_resident_from_q"]
 COMM_ID_BYTES = 128
 
 
@@ -29,6 +30,16 @@ class RawDesc(C.Structure):
     """struct irlosc_raw_desc (include/irlosc.h)."""
     _fields_ = [("nv", C.c_int32), ("n_sensor", C.c_int32), ("joint_ids", C.c_int32 * 32),
                 ("dq_src", C.c_int32 * 32), ("ft_force0", C.c_int32 * 4), ("ft_torque0", C.c_int32 * 4)]
+
+
+class Model(C.Structure):
+    """struct irlosc_model (include/irlosc.h)."""
+    _fields_ = [("nb", C.c_int32), ("nj", C.c_int32), ("parent", C.c_int32 * MAX_BODIES),
+                ("joint_of_body", C.c_int32 * MAX_BODIES), ("pos", (C.c_double * 3) * MAX_BODIES),
+                ("quat", (C.c_double * 4) * MAX_BODIES), ("jaxis", (C.c_double * 3) * MAX_N),
+                ("jpos", (C.c_double * 3) * MAX_N), ("armature", C.c_double * MAX_N), ("mass", C.c_double * MAX_BODIES),
+                ("ipos", (C.c_double * 3) * MAX_BODIES), ("iquat", (C.c_double * 4) * MAX_BODIES),
+                ("inertia", (C.c_double * 3) * MAX_BODIES), ("gravity", C.c_double * 3), ("ee_body", C.c_int32 * MAX_DEV)]
 
 
 class Cfg(C.Structure):
@@ -80,6 +91,10 @@ def load():
     lib.irlosc_sync.argtypes = [vp]
     lib.irlosc_step_device.argtypes = [vp, i32] + [vp] * 11
     lib.irlosc_device_sync.argtypes = [vp]
+    lib.irlosc_set_model.argtypes = [vp, C.POINTER(Model)]
+    lib.irlosc_upload_q.argtypes = [vp, i32, i32, vp, vp]
+    lib.irlosc_frontend.argtypes = [vp, i32, i32]
+    lib.irlosc_step_resident_from_q.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.irlosc_tick.argtypes = [vp, i32] + [vp] * 10
     lib.irlosc_comm_unique_id.argtypes = [vp]
     lib.irlosc_comm_create.argtypes = [i32, i32, i32, vp, C.POINTER(vp)]

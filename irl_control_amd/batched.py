@@ -142,6 +142,43 @@ class BatchedOSC:
         self._chk(self.lib.irlosc_download(self._h, B, _lib.ptr(u), _lib.ptr(fl)))
         return u, fl
 
+    # -- rigid-body front end: joint coordinates in, records assembled on the GPU ------------------------------------
+    def set_model(self, model, ee_bodies=None):
+        """`model`: rigid_body.RigidBodyModel; `ee_bodies`: EE body name per target device (targets order), default the
+        Dual-UR5 map."""
+        from .rigid_body import DUAL_UR5_EE
+        names = ee_bodies if ee_bodies is not None else [DUAL_UR5_EE[d] for d in self.layout.dev_names]
+        st = model.to_struct(list(names))
+        self._chk(self.lib.irlosc_set_model(self._h, C.byref(st)))
+        self._model = model
+
+    def upload_q(self, qpos, qvel, slot: int = 0):
+        B = int(np.shape(qpos)[0])
+        qp = np.ascontiguousarray(qpos, dtype=np.float64)
+        qv = np.ascontiguousarray(qvel, dtype=np.float64)
+        if qp.shape != (B, self.layout.n) or qv.shape != (B, self.layout.n):
+            raise ValueError(f"qpos / qvel: expected shape {(B, self.layout.n)}")
+        self._chk(self.lib.irlosc_upload_q(self._h, slot, B, _lib.ptr(qp), _lib.ptr(qv)))
+        self._B[slot] = B
+
+    def frontend(self, slot: int = 0):
+        """(qpos, qvel) of the slot -> its M, J, dq, bias, ee_pose records (on the GPU)."""
+        self._chk(self.lib.irlosc_frontend(self._h, slot, self._B[slot]))
+
+    def step_from_q(self, qpos, qvel, tgt_pose, tgt_vel=None, return_flags: bool = False):
+        """One tick from joint coordinates: upload (qpos, qvel), front end, step, download."""
+        self.upload_q(qpos, qvel)
+        self.frontend()
+        self.set_targets(tgt_pose, tgt_vel)
+        return self.step(return_flags=return_flags)
+
+    def step_resident_from_q(self, iters: int, first_slot: int = 0, B: Optional[int] = None):
+        """-> (ms_total, ms_per_step): `iters` x (front end + step) on resident joint coordinates, HIP-event timed."""
+        B = self._B[first_slot] if B is None else B
+        t, a = C.c_float(), C.c_float()
+        self._chk(self.lib.irlosc_step_resident_from_q(self._h, first_slot, B, iters, C.byref(t), C.byref(a)))
+        return t.value, a.value
+
     def sync(self):
         self._chk(self.lib.irlosc_sync(self._h))
 

@@ -19,6 +19,7 @@
 #include "osc_group.hpp"
 #include "osc_assemble.hpp"
 #include "osc_row16.hpp"
+#include "osc_frontend.hpp"
 
 using namespace irlosc;
 
@@ -65,6 +66,10 @@ struct irlosc_ctx {
     int32_t* dr16_list = nullptr;
     int32_t* dr16_count = nullptr;
     int r16_parity = 0;
+    // rigid-body front end (irlosc_set_model): device copy of the tables, resident joint coordinates per slot
+    FeModel* dmodel = nullptr;
+    std::vector<double*> dqpos, dqvel;
+    std::vector<int> has_q;
     // irlosc_tick: one pinned host block and one device block per direction, grown on demand
     void* tick_hin = nullptr; void* tick_din = nullptr; size_t tick_in_bytes = 0;
     void* tick_hout = nullptr; void* tick_dout = nullptr; size_t tick_out_bytes = 0;
@@ -154,6 +159,9 @@ static void free_all(irlosc_ctx* c) {
     for (int k = 0; k < irlosc_ctx::NTABLES; ++k)
         if (c->dtable[k]) (void)hipFree(c->dtable[k]);
     if (c->draw) (void)hipFree(c->draw);
+    if (c->dmodel) (void)hipFree(c->dmodel);
+    for (double* p : c->dqpos) if (p) (void)hipFree(p);
+    for (double* p : c->dqvel) if (p) (void)hipFree(p);
     if (c->tick_hin) (void)hipHostFree(c->tick_hin);
     if (c->tick_din) (void)hipFree(c->tick_din);
     if (c->tick_hout) (void)hipHostFree(c->tick_hout);
@@ -813,6 +821,127 @@ extern "C" int irlosc_sync(irlosc_ctx* c) {
     if (!c) return IRLOSC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.hip_device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return IRLOSC_OK;
+}
+
+// ---- rigid-body front end ------------------------------------------------------------------------------------------
+extern "C" int irlosc_set_model(irlosc_ctx* c, const irlosc_model* m) {
+    if (!c) return IRLOSC_ERR_ARG;
+    if (!m) return fail(c, IRLOSC_ERR_ARG, "model is NULL");
+    if (m->nb < 1 || m->nb > IRLOSC_MAX_BODIES) return fail(c, IRLOSC_ERR_ARG, "nb=%d out of [1,%d]", m->nb, IRLOSC_MAX_BODIES);
+    if (m->nj != c->cfg.n) return fail(c, IRLOSC_ERR_ARG, "model has %d hinges but cfg.n = %d", m->nj, c->cfg.n);
+    FeModel h;
+    memset(&h, 0, sizeof h);
+    h.nb = m->nb; h.nj = m->nj; h.ndev = c->cfg.ndev; h.k = c->k;
+    std::vector<int> seen(m->nj, 0);
+    for (int b = 0; b < m->nb; ++b) {
+        const int par = m->parent[b], jb = m->joint_of_body[b];
+        if (par >= b || par < -1) return fail(c, IRLOSC_ERR_ARG, "body %d: parent %d must precede it (or be -1)", b, par);
+        if (jb < -1 || jb >= m->nj) return fail(c, IRLOSC_ERR_ARG, "body %d: hinge index %d out of range", b, jb);
+        if (jb >= 0 && seen[jb]++) return fail(c, IRLOSC_ERR_ARG, "hinge %d sits on two bodies", jb);
+        if (!(m->mass[b] >= 0.0)) return fail(c, IRLOSC_ERR_ARG, "body %d: negative mass", b);
+        h.parent[b] = par; h.joint_of_body[b] = jb;
+        h.depth[b] = par < 0 ? 0 : h.depth[par] + 1;
+        h.maxdepth = std::max(h.maxdepth, h.depth[b]);
+        h.anc_mask[b] = (par < 0 ? 0u : h.anc_mask[par]) | (jb >= 0 ? 1u << jb : 0u);
+        if (jb >= 0) h.body_of_joint[jb] = b;
+        for (int i = 0; i < 3; ++i) { h.pos[b][i] = m->pos[b][i]; h.ipos[b][i] = m->ipos[b][i]; h.inertia[b][i] = m->inertia[b][i]; }
+        for (int i = 0; i < 4; ++i) { h.quat[b][i] = m->quat[b][i]; h.iquat[b][i] = m->iquat[b][i]; }
+        h.mass[b] = m->mass[b];
+    }
+    for (int j = 0; j < m->nj; ++j) {
+        if (!seen[j]) return fail(c, IRLOSC_ERR_ARG, "hinge %d sits on no body", j);
+        for (int i = 0; i < 3; ++i) { h.jaxis[j][i] = m->jaxis[j][i]; h.jpos[j][i] = m->jpos[j][i]; }
+        h.armature[j] = m->armature[j];
+        for (int b = 0; b < m->nb; ++b) if ((h.anc_mask[b] >> j) & 1u) h.sub_mask[j] |= 1ull << b;
+    }
+    for (int i = 0; i < 3; ++i) h.gravity[i] = m->gravity[i];
+    int row = 0;
+    for (int d = 0; d < c->cfg.ndev; ++d) {
+        if (m->ee_body[d] < 0 || m->ee_body[d] >= m->nb) return fail(c, IRLOSC_ERR_ARG, "ee_body[%d]=%d out of range", d, m->ee_body[d]);
+        h.ee_body[d] = m->ee_body[d];
+        h.row0[d] = row; row += c->cfg.dev_rows[d];
+        for (int i = 0; i < 6; ++i) if (c->cfg.ctrlr_dof[d][i]) h.dofmask[d] |= 1u << i;
+    }
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    if (!c->dmodel) HIPCHK(c, hipMalloc((void**)&c->dmodel, sizeof(FeModel)));
+    HIPCHK(c, hipMemcpyAsync(c->dmodel, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->dqpos.empty()) {
+        c->dqpos.assign(c->cfg.n_slots, nullptr);
+        c->dqvel.assign(c->cfg.n_slots, nullptr);
+        c->has_q.assign(c->cfg.n_slots, 0);
+        for (int s2 = 0; s2 < c->cfg.n_slots; ++s2) {
+            HIPCHK(c, hipMalloc((void**)&c->dqpos[s2], (size_t)c->cfg.max_batch * c->cfg.n * sizeof(double)));
+            HIPCHK(c, hipMalloc((void**)&c->dqvel[s2], (size_t)c->cfg.max_batch * c->cfg.n * sizeof(double)));
+        }
+    }
+    return IRLOSC_OK;
+}
+
+extern "C" int irlosc_upload_q(irlosc_ctx* c, int32_t slot, int32_t B, const double* qpos, const double* qvel) {
+    if (!c) return IRLOSC_ERR_ARG;
+    int rc = check_slot(c, slot, B);
+    if (rc) return rc;
+    if (!c->dmodel) return fail(c, IRLOSC_ERR_STATE, "irlosc_set_model has not been called");
+    if (B == 0) { c->has_q[slot] = 1; return IRLOSC_OK; }
+    if (!qpos || !qvel) return fail(c, IRLOSC_ERR_ARG, "qpos and qvel are required");
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    const size_t bytes = (size_t)B * c->cfg.n * sizeof(double);
+    HIPCHK(c, hipMemcpyAsync(c->dqpos[slot], qpos, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dqvel[slot], qvel, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->has_q[slot] = 1;
+    return IRLOSC_OK;
+}
+
+static int frontend_launch(irlosc_ctx* c, int slot, int B) {
+    if (!c->dmodel) return fail(c, IRLOSC_ERR_STATE, "irlosc_set_model has not been called");
+    if (!c->has_q[slot]) return fail(c, IRLOSC_ERR_STATE, "slot %d: irlosc_upload_q must precede irlosc_frontend", slot);
+    if (B == 0) { c->uploaded[slot] = 1; return IRLOSC_OK; }
+    const dim3 grid(std::min(B, 1 << 20));
+    if (c->cfg.dtype == IRLOSC_F64) {
+        const FeOut<double> o{(double*)c->dM[slot], (double*)c->dJ[slot], (double*)c->ddq[slot], (double*)c->dbias[slot], (double*)c->dee[slot]};
+        hipLaunchKernelGGL(osc_frontend_kernel<double>, grid, dim3(64), 0, c->stream, c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B);
+    } else {
+        const FeOut<float> o{(float*)c->dM[slot], (float*)c->dJ[slot], (float*)c->ddq[slot], (float*)c->dbias[slot], (float*)c->dee[slot]};
+        hipLaunchKernelGGL(osc_frontend_kernel<float>, grid, dim3(64), 0, c->stream, c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->uploaded[slot] = 1;
+    return IRLOSC_OK;
+}
+
+extern "C" int irlosc_frontend(irlosc_ctx* c, int32_t slot, int32_t B) {
+    if (!c) return IRLOSC_ERR_ARG;
+    int rc = check_slot(c, slot, B);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    return frontend_launch(c, slot, B);
+}
+
+extern "C" int irlosc_step_resident_from_q(irlosc_ctx* c, int32_t first_slot, int32_t B, int32_t iters, float* ms_total,
+                                           float* ms_step_avg) {
+    if (!c) return IRLOSC_ERR_ARG;
+    int rc = check_slot(c, first_slot, B);
+    if (rc) return rc;
+    if (iters < 1) return fail(c, IRLOSC_ERR_ARG, "iters must be >= 1");
+    if (c->gains_nb == 0) return fail(c, IRLOSC_ERR_STATE, "irlosc_set_gains has not been called");
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < iters; ++i) {
+        const int slot = (first_slot + i) % c->cfg.n_slots;
+        rc = frontend_launch(c, slot, B);
+        if (rc) return rc;
+        rc = launch_slot(c, slot, B);
+        if (rc) return rc;
+    }
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (ms_total) *ms_total = ms;
+    if (ms_step_avg) *ms_step_avg = ms / (float)iters;
     return IRLOSC_OK;
 }
 

@@ -1,0 +1,285 @@
+// Rigid-body front end: joint coordinates in, the resident OSC records out.
+//
+// What the reference pulls out of MuJoCo on the host for every robot and tick,
+//   M     = mj_fullM(qM)[ids][:, ids]                         robot.py:68-72
+//   J_d   = vstack(jacp(EE_d), jacr(EE_d))[ctrlr_dof]         device.py:115-133, osc.py:134-138
+//   dq    = qvel, bias = qfrc_bias                            robot.py:60-65, osc.py:190-191
+//   pose  = xpos / xquat of the EE bodies                     device.py:97-99
+// computed on the GPU from (qpos, qvel) for a batch, so that 4.3 KB of records per robot and tick no longer cross PCIe
+// (2 x 25 coordinates do).  Forward kinematics, EE Jacobians, composite-rigid-body M and recursive-Newton-Euler bias
+// for a tree of hinge joints (irl_control_amd/models/dual_ur5.json <- scenes/dual_ur5.xml:51-265), fp64 arithmetic.
+//
+// Formulation: everything in WORLD coordinates with spatial vectors taken about the world origin
+// (angular, linear-at-origin), which turns every tree recursion but the kinematic chain itself into a masked sum:
+//   S_j = (a_j, p_j x a_j)                      motion vector of hinge j (axis a_j through p_j)
+//   v_b = sum_{j moves b} S_j qd_j              body velocities
+//   c_j = (v_parent(j) x S_j) qd_j              velocity-product accelerations;  a_b = (0, -g) + sum_{j moves b} c_j
+//   f_b = I_b a_b + v_b x* I_b v_b              bias_j = S_j . sum_{b under j} f_b
+//   F_j = (sum_{b under j} I_b) S_j             M[i][j] = S_i . F_j   for i on the path from j to the root
+// One 64-lane wave per instance: lane = body (<= 64) in the body phases, lane = joint (<= 32) in the joint phases,
+// tables and intermediates in LDS.  This kernel is arithmetic-bound and small next to the OSC step.
+#pragma once
+#include "osc_common.hpp"
+
+namespace irlosc {
+
+constexpr int FE_MAXB = 64;      // bodies
+constexpr int FE_MAXJ = IRLOSC_MAX_N;
+
+// Device-side model tables (one copy per context, read through the constant address space: uniform indices).
+struct FeModel {
+    int32_t nb, nj, maxdepth, ndev;
+    int32_t parent[FE_MAXB];
+    int32_t joint_of_body[FE_MAXB];      // -1: welded to its parent
+    int32_t depth[FE_MAXB];
+    int32_t body_of_joint[FE_MAXJ];
+    uint32_t anc_mask[FE_MAXB];          // bit j: joint j moves body b
+    uint64_t sub_mask[FE_MAXJ];          // bit b: body b is under joint j
+    double pos[FE_MAXB][3], quat[FE_MAXB][4];
+    double jaxis[FE_MAXJ][3], jpos[FE_MAXJ][3], armature[FE_MAXJ];
+    double mass[FE_MAXB], ipos[FE_MAXB][3], iquat[FE_MAXB][4], inertia[FE_MAXB][3];
+    double gravity[3];
+    int32_t ee_body[IRLOSC_MAX_DEV];
+    uint32_t dofmask[IRLOSC_MAX_DEV];
+    int32_t row0[IRLOSC_MAX_DEV];
+    int32_t k;
+    int32_t pad;
+};
+
+struct V3 { double x, y, z; };
+__device__ __forceinline__ V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(double s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 ld3(const double* p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ void st3(double* p, V3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+
+struct Q4 { double w, x, y, z; };
+__device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
+    return Q4{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+              a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ Q4 qnormalized(Q4 q) {
+    const double r = 1.0 / sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    return Q4{q.w * r, q.x * r, q.y * r, q.z * r};
+}
+// rotation matrix of a unit quaternion, row major into m[9]
+__device__ __forceinline__ void q2m(Q4 q, double* m) {
+    m[0] = 1 - 2 * (q.y * q.y + q.z * q.z); m[1] = 2 * (q.x * q.y - q.w * q.z); m[2] = 2 * (q.x * q.z + q.w * q.y);
+    m[3] = 2 * (q.x * q.y + q.w * q.z); m[4] = 1 - 2 * (q.x * q.x + q.z * q.z); m[5] = 2 * (q.y * q.z - q.w * q.x);
+    m[6] = 2 * (q.x * q.z - q.w * q.y); m[7] = 2 * (q.y * q.z + q.w * q.x); m[8] = 1 - 2 * (q.x * q.x + q.y * q.y);
+}
+__device__ __forceinline__ V3 mv(const double* m, V3 a) {
+    return V3{m[0] * a.x + m[1] * a.y + m[2] * a.z, m[3] * a.x + m[4] * a.y + m[5] * a.z, m[6] * a.x + m[7] * a.y + m[8] * a.z};
+}
+// momentum (angular about the origin, linear) of a body (mass m, centre c, symmetric inertia Ic about c: xx xy xz yy yz zz)
+// moving with the spatial velocity (w, v)
+__device__ __forceinline__ void inertia_apply(double m, V3 c, const double* Ic, V3 w, V3 v, V3& n, V3& f) {
+    f = m * (v + cross(w, c));
+    const V3 Iw = V3{Ic[0] * w.x + Ic[1] * w.y + Ic[2] * w.z, Ic[1] * w.x + Ic[3] * w.y + Ic[4] * w.z,
+                     Ic[2] * w.x + Ic[4] * w.y + Ic[5] * w.z};
+    n = Iw + cross(c, f);
+}
+
+template <typename TOUT>
+struct FeOut { TOUT* M; TOUT* J; TOUT* dq; TOUT* bias; TOUT* ee; };
+
+template <typename TOUT>
+__global__ __launch_bounds__(64) void osc_frontend_kernel(const FeModel* __restrict__ model_, const double* __restrict__ qpos,
+                                                          const double* __restrict__ qvel, const FeOut<TOUT> out, const int B) {
+    typedef const __attribute__((address_space(4))) FeModel* cmodel_t;
+    const cmodel_t md = (cmodel_t)model_;
+    __shared__ double s_q[FE_MAXJ], s_qd[FE_MAXJ];
+    __shared__ double s_xpos[FE_MAXB][3], s_xmat[FE_MAXB][9], s_xq[FE_MAXB][4];
+    __shared__ double s_a[FE_MAXJ][3], s_p[FE_MAXJ][3], s_sv[FE_MAXJ][3];      // axis, anchor, p x a
+    __shared__ double s_c[FE_MAXB][3], s_Ic[FE_MAXB][6];
+    __shared__ double s_vw[FE_MAXB][3], s_vv[FE_MAXB][3];
+    __shared__ double s_cw[FE_MAXJ][3], s_cv[FE_MAXJ][3];
+    __shared__ double s_fn[FE_MAXB][3], s_ff[FE_MAXB][3];
+    __shared__ double s_Fn[FE_MAXJ][3], s_Ff[FE_MAXJ][3];
+    const int lane = threadIdx.x;
+    const int nb = md->nb, nj = md->nj;
+    for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
+        if (lane < nj) {
+            s_q[lane] = qpos[(size_t)inst * nj + lane];
+            s_qd[lane] = qvel[(size_t)inst * nj + lane];
+        }
+        __syncthreads();
+        // ---- forward kinematics, one tree level per round (lane = body) -------------------------------------------
+        const int b = lane;
+        const bool isb = b < nb;
+        const int dep = isb ? md->depth[b] : -1;
+        const int jb = isb ? md->joint_of_body[b] : -1;
+        for (int lev = 0; lev <= md->maxdepth; ++lev) {
+            if (isb && dep == lev) {
+                const int par = md->parent[b];
+                V3 pp = v3(0, 0, 0);
+                Q4 pq = Q4{1, 0, 0, 0};
+                double pm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+                if (par >= 0) {
+                    pp = ld3(s_xpos[par]);
+                    pq = Q4{s_xq[par][0], s_xq[par][1], s_xq[par][2], s_xq[par][3]};
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) pm[i] = s_xmat[par][i];
+                }
+                const V3 x0 = pp + mv(pm, v3(md->pos[b][0], md->pos[b][1], md->pos[b][2]));
+                const Q4 q0 = qmul(pq, Q4{md->quat[b][0], md->quat[b][1], md->quat[b][2], md->quat[b][3]});
+                Q4 qb = qnormalized(q0);
+                V3 xb = x0;
+                double m9[9];
+                if (jb >= 0) {
+                    double m0[9];
+                    q2m(q0, m0);
+                    const V3 jp = v3(md->jpos[jb][0], md->jpos[jb][1], md->jpos[jb][2]);
+                    const V3 ax = v3(md->jaxis[jb][0], md->jaxis[jb][1], md->jaxis[jb][2]);
+                    const V3 anchor = x0 + mv(m0, jp);
+                    const V3 aw = mv(m0, ax);
+                    double sn, cs;
+                    sincos(0.5 * s_q[jb], &sn, &cs);
+                    qb = qnormalized(qmul(q0, Q4{cs, sn * ax.x, sn * ax.y, sn * ax.z}));
+                    q2m(qb, m9);
+                    xb = anchor - mv(m9, jp);
+                    st3(s_a[jb], aw);
+                    st3(s_p[jb], anchor);
+                    st3(s_sv[jb], cross(anchor, aw));
+                } else {
+                    q2m(qb, m9);
+                }
+                st3(s_xpos[b], xb);
+                s_xq[b][0] = qb.w; s_xq[b][1] = qb.x; s_xq[b][2] = qb.y; s_xq[b][3] = qb.z;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) s_xmat[b][i] = m9[i];
+            }
+            __syncthreads();
+        }
+        // ---- per body: centre of mass, world inertia, spatial velocity ---------------------------------------------
+        double mass = 0.0;
+        if (isb) {
+            mass = md->mass[b];
+            const V3 c = ld3(s_xpos[b]) + mv(s_xmat[b], v3(md->ipos[b][0], md->ipos[b][1], md->ipos[b][2]));
+            st3(s_c[b], c);
+            double mi[9], R[9];
+            q2m(Q4{md->iquat[b][0], md->iquat[b][1], md->iquat[b][2], md->iquat[b][3]}, mi);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc)
+                    R[r * 3 + cc] = s_xmat[b][r * 3] * mi[cc] + s_xmat[b][r * 3 + 1] * mi[3 + cc] + s_xmat[b][r * 3 + 2] * mi[6 + cc];
+            }
+            const double d0 = md->inertia[b][0], d1 = md->inertia[b][1], d2 = md->inertia[b][2];
+            int e = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int cc = r; cc < 3; ++cc)
+                    s_Ic[b][e++] = R[r * 3] * d0 * R[cc * 3] + R[r * 3 + 1] * d1 * R[cc * 3 + 1] + R[r * 3 + 2] * d2 * R[cc * 3 + 2];
+            }
+            V3 vw = v3(0, 0, 0), vv = v3(0, 0, 0);
+            const uint32_t am = md->anc_mask[b];
+            for (int j = 0; j < nj; ++j) {
+                if ((am >> j) & 1u) {
+                    const double qd = s_qd[j];
+                    vw = vw + qd * ld3(s_a[j]);
+                    vv = vv + qd * ld3(s_sv[j]);
+                }
+            }
+            st3(s_vw[b], vw);
+            st3(s_vv[b], vv);
+        }
+        __syncthreads();
+        // ---- per joint: velocity-product acceleration (v_parent x S_j) qd_j -----------------------------------------
+        const int j = lane;
+        const bool isj = j < nj;
+        if (isj) {
+            const int bj = md->body_of_joint[j];
+            const double qd = s_qd[j];
+            const V3 a = ld3(s_a[j]), sv = ld3(s_sv[j]);
+            const V3 pw = ld3(s_vw[bj]) - qd * a, pv = ld3(s_vv[bj]) - qd * sv;
+            st3(s_cw[j], qd * cross(pw, a));
+            st3(s_cv[j], qd * (cross(pw, sv) + cross(pv, a)));
+        }
+        __syncthreads();
+        // ---- per body: spatial acceleration and the force the body needs ----------------------------------------------
+        if (isb) {
+            V3 fn = v3(0, 0, 0), ff = v3(0, 0, 0);
+            if (mass > 0.0) {
+                V3 aw = v3(0, 0, 0), av = v3(-md->gravity[0], -md->gravity[1], -md->gravity[2]);
+                const uint32_t am = md->anc_mask[b];
+                for (int jj = 0; jj < nj; ++jj) {
+                    if ((am >> jj) & 1u) { aw = aw + ld3(s_cw[jj]); av = av + ld3(s_cv[jj]); }
+                }
+                const V3 c = ld3(s_c[b]), vw = ld3(s_vw[b]), vv = ld3(s_vv[b]);
+                V3 n1, f1, hn, hf;
+                inertia_apply(mass, c, s_Ic[b], aw, av, n1, f1);
+                inertia_apply(mass, c, s_Ic[b], vw, vv, hn, hf);
+                fn = n1 + cross(vw, hn) + cross(vv, hf);
+                ff = f1 + cross(vw, hf);
+            }
+            st3(s_fn[b], fn);
+            st3(s_ff[b], ff);
+        }
+        __syncthreads();
+        // ---- per joint: bias force, composite-inertia column ---------------------------------------------------------------
+        if (isj) {
+            const V3 a = ld3(s_a[j]), sv = ld3(s_sv[j]);
+            const uint64_t sm = md->sub_mask[j];
+            double bias = 0.0;
+            V3 Fn = v3(0, 0, 0), Ff = v3(0, 0, 0);
+            for (int bb = 0; bb < nb; ++bb) {
+                if ((sm >> bb) & 1ull) {
+                    bias += dot(a, ld3(s_fn[bb])) + dot(sv, ld3(s_ff[bb]));
+                    const double mb = md->mass[bb];
+                    if (mb > 0.0) {
+                        V3 n, f;
+                        inertia_apply(mb, ld3(s_c[bb]), s_Ic[bb], a, sv, n, f);
+                        Fn = Fn + n;
+                        Ff = Ff + f;
+                    }
+                }
+            }
+            st3(s_Fn[j], Fn);
+            st3(s_Ff[j], Ff);
+            out.bias[(size_t)inst * nj + j] = (TOUT)bias;
+            out.dq[(size_t)inst * nj + j] = (TOUT)s_qd[j];
+        }
+        __syncthreads();
+        // ---- M row j (lane = joint), J rows (lane = column), EE poses ------------------------------------------------------
+        if (isj) {
+            const int bj = md->body_of_joint[j];
+            const uint32_t amj = md->anc_mask[bj];
+            const V3 a = ld3(s_a[j]), sv = ld3(s_sv[j]), Fn = ld3(s_Fn[j]), Ff = ld3(s_Ff[j]);
+            TOUT* Mrow = out.M + ((size_t)inst * nj + j) * nj;
+            for (int i = 0; i < nj; ++i) {
+                double v = 0.0;
+                if ((amj >> i) & 1u) v = dot(ld3(s_a[i]), Fn) + dot(ld3(s_sv[i]), Ff);                       // i above (or is) j
+                else if ((md->anc_mask[md->body_of_joint[i]] >> j) & 1u) v = dot(a, ld3(s_Fn[i])) + dot(sv, ld3(s_Ff[i]));
+                if (i == j) v += md->armature[j];
+                Mrow[i] = (TOUT)v;
+            }
+            const V3 p = ld3(s_p[j]);
+            for (int d = 0; d < md->ndev; ++d) {
+                const int eb = md->ee_body[d];
+                const bool moves = (md->anc_mask[eb] >> j) & 1u;
+                const V3 jp = moves ? cross(a, ld3(s_xpos[eb]) - p) : v3(0, 0, 0);
+                const V3 jr = moves ? a : v3(0, 0, 0);
+                const double six[6] = {jp.x, jp.y, jp.z, jr.x, jr.y, jr.z};
+                int row = md->row0[d];
+                const uint32_t dm = md->dofmask[d];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    if ((dm >> r) & 1u) { out.J[((size_t)inst * md->k + row) * nj + j] = (TOUT)six[r]; ++row; }
+                }
+            }
+        }
+        if (lane < md->ndev * 7) {
+            const int d = lane / 7, e = lane - d * 7;
+            const int eb = md->ee_body[d];
+            out.ee[((size_t)inst * md->ndev + d) * 7 + e] = (TOUT)(e < 3 ? s_xpos[eb][e] : s_xq[eb][e - 3]);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace irlosc

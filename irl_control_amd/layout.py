@@ -86,7 +86,7 @@ class OSCLayout:
 
     def as_oracle_dict(self) -> Dict:
         """The plain-dict form oracle/osc_oracle.generate_batch takes (tests only)."""
-        return dict(n=self.n, dev_rows=self.dev_rows, ctrlr_dof=self.ctrlr_dof,
+        return dict(n=self.n, dev_names=list(self.dev_names), dev_rows=self.dev_rows, ctrlr_dof=self.ctrlr_dof,
                     joint_ids=self.joint_ids, j_idx0=self.j_idx0, has_max_vel=self.has_max_vel,
                     use_g=self.use_g, admittance=self.admittance, nullspace=self.nullspace)
 

@@ -100,3 +100,15 @@ def test_comm_entry_points_validate_and_need_a_gpu():
     s, e = C.c_double(1.0), C.c_double(1.0)
     assert lib.irlosc_bench_allreduce(None, C.byref(s), C.byref(e)) == -1
     lib.irlosc_comm_destroy(None)
+
+
+def test_model_struct_matches_header_layout():
+    # struct irlosc_model: 2 int32, 2 x int32[64], pos[64][3], quat[64][4], jaxis[32][3], jpos[32][3], armature[32],
+    # mass[64], ipos[64][3], iquat[64][4], inertia[64][3], gravity[3], ee_body[4]
+    expect = 4 * (2 + 64 + 64) + 8 * (64 * 3 + 64 * 4 + 32 * 3 + 32 * 3 + 32 + 64 + 64 * 3 + 64 * 4 + 64 * 3 + 3) + 4 * 4
+    assert C.sizeof(_lib.Model) == expect
+    from irl_control_amd.rigid_body import RigidBodyModel
+    m = RigidBodyModel.load("dual_ur5")
+    st = m.to_struct(["ur_EE_ur5right", "ur_EE_ur5left", "ur_stand_dummy"])
+    assert st.nb == 35 and st.nj == 25 and st.parent[0] == -1 and st.joint_of_body[1] == 0
+    assert list(st.ee_body)[:3] == [m.body_id("ur_EE_ur5right"), m.body_id("ur_EE_ur5left"), m.body_id("ur_stand_dummy")]

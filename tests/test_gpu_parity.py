@@ -704,3 +704,51 @@ def test_admit_test_loop_matches_reference_tick_by_tick():
     jump_in = np.abs(g["forces"][lo + 1] - g["forces"][lo]).max()        # first tick that sees the wrench
     jump_before = np.abs(g["forces"][lo] - g["forces"][lo - 1]).max()
     assert jump_in > 2 * jump_before
+
+
+# ------------------------------------------------------------------------------------------------
+# Rigid-body front end: records from (qpos, qvel) on the GPU
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", ["k13", "k7", "k12_admit"])
+def test_frontend_records_and_step_from_q(cfg):
+    """irlosc_frontend against the float64 rigid-body oracle (itself pinned by physics identities, tests/test_rigid_body.py):
+    the torques of step_from_q equal, to 1e-9, those of the OSC step on the oracle's records, and equal the OSC oracle
+    on those records to 1e-5 in the parity domain."""
+    from irl_control_amd.rigid_body import DUAL_UR5_EE, RigidBodyModel
+    from oracle import rigid_body as rb
+    B = 64
+    lay = synth.make_layout(cfg)
+    _, gains, g = synth.make_batch(cfg, B, seed=3)
+    model = RigidBodyModel.load("dual_ur5")
+    rng = np.random.default_rng(17)
+    qpos, qvel = model.random_state(rng, B)
+    om = rb.Model()
+    recs = [rb.records(om, lay.as_oracle_dict(), DUAL_UR5_EE, qpos[b], qvel[b]) for b in range(B)]
+    R = {k: np.array([r[k] for r in recs]) for k in ("M", "J", "dq", "bias", "ee_pose")}
+    tgt = R["ee_pose"].copy()
+    tgt[:, :, :3] += rng.normal(0.0, 0.2, size=tgt[:, :, :3].shape)
+    osc = BatchedOSC(lay, B, dtype=np.float64)
+    osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+    osc.set_model(model)
+    u_q, fl_q = osc.step_from_q(qpos, qvel, tgt, return_flags=True)
+    u_r, fl_r = osc.generate_batched(R["M"], R["J"], R["dq"], R["bias"], R["ee_pose"], tgt, return_flags=True)
+    osc.close()
+    assert np.array_equal(fl_q & 0x4f, fl_r & 0x4f)
+    d = np.abs(u_q - u_r).max(axis=1) / np.abs(u_r).max(axis=1)
+    assert d.max() <= 1e-9, float(d.max())
+    ref = osc_oracle.generate_batch(lay.as_oracle_dict(), gains, R["M"], R["J"], R["dq"], R["bias"], R["ee_pose"], tgt)
+    dom = np.array([in_parity_domain(*osc_oracle.task_inertia(R["J"][b], R["M"][b])[2:]) for b in range(B)])
+    assert dom.sum() >= B // 2
+    assert rel_err(u_q, ref)[dom].max() <= TOL64
+
+
+def test_frontend_needs_a_model_and_coordinates():
+    lay, gains, g = synth.make_batch("k13", 8, seed=1)
+    osc = BatchedOSC(lay, 8, dtype=np.float64)
+    with pytest.raises(_lib.IrloscError, match="irlosc_set_model"):
+        osc.upload_q(np.zeros((8, 25)), np.zeros((8, 25)))
+    from irl_control_amd.rigid_body import RigidBodyModel
+    osc.set_model(RigidBodyModel.load("dual_ur5"))
+    with pytest.raises(_lib.IrloscError, match="irlosc_upload_q"):
+        osc.frontend()
+    osc.close()

@@ -1,0 +1,96 @@
+"""The float64 rigid-body oracle (oracle/rigid_body.py) against MuJoCo-independent identities: MuJoCo is not available,
+so what the front end must reproduce (M, EE Jacobians, bias forces, EE poses: robot.py:69, device.py:125-128,
+osc.py:191 in the reference) is pinned by physics instead of by a recorded MuJoCo output."""
+import numpy as np
+import pytest
+
+from oracle import rigid_body as rb
+
+
+@pytest.fixture(scope="module")
+def model():
+    return rb.Model()
+
+
+def _state(model, seed):
+    rng = np.random.default_rng(seed)
+    q = rng.uniform(-np.pi, np.pi, model.nj)
+    for j, b in enumerate(model.joint_body):                 # gripper joints inside their ranges
+        lo, hi = model.bodies[b]["joint"]["range"]
+        if hi - lo < 3.0:
+            q[j] = rng.uniform(lo, hi)
+    return q, rng.normal(0.0, 0.5, model.nj)
+
+
+def test_tree_matches_the_reference_scene(model):
+    # joint / actuator numbering of SURVEY.md Appendix A (scenes/dual_ur5.xml)
+    names = model.raw["joint_names"]
+    assert model.nj == 25 and names[0] == "ur_stand_joint" and names[1] == "joint0_ur5right" and names[13] == "joint0_ur5left"
+    assert names[10] == "right_outer_knuckle_joint_ur5right" and names[22] == "right_outer_knuckle_joint_ur5left"
+    acts = [names.index(a) for a in model.raw["actuator_joints"]]
+    assert acts == [0, 1, 2, 3, 4, 5, 6, 10, 13, 14, 15, 16, 17, 18, 22]
+    ee_r, ee_l = model.body_id("ur_EE_ur5right"), model.body_id("ur_EE_ur5left")
+    assert list(np.nonzero(model.anc[ee_r])[0]) == [0, 1, 2, 3, 4, 5, 6]
+    assert list(np.nonzero(model.anc[ee_l])[0]) == [0, 13, 14, 15, 16, 17, 18]
+    assert list(np.nonzero(model.anc[model.body_id("ur_stand_dummy")])[0]) == [0]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_jacobians_equal_finite_differences_of_the_kinematics(model, seed):
+    q, _ = _state(model, seed)
+    kin = rb.kinematics(model, q)
+    h = 1e-6
+    for name in ("ur_EE_ur5right", "ur_EE_ur5left", "ur_stand_dummy", "left_inner_finger_ur5left"):
+        b = model.body_id(name)
+        jp, jr = rb.body_jacobian(model, kin, b)
+        for j in range(model.nj):
+            dq = np.zeros(model.nj); dq[j] = h
+            kp, km = rb.kinematics(model, q + dq), rb.kinematics(model, q - dq)
+            assert np.allclose((kp["xpos"][b] - km["xpos"][b]) / (2 * h), jp[:, j], atol=1e-8)
+            dR = (kp["xmat"][b] - km["xmat"][b]) / (2 * h) @ kin["xmat"][b].T          # [w]x
+            w = np.array([dR[2, 1], dR[0, 2], dR[1, 0]])
+            assert np.allclose(w, jr[:, j], atol=1e-8)
+
+
+@pytest.mark.parametrize("seed", [0, 3])
+def test_mass_matrix_equals_the_kinetic_energy_form(model, seed):
+    q, qd = _state(model, seed)
+    M, _, _ = rb.dynamics(model, q, qd)
+    M2 = rb.mass_matrix_energy_form(model, q)
+    assert np.allclose(M, M.T, atol=1e-14)
+    assert np.allclose(M, M2, rtol=1e-12, atol=1e-13)
+    assert np.linalg.eigvalsh(M).min() > 0
+    # sparsity of the Dual-UR5 tree: the two arms only couple through the stand joint
+    assert np.all(M[1:13, 13:25] == 0.0) and np.all(M[0, 1:] != 0.0)
+
+
+@pytest.mark.parametrize("seed", [0, 4])
+def test_bias_forces_satisfy_lagranges_equations(model, seed):
+    """bias_i = sum_jk (dM_ij/dq_k - 1/2 dM_jk/dq_i) qd_j qd_k + dPE/dq_i, derivatives by central differences."""
+    q, qd = _state(model, seed)
+    _, bias, _ = rb.dynamics(model, q, qd)
+    h = 1e-5
+    n = model.nj
+    dM = np.zeros((n, n, n))
+    dPE = np.zeros(n)
+    for k in range(n):
+        e = np.zeros(n); e[k] = h
+        dM[:, :, k] = (rb.mass_matrix_energy_form(model, q + e) - rb.mass_matrix_energy_form(model, q - e)) / (2 * h)
+        dPE[k] = (rb.potential_energy(model, q + e) - rb.potential_energy(model, q - e)) / (2 * h)
+    c = np.einsum("ijk,j,k->i", dM, qd, qd) - 0.5 * np.einsum("jki,j,k->i", dM, qd, qd)
+    assert np.allclose(bias, c + dPE, rtol=1e-6, atol=1e-6 * np.abs(bias).max())
+    # gravity alone: zero velocity
+    _, g, _ = rb.dynamics(model, q, np.zeros(n))
+    assert np.allclose(g, dPE, rtol=1e-7, atol=1e-7 * np.abs(g).max())
+    assert abs(g[0]) < 1e-9          # the stand joint is vertical: gravity exerts no torque about it
+
+
+def test_records_have_the_abi_layout(model):
+    q, qd = _state(model, 5)
+    lay = dict(dev_names=["ur5right", "ur5left", "base"], ctrlr_dof=[[True] * 6, [True] * 6, [False] * 5 + [True]])
+    ee = dict(base="ur_stand_dummy", ur5right="ur_EE_ur5right", ur5left="ur_EE_ur5left")
+    r = rb.records(model, lay, ee, q, qd)
+    assert r["M"].shape == (25, 25) and r["J"].shape == (13, 25) and r["ee_pose"].shape == (3, 7)
+    assert np.allclose(r["J"][12], np.eye(25)[0])                     # base yaw row: rotation about z of joint 0 only
+    assert np.all(r["J"][:6, 7:] == 0) and np.all(r["J"][6:12, 1:13] == 0)
+    assert np.allclose(np.linalg.norm(r["ee_pose"][:, 3:], axis=1), 1.0)
