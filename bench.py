@@ -186,6 +186,46 @@ def parity_sample(lay, arr, u, ref, idx):
             "note": "GPU vs float64 oracle on the same (record-dtype-rounded) inputs; parity domain per SURVEY.md 8c"}
 
 
+def measure_from_q(BatchedOSC, synth, args, B, local_rank):
+    """The path from joint coordinates: per step the rigid-body front end computes M, J,
+    bias and the EE poses from resident (qpos, qvel) on the GPU, then the OSC step runs on them.  What a host-side
+    simulator would have to ship per step otherwise is the 8.5 KB of records (PCIe ceiling ~63 GB/s / 8 536 B = 7.4e6
+    steps/s in float64, 1.5e7 in float32)."""
+    from irl_control_amd.rigid_body import RigidBodyModel
+    try:
+        dt, arith, kern = MODES[args.dtype]
+        lay = synth.make_layout(args.layout)
+        model = RigidBodyModel.load("dual_ur5")
+        osc = BatchedOSC(lay, B, dtype=dt, hip_device=local_rank, n_slots=args.slots, kernel=kern)
+        osc.set_model(model)
+        rng = np.random.default_rng(20241008 + 77)
+        _, gains, arr = synth.make_batch(args.layout, B, seed=20241008 + 2000, dtype=dt)
+        osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+        for s in range(args.slots):
+            qpos, qvel = model.random_state(rng, B)
+            osc.upload_q(qpos, qvel, slot=s)
+            osc.frontend(slot=s)
+            osc.set_targets(arr["tgt_pose"], arr.get("tgt_vel"), slot=s)
+        steps = max(20, min(200, args.steps // 4))
+        osc.step_resident_from_q(20)
+        osc.device_sync()
+        t0 = time.perf_counter()
+        ms_total, ms_step = osc.step_resident_from_q(steps)
+        osc.device_sync()
+        el = time.perf_counter() - t0
+        _, ms_osc = osc.step_resident(steps)
+        esz = np.dtype(dt).itemsize
+        res = dict(value=B * steps / el, unit="steps/s", ms_per_step=el / steps * 1e3, ms_per_step_events=ms_step,
+                   ms_osc_step_alone=ms_osc, ms_front_end=ms_step - ms_osc, kernel="osc_frontend + " + osc.kernel_name,
+                   input_bytes_per_step_per_instance=2 * lay.n * 8 + 7 * lay.ndev * esz,
+                   note="per step: rigid-body front end (FK, EE Jacobians, CRBA, RNEA) from resident (qpos, qvel), then the OSC "
+                        "step on the records it wrote; nothing crosses PCIe")
+        osc.close()
+        return res
+    except Exception as e:                              # never break the bench line
+        return dict(error=str(e))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,6 +241,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=-1, help="override: 0 auto, 1 generic, 2 group, 3 row16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other arithmetic / storage variants")
+    ap.add_argument("--no-from-q", action="store_true", help="skip the joint-coordinates path (front end + step)")
     args = ap.parse_args()
 
     from irl_control_amd import BatchedOSC, sharding, synth
@@ -327,6 +368,8 @@ def main():
             sec.pop("layout")
             out["secondary"].append({"mode": other, "dtype": sec["arith"], "records": sec["records"], "value": sec["value"],
                                      "ms_per_step": sec["ms_per_step"], "kernel": sec["kernel"], "roofline": sec["roofline"]})
+    if world == 1 and not args.no_from_q:
+        out["from_q"] = measure_from_q(BatchedOSC, synth, args, B, local_rank)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if comm:

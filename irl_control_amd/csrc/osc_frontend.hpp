@@ -16,8 +16,11 @@
 //   c_j = (v_parent(j) x S_j) qd_j              velocity-product accelerations;  a_b = (0, -g) + sum_{j moves b} c_j
 //   f_b = I_b a_b + v_b x* I_b v_b              bias_j = S_j . sum_{b under j} f_b
 //   F_j = (sum_{b under j} I_b) S_j             M[i][j] = S_i . F_j   for i on the path from j to the root
-// One 64-lane wave per instance: lane = body (<= 64) in the body phases, lane = joint (<= 32) in the joint phases,
-// tables and intermediates in LDS.  This kernel is arithmetic-bound and small next to the OSC step.
+// The kernel evaluates the same sums recursively: v_b, a_b come down the tree with the pose (one level per round),
+// sum_{b under j} f_b and sum_{b under j} I_b go up it (children add into their parent; I_b as the additive triple
+// m, m c, I about the origin), and M only has entries on the path from a hinge to the root.  One 64-lane wave per
+// instance: lane = body (<= 64) in the body phases, lane = hinge (<= 32) in the hinge phases, intermediates in LDS,
+// M assembled in LDS and written out coalesced.
 #pragma once
 #include "osc_common.hpp"
 
@@ -93,36 +96,43 @@ __global__ __launch_bounds__(64) void osc_frontend_kernel(const FeModel* __restr
     const cmodel_t md = (cmodel_t)model_;
     __shared__ double s_q[FE_MAXJ], s_qd[FE_MAXJ];
     __shared__ double s_xpos[FE_MAXB][3], s_xmat[FE_MAXB][9], s_xq[FE_MAXB][4];
-    __shared__ double s_a[FE_MAXJ][3], s_p[FE_MAXJ][3], s_sv[FE_MAXJ][3];      // axis, anchor, p x a
-    __shared__ double s_c[FE_MAXB][3], s_Ic[FE_MAXB][6];
-    __shared__ double s_vw[FE_MAXB][3], s_vv[FE_MAXB][3];
-    __shared__ double s_cw[FE_MAXJ][3], s_cv[FE_MAXJ][3];
-    __shared__ double s_fn[FE_MAXB][3], s_ff[FE_MAXB][3];
-    __shared__ double s_Fn[FE_MAXJ][3], s_Ff[FE_MAXJ][3];
+    __shared__ double s_vel[FE_MAXB][6], s_acc[FE_MAXB][6];                     // spatial velocity / acceleration of a body
+    __shared__ double s_S[FE_MAXJ][6], s_p[FE_MAXJ][3];                         // (a, p x a) and the anchor p of a hinge
+    __shared__ double s_f[FE_MAXB][6];                                          // force on the body, then on its whole subtree
+    __shared__ double s_I[FE_MAXB][10];                                         // (m, m c, I about the origin) of the subtree
+    __shared__ double s_F[FE_MAXJ][6];                                          // composite inertia of the subtree times S_j
+    __shared__ double s_M[FE_MAXJ * FE_MAXJ];
     const int lane = threadIdx.x;
     const int nb = md->nb, nj = md->nj;
+    const int b = lane;
+    const bool isb = b < nb;
+    const int dep = isb ? md->depth[b] : -1;
+    const int jb = isb ? md->joint_of_body[b] : -1;
+    const int par = isb ? md->parent[b] : -1;
+    const int j = lane;
+    const bool isj = j < nj;
+    const int bj = isj ? md->body_of_joint[j] : 0;
     for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
-        if (lane < nj) {
-            s_q[lane] = qpos[(size_t)inst * nj + lane];
-            s_qd[lane] = qvel[(size_t)inst * nj + lane];
+        if (isj) {
+            s_q[j] = qpos[(size_t)inst * nj + j];
+            s_qd[j] = qvel[(size_t)inst * nj + j];
         }
+        for (int e = lane; e < nj * nj; e += 64) s_M[e] = 0.0;
         __syncthreads();
-        // ---- forward kinematics, one tree level per round (lane = body) -------------------------------------------
-        const int b = lane;
-        const bool isb = b < nb;
-        const int dep = isb ? md->depth[b] : -1;
-        const int jb = isb ? md->joint_of_body[b] : -1;
+        // ---- down the tree, one level per round (lane = body): pose, hinge axis, spatial velocity and acceleration ----
         for (int lev = 0; lev <= md->maxdepth; ++lev) {
             if (isb && dep == lev) {
-                const int par = md->parent[b];
                 V3 pp = v3(0, 0, 0);
                 Q4 pq = Q4{1, 0, 0, 0};
                 double pm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+                V3 vw = v3(0, 0, 0), vv = v3(0, 0, 0), aw = v3(0, 0, 0), av = v3(-md->gravity[0], -md->gravity[1], -md->gravity[2]);
                 if (par >= 0) {
                     pp = ld3(s_xpos[par]);
                     pq = Q4{s_xq[par][0], s_xq[par][1], s_xq[par][2], s_xq[par][3]};
 #pragma unroll
                     for (int i = 0; i < 9; ++i) pm[i] = s_xmat[par][i];
+                    vw = ld3(s_vel[par]); vv = ld3(s_vel[par] + 3);
+                    aw = ld3(s_acc[par]); av = ld3(s_acc[par] + 3);
                 }
                 const V3 x0 = pp + mv(pm, v3(md->pos[b][0], md->pos[b][1], md->pos[b][2]));
                 const Q4 q0 = qmul(pq, Q4{md->quat[b][0], md->quat[b][1], md->quat[b][2], md->quat[b][3]});
@@ -135,15 +145,22 @@ __global__ __launch_bounds__(64) void osc_frontend_kernel(const FeModel* __restr
                     const V3 jp = v3(md->jpos[jb][0], md->jpos[jb][1], md->jpos[jb][2]);
                     const V3 ax = v3(md->jaxis[jb][0], md->jaxis[jb][1], md->jaxis[jb][2]);
                     const V3 anchor = x0 + mv(m0, jp);
-                    const V3 aw = mv(m0, ax);
+                    const V3 a = mv(m0, ax);
+                    const V3 sv = cross(anchor, a);
                     double sn, cs;
                     sincos(0.5 * s_q[jb], &sn, &cs);
                     qb = qnormalized(qmul(q0, Q4{cs, sn * ax.x, sn * ax.y, sn * ax.z}));
                     q2m(qb, m9);
                     xb = anchor - mv(m9, jp);
-                    st3(s_a[jb], aw);
+                    st3(s_S[jb], a);
+                    st3(s_S[jb] + 3, sv);
                     st3(s_p[jb], anchor);
-                    st3(s_sv[jb], cross(anchor, aw));
+                    const double qd = s_qd[jb];
+                    // a_b = a_parent + (v_parent x S) qd ;  v_b = v_parent + S qd
+                    aw = aw + qd * cross(vw, a);
+                    av = av + qd * (cross(vw, sv) + cross(vv, a));
+                    vw = vw + qd * a;
+                    vv = vv + qd * sv;
                 } else {
                     q2m(qb, m9);
                 }
@@ -151,113 +168,83 @@ __global__ __launch_bounds__(64) void osc_frontend_kernel(const FeModel* __restr
                 s_xq[b][0] = qb.w; s_xq[b][1] = qb.x; s_xq[b][2] = qb.y; s_xq[b][3] = qb.z;
 #pragma unroll
                 for (int i = 0; i < 9; ++i) s_xmat[b][i] = m9[i];
+                st3(s_vel[b], vw); st3(s_vel[b] + 3, vv);
+                st3(s_acc[b], aw); st3(s_acc[b] + 3, av);
             }
             __syncthreads();
         }
-        // ---- per body: centre of mass, world inertia, spatial velocity ---------------------------------------------
-        double mass = 0.0;
+        // ---- per body: inertia about the world origin, the force it needs --------------------------------------------
         if (isb) {
-            mass = md->mass[b];
-            const V3 c = ld3(s_xpos[b]) + mv(s_xmat[b], v3(md->ipos[b][0], md->ipos[b][1], md->ipos[b][2]));
-            st3(s_c[b], c);
-            double mi[9], R[9];
-            q2m(Q4{md->iquat[b][0], md->iquat[b][1], md->iquat[b][2], md->iquat[b][3]}, mi);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                for (int cc = 0; cc < 3; ++cc)
-                    R[r * 3 + cc] = s_xmat[b][r * 3] * mi[cc] + s_xmat[b][r * 3 + 1] * mi[3 + cc] + s_xmat[b][r * 3 + 2] * mi[6 + cc];
-            }
-            const double d0 = md->inertia[b][0], d1 = md->inertia[b][1], d2 = md->inertia[b][2];
-            int e = 0;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                for (int cc = r; cc < 3; ++cc)
-                    s_Ic[b][e++] = R[r * 3] * d0 * R[cc * 3] + R[r * 3 + 1] * d1 * R[cc * 3 + 1] + R[r * 3 + 2] * d2 * R[cc * 3 + 2];
-            }
-            V3 vw = v3(0, 0, 0), vv = v3(0, 0, 0);
-            const uint32_t am = md->anc_mask[b];
-            for (int j = 0; j < nj; ++j) {
-                if ((am >> j) & 1u) {
-                    const double qd = s_qd[j];
-                    vw = vw + qd * ld3(s_a[j]);
-                    vv = vv + qd * ld3(s_sv[j]);
-                }
-            }
-            st3(s_vw[b], vw);
-            st3(s_vv[b], vv);
-        }
-        __syncthreads();
-        // ---- per joint: velocity-product acceleration (v_parent x S_j) qd_j -----------------------------------------
-        const int j = lane;
-        const bool isj = j < nj;
-        if (isj) {
-            const int bj = md->body_of_joint[j];
-            const double qd = s_qd[j];
-            const V3 a = ld3(s_a[j]), sv = ld3(s_sv[j]);
-            const V3 pw = ld3(s_vw[bj]) - qd * a, pv = ld3(s_vv[bj]) - qd * sv;
-            st3(s_cw[j], qd * cross(pw, a));
-            st3(s_cv[j], qd * (cross(pw, sv) + cross(pv, a)));
-        }
-        __syncthreads();
-        // ---- per body: spatial acceleration and the force the body needs ----------------------------------------------
-        if (isb) {
+            const double mass = md->mass[b];
+            double I10[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             V3 fn = v3(0, 0, 0), ff = v3(0, 0, 0);
             if (mass > 0.0) {
-                V3 aw = v3(0, 0, 0), av = v3(-md->gravity[0], -md->gravity[1], -md->gravity[2]);
-                const uint32_t am = md->anc_mask[b];
-                for (int jj = 0; jj < nj; ++jj) {
-                    if ((am >> jj) & 1u) { aw = aw + ld3(s_cw[jj]); av = av + ld3(s_cv[jj]); }
+                const V3 c = ld3(s_xpos[b]) + mv(s_xmat[b], v3(md->ipos[b][0], md->ipos[b][1], md->ipos[b][2]));
+                double mi[9], R[9], Ic[6];
+                q2m(Q4{md->iquat[b][0], md->iquat[b][1], md->iquat[b][2], md->iquat[b][3]}, mi);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc)
+                        R[r * 3 + cc] = s_xmat[b][r * 3] * mi[cc] + s_xmat[b][r * 3 + 1] * mi[3 + cc] + s_xmat[b][r * 3 + 2] * mi[6 + cc];
                 }
-                const V3 c = ld3(s_c[b]), vw = ld3(s_vw[b]), vv = ld3(s_vv[b]);
+                const double d0 = md->inertia[b][0], d1 = md->inertia[b][1], d2 = md->inertia[b][2];
+                int e = 0;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int cc = r; cc < 3; ++cc)
+                        Ic[e++] = R[r * 3] * d0 * R[cc * 3] + R[r * 3 + 1] * d1 * R[cc * 3 + 1] + R[r * 3 + 2] * d2 * R[cc * 3 + 2];
+                }
+                const V3 vw = ld3(s_vel[b]), vv = ld3(s_vel[b] + 3), aw = ld3(s_acc[b]), av = ld3(s_acc[b] + 3);
                 V3 n1, f1, hn, hf;
-                inertia_apply(mass, c, s_Ic[b], aw, av, n1, f1);
-                inertia_apply(mass, c, s_Ic[b], vw, vv, hn, hf);
+                inertia_apply(mass, c, Ic, aw, av, n1, f1);
+                inertia_apply(mass, c, Ic, vw, vv, hn, hf);
                 fn = n1 + cross(vw, hn) + cross(vv, hf);
                 ff = f1 + cross(vw, hf);
+                // (m, m c, I_O = Ic + m (c.c 1 - c c^T)): additive over bodies
+                const double cc2 = dot(c, c);
+                I10[0] = mass; I10[1] = mass * c.x; I10[2] = mass * c.y; I10[3] = mass * c.z;
+                I10[4] = Ic[0] + mass * (cc2 - c.x * c.x); I10[5] = Ic[1] - mass * c.x * c.y; I10[6] = Ic[2] - mass * c.x * c.z;
+                I10[7] = Ic[3] + mass * (cc2 - c.y * c.y); I10[8] = Ic[4] - mass * c.y * c.z; I10[9] = Ic[5] + mass * (cc2 - c.z * c.z);
             }
-            st3(s_fn[b], fn);
-            st3(s_ff[b], ff);
+            st3(s_f[b], fn); st3(s_f[b] + 3, ff);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) s_I[b][i] = I10[i];
         }
         __syncthreads();
-        // ---- per joint: bias force, composite-inertia column ---------------------------------------------------------------
-        if (isj) {
-            const V3 a = ld3(s_a[j]), sv = ld3(s_sv[j]);
-            const uint64_t sm = md->sub_mask[j];
-            double bias = 0.0;
-            V3 Fn = v3(0, 0, 0), Ff = v3(0, 0, 0);
-            for (int bb = 0; bb < nb; ++bb) {
-                if ((sm >> bb) & 1ull) {
-                    bias += dot(a, ld3(s_fn[bb])) + dot(sv, ld3(s_ff[bb]));
-                    const double mb = md->mass[bb];
-                    if (mb > 0.0) {
-                        V3 n, f;
-                        inertia_apply(mb, ld3(s_c[bb]), s_Ic[bb], a, sv, n, f);
-                        Fn = Fn + n;
-                        Ff = Ff + f;
-                    }
-                }
+        // ---- up the tree: subtree sums of the forces and of the inertias (children add into their parent) ----------------
+        for (int lev = md->maxdepth; lev >= 1; --lev) {
+            if (isb && dep == lev && par >= 0) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) atomicAdd(&s_f[par][i], s_f[b][i]);
+#pragma unroll
+                for (int i = 0; i < 10; ++i) atomicAdd(&s_I[par][i], s_I[b][i]);
             }
-            st3(s_Fn[j], Fn);
-            st3(s_Ff[j], Ff);
+            __syncthreads();
+        }
+        // ---- per hinge: bias force, composite-inertia column F_j, then the entries of M on the path to the root ---------
+        if (isj) {
+            const V3 a = ld3(s_S[j]), sv = ld3(s_S[j] + 3);
+            const double bias = dot(a, ld3(s_f[bj])) + dot(sv, ld3(s_f[bj] + 3));
+            const double* I = s_I[bj];
+            const V3 h = v3(I[1], I[2], I[3]);
+            const V3 Iw = v3(I[4] * a.x + I[5] * a.y + I[6] * a.z, I[5] * a.x + I[7] * a.y + I[8] * a.z, I[6] * a.x + I[8] * a.y + I[9] * a.z);
+            const V3 Fn = Iw + cross(h, sv);
+            const V3 Ff = I[0] * sv + cross(a, h);
             out.bias[(size_t)inst * nj + j] = (TOUT)bias;
             out.dq[(size_t)inst * nj + j] = (TOUT)s_qd[j];
-        }
-        __syncthreads();
-        // ---- M row j (lane = joint), J rows (lane = column), EE poses ------------------------------------------------------
-        if (isj) {
-            const int bj = md->body_of_joint[j];
-            const uint32_t amj = md->anc_mask[bj];
-            const V3 a = ld3(s_a[j]), sv = ld3(s_sv[j]), Fn = ld3(s_Fn[j]), Ff = ld3(s_Ff[j]);
-            TOUT* Mrow = out.M + ((size_t)inst * nj + j) * nj;
-            for (int i = 0; i < nj; ++i) {
-                double v = 0.0;
-                if ((amj >> i) & 1u) v = dot(ld3(s_a[i]), Fn) + dot(ld3(s_sv[i]), Ff);                       // i above (or is) j
-                else if ((md->anc_mask[md->body_of_joint[i]] >> j) & 1u) v = dot(a, ld3(s_Fn[i])) + dot(sv, ld3(s_Ff[i]));
-                if (i == j) v += md->armature[j];
-                Mrow[i] = (TOUT)v;
+            int bb = bj;
+            while (bb >= 0) {                               // hinges on the path from j to the root
+                const int i = md->joint_of_body[bb];
+                if (i >= 0) {
+                    const double v = dot(ld3(s_S[i]), Fn) + dot(ld3(s_S[i] + 3), Ff) + (i == j ? md->armature[j] : 0.0);
+                    s_M[j * nj + i] = v;
+                    s_M[i * nj + j] = v;
+                }
+                bb = md->parent[bb];
             }
+            // EE Jacobian columns of this hinge
             const V3 p = ld3(s_p[j]);
             for (int d = 0; d < md->ndev; ++d) {
                 const int eb = md->ee_body[d];
@@ -278,6 +265,9 @@ __global__ __launch_bounds__(64) void osc_frontend_kernel(const FeModel* __restr
             const int eb = md->ee_body[d];
             out.ee[((size_t)inst * md->ndev + d) * 7 + e] = (TOUT)(e < 3 ? s_xpos[eb][e] : s_xq[eb][e - 3]);
         }
+        __syncthreads();
+        TOUT* Mo = out.M + (size_t)inst * nj * nj;
+        for (int e = lane; e < nj * nj; e += 64) Mo[e] = (TOUT)s_M[e];
         __syncthreads();
     }
 }
