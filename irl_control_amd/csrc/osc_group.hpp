@@ -388,7 +388,7 @@ __device__ __forceinline__ void stage2_body(const S2Args a, int blk, int32_t* ld
 namespace irlosc {
 
 inline bool group_kernel_supports(int dtype, int n, int k, int ndev) {
-    return dtype == IRLOSC_F32 && n == 25 && ((k == 13 && ndev == 3) || (k == 12 && ndev == 2));
+    return dtype == IRLOSC_F32 && n == 25 && ((k == 13 && ndev == 3) || (k == 12 && ndev == 2) || (k == 7 && ndev == 3));
 }
 
 constexpr int GROUP_TILE = 16;        // instances per stage-1 wave
@@ -411,6 +411,7 @@ inline int launch_group_train(const TrainStep* dtable, int nsteps, int total_blo
     const dim3 grid(total_blocks);
     if (k == 13 && ndev == 3) hipLaunchKernelGGL((osc_group_kernel_f32<4, 13, 3, 2>), grid, dim3(64), 0, st, dtable, nsteps);
     else if (k == 12 && ndev == 2) hipLaunchKernelGGL((osc_group_kernel_f32<4, 12, 2, 2>), grid, dim3(64), 0, st, dtable, nsteps);
+    else if (k == 7 && ndev == 3) hipLaunchKernelGGL((osc_group_kernel_f32<4, 7, 3, 2>), grid, dim3(64), 0, st, dtable, nsteps);
     else return (int)hipErrorNotSupported;
     return (int)hipGetLastError();
 }

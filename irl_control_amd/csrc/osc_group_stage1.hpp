@@ -192,10 +192,12 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const TrainStep* _
     using GE = Geo<G>;
     constexpr int TILE = GE::TILE, P = GE::P, NS = GE::NS, LS = GE::LS, CI = GE::CI;
     constexpr bool ODD = GE::ODD;
-    constexpr bool HASJ3 = (K % 4) == 1;
-    static_assert(K % 4 == 0 || K % 4 == 1, "the last J chunk must be 4 rows or 1 row");
+    constexpr int NJ4 = K / 4;                       // J chunks of 4 rows ...
+    constexpr int NJ1 = K % 4;                       // ... then the remaining rows one per chunk (k = 13: 1, k = 7: 3)
+    constexpr bool LAST1 = NJ1 > 0;                  // the last J chunk is a single row
     constexpr int NCHM = 7;                          // M chunks: 6 x 4 rows + 1 row
-    constexpr int NCHJ = (K + 3) / 4;                // J chunks: 4-row ones (+ a 1-row tail when k = 13)
+    constexpr int NCHJ = NJ4 + NJ1;                  // J chunks
+    static_assert(NJ4 >= 1 && NCHJ >= 2, "at least one 4-row chunk and two chunks of J");
     constexpr int NCH1 = NCHM + NCHJ;                // chunks of the first pass (M then J)
     constexpr int NA = K * (K + 1) / 2;
     constexpr int PDQ = TILE * N / 4, PEE = TILE * NDEV * 7 / 4;      // 16-byte pieces of the vector arrays
@@ -209,12 +211,18 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const TrainStep* _
     constexpr int NT = NCH1;                         // ring chunks (one pass; the tail of J simply stays in the ring)
     // Second pass over J (u -= J^T t): rows 8..11 (chunk J2) are still in their ring slot and, for k = 13, row 12
     // (chunk J3) in the other one; only rows 0..7 are fetched again, straight into registers.
-    constexpr int NDL = 8;                           // rows [0, NDL) by plain loads into registers
-    static_assert(NCHJ >= 3 && NDL == 4 * (NCHJ - 1 - (HASJ3 ? 1 : 0)), "rows 8.. must be the resident chunks");
-    constexpr int SLOT_J2 = (NCHM + 2) % NB;         // ring slot of chunk J2 (rows 8..11)
-    constexpr int SLOT_A = 1 - SLOT_J2;              // the other slot: J3 (k = 13: its first 400 floats) + the A hand-off area
+    // The last chunk of J always stays in its slot.  If it is a single row (k = 13, k = 7), the A hand-off area goes
+    // BEHIND it in the same slot and the chunk before it survives in the other slot too; if it has four rows (k = 12)
+    // the A area takes the other slot.  Rows [0, NDL) are the ones that have to be fetched again.
     static_assert(NB == 2, "resident-tail bookkeeping assumes two ring slots");
-    constexpr int A_OFF = HASJ3 ? TILE * N : 0;      // A records start behind J3's row
+    constexpr int LAST_ROWS = LAST1 ? 1 : 4;
+    constexpr int PREV_ROWS = NJ1 >= 2 ? 1 : 4;      // rows of the chunk before the last one
+    constexpr bool PREV_RES = LAST1;                 // that chunk is still intact when the torque phase runs
+    constexpr int SLOT_LAST = (NT - 1) % NB, SLOT_PREV = (NT - 2) % NB;
+    constexpr int SLOT_A = LAST1 ? SLOT_LAST : SLOT_PREV;
+    constexpr int A_OFF = LAST1 ? TILE * N : 0;      // A records start behind the single resident row
+    constexpr int NDL = K - LAST_ROWS - (PREV_RES ? PREV_ROWS : 0);     // rows [0, NDL) by plain loads into registers
+    constexpr int ROW_PREV = NDL, ROW_LAST = K - LAST_ROWS;             // first row of the two resident chunks
     constexpr int A_FIT = (SLOT - A_OFF) / NA < TILE ? (SLOT - A_OFF) / NA : TILE;   // instances whose record fits in the slot
     __shared__ __attribute__((aligned(16))) float ring[NB * SLOT];
     __shared__ __attribute__((aligned(16))) float vec[VEC_END];
@@ -275,8 +283,8 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const TrainStep* _
         else if (m == 6) dma1row<N * N * 4>(Mt + 24 * N, dst, lane);
         else {
             const int jc = m - NCHM;
-            if (jc < 3) dma4rows<K * N * 4>(Jt + jc * 4 * N, dst, lane);
-            else dma1row<K * N * 4>(Jt + 12 * N, dst, lane);
+            if (jc < NJ4) dma4rows<K * N * 4>(Jt + jc * 4 * N, dst, lane);
+            else dma1row<K * N * 4>(Jt + (4 * NJ4 + (jc - NJ4)) * N, dst, lane);
         }
     };
     // Rule: after chunk m has been consumed, chunk m + NB is issued into the slot it vacated.  Hence "younger DMAs
@@ -496,10 +504,11 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const TrainStep* _
         const int n = NCHM + jc;
         float* buf = ring + (n % NB) * SLOT;
         wait_chunks<CI>((NT - 1 - n) < (NB - 1) ? (NT - 1 - n) : (NB - 1));
-        const int jstride = jc < 3 ? GE::STR4 : N;
+        const int jstride = jc < NJ4 ? GE::STR4 : N;
+        const int jrow0 = jc < NJ4 ? 4 * jc : 4 * NJ4 + (jc - NJ4);      // first row of J in this chunk
         Row dqc;                                   // dq of the own rows: re-read per chunk (7 registers saved)
         load_row(vec + VEC_DQ + q * N, dqc);
-        const int R = jc < 3 ? 4 : 1;
+        const int R = jc < NJ4 ? 4 : 1;
         Row bb[4];
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
@@ -510,7 +519,7 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const TrainStep* _
             float dxs = dx2.x + dx2.y;
             if (ODD) dxs = fmaf(bb[rr].o, dqc.o, dxs);
             dxs = gsum<G>(dxs);
-            if (g == 0) xq[25 + jc * 4 + rr] = dxs;
+            if (g == 0) xq[25 + jrow0 + rr] = dxs;
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) bb[rr].p[pp] = bb[rr].p[pp] * dinv.p[pp];     // b' = D^-1 b
             if (ODD) bb[rr].o *= dinv.o;
@@ -546,11 +555,11 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const TrainStep* _
                     bb[rr].o = lastpad ? 0.f : y24;
                 }
 #pragma unroll
-                for (int pp = 0; pp < P; ++pp) Y[jc * 4 + rr].p[pp] = bb[rr].p[pp];
-                Y[jc * 4 + rr].o = ODD ? bb[rr].o : 0.f;
+                for (int pp = 0; pp < P; ++pp) Y[jrow0 + rr].p[pp] = bb[rr].p[pp];
+                Y[jrow0 + rr].o = ODD ? bb[rr].o : 0.f;
 #pragma unroll
-                for (int pp = 0; pp < P; ++pp) asm volatile("" : "+v"(Y[jc * 4 + rr].p[pp]));
-                if (ODD) asm volatile("" : "+v"(Y[jc * 4 + rr].o));
+                for (int pp = 0; pp < P; ++pp) asm volatile("" : "+v"(Y[jrow0 + rr].p[pp]));
+                if (ODD) asm volatile("" : "+v"(Y[jrow0 + rr].o));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -818,10 +827,10 @@ __global__ __launch_bounds__(64, 2) void osc_group_kernel_f32(const TrainStep* _
             if (ODD) jt.o = fmaf(jd[r].o, t[r], jt.o);      // padding lanes: junk in, never stored
         }
 #pragma unroll
-        for (int r = NDL; r < K; ++r) {                     // the resident tail: J2 (4 rows), then J3 (k = 13)
+        for (int r = NDL; r < K; ++r) {                     // the resident tail: the chunk before the last (if intact), the last
             Row jr;
-            if (r < NDL + 4) load_row(ring + SLOT_J2 * SLOT + q * GE::STR4 + (r - NDL) * N, jr);
-            else load_row(ring + SLOT_A * SLOT + q * N, jr);
+            if (r < ROW_LAST) load_row(ring + SLOT_PREV * SLOT + q * (PREV_ROWS == 4 ? GE::STR4 : N) + (r - ROW_PREV) * N, jr);
+            else load_row(ring + SLOT_LAST * SLOT + q * (LAST_ROWS == 4 ? GE::STR4 : N) + (r - ROW_LAST) * N, jr);
             const v2f t2 = v2f{t[r], t[r]};
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) jt.p[pp] = __builtin_elementwise_fma(jr.p[pp], t2, jt.p[pp]);

@@ -197,7 +197,8 @@ def test_admittance_wrench_enters_linearly_full_size():
 # k13_gimbal is deliberately absent: within 1e-5 rad of gimbal lock the sxyz angles are computed from matrix
 # entries of size ~1e-7, below float32 resolution; that fixture is an fp64 test (test_fp64_matches_reference_outputs).
 @pytest.mark.parametrize("name", ["k13_xyz_abg", "k13_iros2022", "k13_random_gains", "k13_pinv_regime",
-                                  "k13_no_g_no_null", "k13_no_max_vel", "k12_admittance"])
+                                  "k13_no_g_no_null", "k13_no_max_vel", "k12_admittance", "k7_gain_test",
+                                  "k7_real_actuators"])
 def test_fp32_group_path_on_reference_goldens(name):
     """The fp32 two-stage group path on the reference-minted fixtures (32 or fewer instances, so this
     also exercises the ragged-tail hand-over to the generic kernel).  Tolerance scales with
@@ -225,6 +226,11 @@ def test_fp32_group_path_on_reference_goldens(name):
     assert ok.sum() >= 0.6 * len(ok)
     assert np.all(err[ok] <= np.minimum(tol[ok], 0.5)), (kname, name, float((err[ok] / tol[ok]).max()))
     assert not np.any(fl & _lib.FLAG_NONFINITE)
+    # fp32 branch decisions (osc.py:52): the PINV flag must agree with the reference's det test outside a band around
+    # the 1e-4 threshold (the fp32 product of k pivots carries ~k * eps32 * cond of relative error)
+    det = np.array([osc_oracle.task_inertia(g32["J"][b], g32["M"][b])[3] for b in range(g["M"].shape[0])])
+    clear = ok & ((np.abs(det) < 0.5e-4) | (np.abs(det) > 2e-4))
+    assert np.array_equal((fl[clear] & _lib.FLAG_PINV_BRANCH) != 0, np.abs(det[clear]) < 1e-4)
 
 
 @pytest.mark.parametrize("B", [1, 15, 16, 17, 33, 100])
