@@ -29,6 +29,15 @@
  *   u[B][n]         joint torques u_all (osc.py:152-200)
  *   flags[B]        uint32 status bits per instance (IRLOSC_FLAG_*)
  *
+ * Contracts the kernels rely on (not checked on the device):
+ *   - M is symmetric: the throughput kernels read row j of M as its column j (the generic kernel uses M as given);
+ *     irl_control_amd.BatchedOSC.upload(check_symmetric=True) / OSC.generate check it on the host;
+ *   - device pointers handed to irlosc_step_device / irlosc_assemble_device are 16-byte aligned;
+ *   - a context is driven from ONE stream at a time: its train tables, worklists and pending stage-2 work are ordered
+ *     by stream order only, so a caller stream passed to the *_device entry points must not run concurrently with the
+ *     context's own stream or with another caller stream on the same context;
+ *   - a step over B instances needs B instances of state and of targets in the slot (IRLOSC_ERR_STATE otherwise).
+ *
  * Ownership: the caller owns every host buffer (borrowed for the duration of the call); the
  * library owns its device buffers and its HIP stream.  Errors: 0 = success, negative irlosc_status
  * otherwise, message via irlosc_last_error(); nothing throws across the ABI.  A context is bound

@@ -46,6 +46,15 @@ class BatchedOSC:
             raise ValueError(f"{name}: expected shape {tuple(shape)}, got {a.shape}")
         return a
 
+    @staticmethod
+    def _check_symmetric(M):
+        """The throughput kernels read rows of M as columns (include/irlosc.h): refuse an asymmetric inertia matrix."""
+        asym = np.abs(M - np.swapaxes(M, 1, 2)).max(axis=(1, 2))
+        scale = np.abs(M).max(axis=(1, 2))
+        bad = np.nonzero(asym > 1e-6 * np.maximum(scale, 1e-300))[0]
+        if len(bad):
+            raise ValueError(f"M of instance {int(bad[0])} is not symmetric (max |M - M^T| = {asym[bad[0]]:.3g})")
+
     @property
     def kernel_name(self) -> str:
         return self.lib.irlosc_kernel_name(self._h).decode()
@@ -72,10 +81,12 @@ class BatchedOSC:
         self._chk(self.lib.irlosc_set_gains(self._h, _lib.ptr(g), _lib.ptr(nk), nb))
         self._gains_sent = (g.copy(), nk.copy(), nb)
 
-    def upload(self, M, J, dq, bias, ee_pose, wrench=None, slot: int = 0):
+    def upload(self, M, J, dq, bias, ee_pose, wrench=None, slot: int = 0, check_symmetric: bool = False):
         L = self.layout
         B = int(np.shape(M)[0])
         M = self._arr(M, (B, L.n, L.n), "M")
+        if check_symmetric:
+            self._check_symmetric(M)
         J = self._arr(J, (B, L.k, L.n), "J")
         dq = self._arr(dq, (B, L.n), "dq")
         bias = self._arr(bias, (B, L.n), "bias")
@@ -102,6 +113,8 @@ class BatchedOSC:
     def set_targets(self, tgt_pose, tgt_vel=None, slot: int = 0):
         L = self.layout
         B = int(np.shape(tgt_pose)[0])
+        if self._B[slot] and B != self._B[slot]:
+            raise ValueError(f"slot {slot} holds {self._B[slot]} instances, targets given for {B}")
         tp = self._arr(tgt_pose, (B, L.ndev, 7), "tgt_pose")
         tv = self._arr(tgt_vel, (B, L.ndev, 6), "tgt_vel")
         self._chk(self.lib.irlosc_set_targets(self._h, slot, B, _lib.ptr(tp), _lib.ptr(tv)))
@@ -186,12 +199,15 @@ class BatchedOSC:
         """hipDeviceSynchronize on this context's GPU (the bench bracket)."""
         self._chk(self.lib.irlosc_device_sync(self._h))
 
-    def tick(self, M, J, dq, bias, ee_pose, tgt_pose, tgt_vel=None, wrench=None, return_flags: bool = False):
+    def tick(self, M, J, dq, bias, ee_pose, tgt_pose, tgt_vel=None, wrench=None, return_flags: bool = False,
+             check_symmetric: bool = False):
         """One control tick for B instances in ONE library call (irlosc_tick): one host-to-device copy, the step, one
         copy back, one synchronisation.  Does not touch the resident slots."""
         L = self.layout
         B = int(np.shape(M)[0])
         M = self._arr(M, (B, L.n, L.n), "M")
+        if check_symmetric:
+            self._check_symmetric(M)
         J = self._arr(J, (B, L.k, L.n), "J")
         dq = self._arr(dq, (B, L.n), "dq")
         bias = self._arr(bias, (B, L.n), "bias")

@@ -33,7 +33,8 @@ struct irlosc_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // resident inputs, one set per slot
     std::vector<void*> dM, dJ, ddq, dbias, dee, dwrench, dtgt, dtvel;
-    std::vector<int> has_wrench, has_tvel, uploaded, targeted;
+    std::vector<int> has_wrench, has_tvel;
+    std::vector<int> uploaded, targeted;    // instances of the slot that hold state / targets (0 = nothing yet, -1 = an empty batch)
     // Output sets (u, flags, stage-2 hand-off records, give-up list).  The group path chains up to TRAIN steps in
     // one launch and the stage 2 of a train's steps rides in the NEXT train, so two trains' worth of sets exist;
     // the generic path only ever uses set 0.
@@ -343,7 +344,7 @@ extern "C" int irlosc_upload(irlosc_ctx* c, int32_t slot, int32_t B, const void*
     if (!c) return IRLOSC_ERR_ARG;
     int rc = check_slot(c, slot, B);
     if (rc) return rc;
-    if (B == 0) { c->uploaded[slot] = 1; return IRLOSC_OK; }
+    if (B == 0) { c->uploaded[slot] = -1; return IRLOSC_OK; }
     if (!M || !J || !dq || !ee_pose) return fail(c, IRLOSC_ERR_ARG, "M, J, dq and ee_pose are required");
     if ((c->cfg.flags & IRLOSC_USE_G) && !bias) return fail(c, IRLOSC_ERR_ARG, "bias required with IRLOSC_USE_G");
     HIPCHK(c, hipSetDevice(c->cfg.hip_device));
@@ -356,7 +357,7 @@ extern "C" int irlosc_upload(irlosc_ctx* c, int32_t slot, int32_t B, const void*
     if (wrench) HIPCHK(c, hipMemcpyAsync(c->dwrench[slot], wrench, b * nd * 6 * e, hipMemcpyHostToDevice, c->stream));
     c->has_wrench[slot] = wrench != nullptr;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->uploaded[slot] = 1;
+    c->uploaded[slot] = B;
     return IRLOSC_OK;
 }
 
@@ -433,7 +434,7 @@ extern "C" int irlosc_upload_raw(irlosc_ctx* c, int32_t slot, int32_t B, const i
     if (!c) return IRLOSC_ERR_ARG;
     int rc = check_slot(c, slot, B);
     if (rc) return rc;
-    if (B == 0) { c->uploaded[slot] = 1; return IRLOSC_OK; }
+    if (B == 0) { c->uploaded[slot] = -1; return IRLOSC_OK; }
     if (!rd || !qM || !qvel || !qfrc_bias || !jacp || !jacr || !ee_xpos || !ee_xquat)
         return fail(c, IRLOSC_ERR_ARG, "desc, qM, qvel, qfrc_bias, jacp, jacr, ee_xpos and ee_xquat are required");
     rc = check_raw_desc(c, rd);
@@ -444,7 +445,7 @@ extern "C" int irlosc_upload_raw(irlosc_ctx* c, int32_t slot, int32_t B, const i
              : upload_raw_t<float>(c, slot, B, rd, qM, qvel, qfrc_bias, jacp, jacr, ee_xpos, ee_xquat, site_xmat, sensordata);
     if (rc) return rc;
     c->has_wrench[slot] = 1;
-    c->uploaded[slot] = 1;
+    c->uploaded[slot] = B;
     return IRLOSC_OK;
 }
 
@@ -455,7 +456,7 @@ extern "C" int irlosc_assemble_device(irlosc_ctx* c, int32_t slot, int32_t B, co
     if (!c) return IRLOSC_ERR_ARG;
     int rc = check_slot(c, slot, B);
     if (rc) return rc;
-    if (B == 0) { c->uploaded[slot] = 1; return IRLOSC_OK; }
+    if (B == 0) { c->uploaded[slot] = -1; return IRLOSC_OK; }
     if (!rd || !qM || !qvel || !qfrc_bias || !jacp || !jacr || !ee_xpos || !ee_xquat)
         return fail(c, IRLOSC_ERR_ARG, "desc, qM, qvel, qfrc_bias, jacp, jacr, ee_xpos and ee_xquat are required");
     rc = check_raw_desc(c, rd);
@@ -467,7 +468,7 @@ extern "C" int irlosc_assemble_device(irlosc_ctx* c, int32_t slot, int32_t B, co
                                     : assemble_launch<float>(c, slot, B, rd, dptr, st);
     if (rc) return rc;
     c->has_wrench[slot] = 1;
-    c->uploaded[slot] = 1;
+    c->uploaded[slot] = B;
     return IRLOSC_OK;
 }
 
@@ -475,7 +476,7 @@ extern "C" int irlosc_set_targets(irlosc_ctx* c, int32_t slot, int32_t B, const 
     if (!c) return IRLOSC_ERR_ARG;
     int rc = check_slot(c, slot, B);
     if (rc) return rc;
-    if (B == 0) { c->targeted[slot] = 1; return IRLOSC_OK; }
+    if (B == 0) { c->targeted[slot] = -1; return IRLOSC_OK; }
     if (!tgt_pose) return fail(c, IRLOSC_ERR_ARG, "tgt_pose is NULL");
     HIPCHK(c, hipSetDevice(c->cfg.hip_device));
     const size_t b = (size_t)B, nd = (size_t)c->cfg.ndev, e = c->esz;
@@ -483,7 +484,7 @@ extern "C" int irlosc_set_targets(irlosc_ctx* c, int32_t slot, int32_t B, const 
     if (tgt_vel) HIPCHK(c, hipMemcpyAsync(c->dtvel[slot], tgt_vel, b * nd * 6 * e, hipMemcpyHostToDevice, c->stream));
     c->has_tvel[slot] = tgt_vel != nullptr;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->targeted[slot] = 1;
+    c->targeted[slot] = B;
     return IRLOSC_OK;
 }
 
@@ -643,9 +644,19 @@ static int launch(irlosc_ctx* c, int B, const void* M, const void* J, const void
     return launch_t<float>(c, B, M, J, dq, bias, ee, tgt, tvel, wrench, u, flags, st);
 }
 
-static int launch_slot(irlosc_ctx* c, int slot, int B) {
+// A step over B instances needs B instances of state AND of targets in the slot (stale or uninitialised HBM otherwise).
+static int check_slot_filled(irlosc_ctx* c, int slot, int B) {
     if (!c->uploaded[slot] || !c->targeted[slot])
         return fail(c, IRLOSC_ERR_STATE, "slot %d: irlosc_upload and irlosc_set_targets must precede a step", slot);
+    if (B > std::max(0, c->uploaded[slot]) || B > std::max(0, c->targeted[slot]))
+        return fail(c, IRLOSC_ERR_STATE, "slot %d holds state for %d and targets for %d instances, step asked for %d", slot,
+                    std::max(0, c->uploaded[slot]), std::max(0, c->targeted[slot]), B);
+    return IRLOSC_OK;
+}
+
+static int launch_slot(irlosc_ctx* c, int slot, int B) {
+    int rcf = check_slot_filled(c, slot, B);
+    if (rcf) return rcf;
     return launch(c, B, c->dM[slot], c->dJ[slot], c->ddq[slot], c->dbias[slot], c->dee[slot], c->dtgt[slot],
                   c->has_tvel[slot] ? c->dtvel[slot] : nullptr, c->has_wrench[slot] ? c->dwrench[slot] : nullptr,
                   c->du, c->dflags, c->stream);
@@ -723,8 +734,8 @@ static int resident_trains(irlosc_ctx* c, int first_slot, int B, int iters, cons
         int sets[irlosc_ctx::TRAIN_MAX];
         for (int i = 0; i < n; ++i) {
             const int slot = (first_slot + done + i) % c->cfg.n_slots;
-            if (!c->uploaded[slot] || !c->targeted[slot])
-                return fail(c, IRLOSC_ERR_STATE, "slot %d: irlosc_upload and irlosc_set_targets must precede a step", slot);
+            int rcf = check_slot_filled(c, slot, B);
+            if (rcf) return rcf;
             sets[i] = c->set_half * c->train + i;
             slot_params(c, ps[i], slot, B, sets[i]);
         }
@@ -884,21 +895,22 @@ extern "C" int irlosc_upload_q(irlosc_ctx* c, int32_t slot, int32_t B, const dou
     int rc = check_slot(c, slot, B);
     if (rc) return rc;
     if (!c->dmodel) return fail(c, IRLOSC_ERR_STATE, "irlosc_set_model has not been called");
-    if (B == 0) { c->has_q[slot] = 1; return IRLOSC_OK; }
+    if (B == 0) { c->has_q[slot] = -1; return IRLOSC_OK; }
     if (!qpos || !qvel) return fail(c, IRLOSC_ERR_ARG, "qpos and qvel are required");
     HIPCHK(c, hipSetDevice(c->cfg.hip_device));
     const size_t bytes = (size_t)B * c->cfg.n * sizeof(double);
     HIPCHK(c, hipMemcpyAsync(c->dqpos[slot], qpos, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->dqvel[slot], qvel, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->has_q[slot] = 1;
+    c->has_q[slot] = B;
     return IRLOSC_OK;
 }
 
 static int frontend_launch(irlosc_ctx* c, int slot, int B) {
     if (!c->dmodel) return fail(c, IRLOSC_ERR_STATE, "irlosc_set_model has not been called");
     if (!c->has_q[slot]) return fail(c, IRLOSC_ERR_STATE, "slot %d: irlosc_upload_q must precede irlosc_frontend", slot);
-    if (B == 0) { c->uploaded[slot] = 1; return IRLOSC_OK; }
+    if (B == 0) { c->uploaded[slot] = -1; return IRLOSC_OK; }
+    if (B > c->has_q[slot]) return fail(c, IRLOSC_ERR_STATE, "slot %d holds joint coordinates of %d instances, front end asked for %d", slot, std::max(0, c->has_q[slot]), B);
     const dim3 grid(std::min(B, 1 << 20));
     if (c->cfg.dtype == IRLOSC_F64) {
         const FeOut<double> o{(double*)c->dM[slot], (double*)c->dJ[slot], (double*)c->ddq[slot], (double*)c->dbias[slot], (double*)c->dee[slot]};
@@ -908,7 +920,7 @@ static int frontend_launch(irlosc_ctx* c, int slot, int B) {
         hipLaunchKernelGGL(osc_frontend_kernel<float>, grid, dim3(64), 0, c->stream, c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B);
     }
     HIPCHK(c, hipGetLastError());
-    c->uploaded[slot] = 1;
+    c->uploaded[slot] = std::max(c->uploaded[slot], B);
     return IRLOSC_OK;
 }
 

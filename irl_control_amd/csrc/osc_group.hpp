@@ -344,7 +344,9 @@ __device__ __forceinline__ void stage2_body(const S2Args a, int blk, int32_t* ld
         // hand t over to the wave: u -= J^T t is done four lanes per instance (coalesced 16-byte groups of J and u)
 #pragma unroll
         for (int r = 0; r < K; ++r) tl[lane * K + r] = t[r];
-        fll[lane] = (m > 0 ? IRLOSC_FLAG_TRUNCATED : 0u) | (giveup ? 0x80000000u : 0u);
+        // the flags must name the branch actually taken here: a failed unshifted factorisation set det = 0, i.e. the
+        // reference's pinv branch (osc.py:52-55), even where stage 1's fp32 pivot product had stayed above 1e-4
+        fll[lane] = (m > 0 ? IRLOSC_FLAG_TRUNCATED : 0u) | (trunc ? IRLOSC_FLAG_PINV_BRANCH : 0u) | (giveup ? 0x80000000u : 0u);
         __syncthreads();
         const int nlive = (count - round * 64) < 64 ? (count - round * 64) : 64;
         for (int grp4 = 0; grp4 * TILE < nlive; ++grp4) {

@@ -110,7 +110,7 @@ class OSC():
                       k=[c['k'] for c in cc], d=[c['d'] for c in cc], max_vel=mv,
                       null_kv=(self.nullspace_config['kv'] if self.nullspace_config is not None else 0.0))
         # one library call per tick: one copy in, the step, one copy out, one synchronisation (irlosc_tick)
-        u, fl = ctx.tick(M, J, dq, bias, ee, tp, tgt_vel=tv, wrench=wr, return_flags=True)
+        u, fl = ctx.tick(M, J, dq, bias, ee, tp, tgt_vel=tv, wrench=wr, return_flags=True, check_symmetric=True)
         self.last_flags = int(fl[0])
         if self.last_flags & _lib.FLAG_BAD_JIDX:
             raise IndexError("target-velocity branch indexed dx out of range (osc.py:176)")

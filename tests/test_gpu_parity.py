@@ -758,3 +758,24 @@ def test_frontend_needs_a_model_and_coordinates():
     with pytest.raises(_lib.IrloscError, match="irlosc_upload_q"):
         osc.frontend()
     osc.close()
+
+
+def test_step_refuses_more_instances_than_the_slot_holds():
+    """state, targets and step sizes are tied together: stepping over more instances than were uploaded (or
+    targeted) is IRLOSC_ERR_STATE instead of a silent pass over stale HBM; an asymmetric M is refused on request."""
+    lay, gains, g = synth.make_batch("k13", 32, seed=2)
+    osc = BatchedOSC(lay, 64, dtype=np.float64)
+    osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+    osc.upload(g["M"][:16], g["J"][:16], g["dq"][:16], g["bias"][:16], g["ee_pose"][:16])
+    with pytest.raises(ValueError, match="holds 16"):
+        osc.set_targets(g["tgt_pose"][:8])
+    osc.set_targets(g["tgt_pose"][:16])
+    u = np.empty((32, 25)); fl = np.empty(32, dtype=np.uint32)
+    rc = osc.lib.irlosc_step(osc._h, 0, 32, _lib.ptr(u), _lib.ptr(fl))
+    assert rc == -3 and b"holds state for 16" in osc.lib.irlosc_last_error(osc._h)
+    assert osc.lib.irlosc_step(osc._h, 0, 16, _lib.ptr(u), _lib.ptr(fl)) == 0
+    Masym = g["M"][:4].copy()
+    Masym[2, 3, 7] += 1.0
+    with pytest.raises(ValueError, match="instance 2 is not symmetric"):
+        osc.upload(Masym, g["J"][:4], g["dq"][:4], g["bias"][:4], g["ee_pose"][:4], check_symmetric=True)
+    osc.close()
