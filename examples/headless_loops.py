@@ -93,3 +93,40 @@ def admit_test_loop(robot, controller, Target, DeviceState, sim, ticks, push_win
         sim.step()
     rec["forces"] = np.array(rec["forces"])
     return rec
+
+
+def force_test_loop(robot, controller, Target, DeviceState, sim, ticks, dyn=None, threshold_ee=0.01):
+    """examples/force_test.py:57-127: admittance controller, the left arm walks a line of waypoints (threshold 1 cm)
+    with orientation target abg = [0, 0, -pi/2], and the left F/T force is read back after every step (the reference
+    logs it to data.csv; `mj_inverse` refreshes the sensors there, here `sim.inverse()` is called when the backend has it)."""
+    right_wps = np.array([[0.3, 0.46432, 0.36243]])
+    left_wps = np.array([[-0.3, y, 0.5] for y in (0.46432, 0.5, 0.55, 0.575, 0.6, 0.625, 0.65, 0.675, 0.7, 0.75)])
+    targets = {"ur5right": Target(), "ur5left": Target()}
+    ur5left = robot.sub_devices_dict["ur5left"]
+    ri = li = 0
+    rec = dict(forces=[], wp=[], ft=[], idxs=None)
+    for _ in range(ticks):
+        targets["ur5right"].set_xyz(right_wps[ri])
+        targets["ur5left"].set_xyz(left_wps[li])
+        targets["ur5left"].set_abg(np.array([0, 0, -1 * np.pi / 2]))
+        sim.data.set_mocap_pos("target_red", right_wps[ri])
+        sim.data.set_mocap_pos("target_blue", left_wps[li])
+        force_idxs, forces = controller.generate(targets)
+        for force_idx, force in zip(force_idxs, forces):
+            sim.data.ctrl[force_idx] = force
+        err_l = np.linalg.norm(ur5left.get_state(DeviceState.EE_XYZ) - targets["ur5left"].get_xyz())
+        if err_l < threshold_ee:
+            li = li + 1 if li < left_wps.shape[0] - 1 else 0
+        if dyn is not None:
+            dyn.goal_xyz = {EE_BODY["ur5right"]: right_wps[ri], EE_BODY["ur5left"]: left_wps[li]}
+            dyn.goal_quat = {EE_BODY["ur5left"]: targets["ur5left"].get_quat()}
+        sim.step()
+        if hasattr(sim, "inverse"):
+            sim.inverse()
+        rec["forces"].append(np.concatenate([np.asarray(f, dtype=np.float64) for f in forces]))
+        rec["wp"].append((ri, li))
+        rec["ft"].append(np.array(ur5left.get_state(DeviceState.FORCE), dtype=np.float64))
+        if rec["idxs"] is None:
+            rec["idxs"] = [np.asarray(x).tolist() for x in force_idxs]
+    rec["forces"] = np.array(rec["forces"]); rec["wp"] = np.array(rec["wp"]); rec["ft"] = np.array(rec["ft"])
+    return rec

@@ -2,8 +2,9 @@
 (API of /root/reference/irl_control/mujoco_app.py:10-62).
 
 The simulator is a backend: pass ``sim=`` (anything exposing the member set listed in
-irl_control_amd/fakesim.py, e.g. ``FakeSim()`` or a real mujoco_py ``MjSim``).  Without ``sim`` the
-scene file is loaded with mujoco_py exactly like the reference, if that package is installed.
+irl_control_amd/fakesim.py, e.g. ``FakeSim()``, a mujoco_py ``MjSim`` or ``mujoco_backend.MujocoSim``).
+Without ``sim`` the scene file is loaded with the official ``mujoco`` bindings (through the MujocoSim
+adapter) when they are installed, else with mujoco_py exactly like the reference.
 """
 import os
 import time
@@ -26,14 +27,20 @@ class MujocoApp():
         with open(cfg_path, 'r') as f:
             self.config = yaml.safe_load(f)
         if sim is None:
-            try:
-                from mujoco_py import MjSim, load_model_from_path
-            except ImportError as e:
-                raise ImportError("no simulator backend: pass sim=FakeSim() (or any MjSim-like "
-                                  "object); mujoco_py is not installed") from e
             scene = scene_file if os.path.isabs(scene_file) else os.path.join(_PKG_DIR, "scenes", scene_file)
-            self.model = load_model_from_path(scene)
-            self.sim = MjSim(self.model)
+            try:
+                import mujoco  # noqa: F401
+                from .mujoco_backend import MujocoSim
+                self.sim = MujocoSim.from_xml_path(scene)
+                self.model = self.sim.model
+            except ImportError:
+                try:
+                    from mujoco_py import MjSim, load_model_from_path
+                except ImportError as e:
+                    raise ImportError("no simulator backend: pass sim=FakeSim() (or any MjSim-like object); neither "
+                                      "mujoco nor mujoco_py is installed") from e
+                self.model = load_model_from_path(scene)
+                self.sim = MjSim(self.model)
         else:
             self.sim = sim
             self.model = sim.model

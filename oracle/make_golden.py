@@ -264,6 +264,8 @@ def make_loop_case(name, seed, ticks, kind, cfg_file, dev_gain_names, admittance
     robot, osc = build_reference(cfg, sim, dev_gain_names, True, True, admittance)
     if kind == "gain_test":
         rec = loops.gain_test_loop(robot, osc, RefTarget, RefDeviceState, sim, ticks, None, dyn)
+    elif kind == "force_test":
+        rec = loops.force_test_loop(robot, osc, RefTarget, RefDeviceState, sim, ticks, dyn)
     else:
         rec = loops.admit_test_loop(robot, osc, RefTarget, RefDeviceState, sim, ticks, push_window, dyn)
     meta = dict(kind=kind, seed=seed, ticks=ticks, cfg_file=cfg_file, idxs=rec["idxs"], push_window=list(push_window),
@@ -272,9 +274,12 @@ def make_loop_case(name, seed, ticks, kind, cfg_file, dev_gain_names, admittance
     if kind == "gain_test":
         arrays["wp"] = np.asarray(rec["wp"], dtype=np.int64)
         arrays["err"] = np.asarray(rec["err"], dtype=np.float64)
+    if kind == "force_test":
+        arrays["wp"] = np.asarray(rec["wp"], dtype=np.int64)
+        arrays["ft"] = np.asarray(rec["ft"], dtype=np.float64)
     path = os.path.join(OUT_DIR, f"{name}.npz")
     np.savez_compressed(path, **arrays)
-    extra = f", {int((np.diff(arrays['wp'], axis=0) != 0).sum())} waypoint switches" if kind == "gain_test" else ""
+    extra = f", {int((np.diff(arrays['wp'], axis=0) != 0).sum())} waypoint switches" if "wp" in arrays else ""
     print(f"{name:28s} {ticks} ticks of the {kind} loop{extra} -> {os.path.getsize(path) // 1024} KiB")
 
 
@@ -311,5 +316,7 @@ if __name__ == "__main__":
     make_loop_case("loop_gain_test", 0, 160, "gain_test", "default_xyz.yaml", G_GAIN)
     make_loop_case("loop_admit_test", 0, 120, "admit_test", "default_xyz_abg.yaml", G_ADMIT, admittance=True,
                    n_free_bodies=2, push_window=(40, 80))
+    make_loop_case("loop_force_test", 0, 240, "force_test", "default_xyz_abg.yaml",
+                   [("ur5right", "osc1"), ("ur5left", "osc1")], admittance=True, n_free_bodies=1)
     make_case("k13_no_max_vel", S + 12, 8, "default_xyz_abg.yaml", RLB, G_GAIN, all_actuated=True,
               no_max_vel=("ur5left",))

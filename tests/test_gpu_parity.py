@@ -779,3 +779,16 @@ def test_step_refuses_more_instances_than_the_slot_holds():
     with pytest.raises(ValueError, match="instance 2 is not symmetric"):
         osc.upload(Masym, g["J"][:4], g["dq"][:4], g["bias"][:4], g["ee_pose"][:4], check_symmetric=True)
     osc.close()
+
+
+def test_force_test_loop_matches_reference_tick_by_tick():
+    """examples/force_test.py:57-127 headless (osc1 gains, admittance, left arm along a line of waypoints at 1 cm,
+    F/T force read back after every step): forces of all 240 ticks, the waypoint indices and the logged sensor force."""
+    g, meta = _load_loop_golden("loop_force_test")
+    mod = _load_example("force_test_headless")
+    rec = mod.run(ticks=meta["ticks"], seed=meta["seed"], verbose=False)
+    assert rec["idxs"] == meta["idxs"]
+    assert np.array_equal(rec["wp"], g["wp"]) and g["wp"][:, 1].max() >= 2
+    assert np.array_equal(rec["ft"], g["ft"])
+    err = np.abs(rec["forces"] - g["forces"]).max(axis=1) / np.abs(g["forces"]).max(axis=1)
+    assert err.max() <= TOL64, float(err.max())

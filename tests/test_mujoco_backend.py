@@ -1,0 +1,87 @@
+"""mujoco_backend.MujocoSim against a stand-in ``mujoco`` module with the official
+bindings' call signatures (MuJoCo itself is in neither image): every member Device / Robot / OSC read must come out in
+mujoco_py's shapes, and the whole host assembly must run on it and equal the same state fed through FakeSim."""
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from irl_control_amd import fakesim
+
+
+def _fake_mujoco(fs: "fakesim.FakeSim"):
+    """A module object that answers the official API from the arrays of a FakeSim."""
+    mj = types.ModuleType("mujoco")
+    mj.mjtObj = types.SimpleNamespace(mjOBJ_BODY=1, mjOBJ_JOINT=3, mjOBJ_SITE=6)
+    sites = list(fs.data.site_xmat)
+
+    class MjModel:
+        __module__ = "mujoco._structs"
+        nv, nu = fs.model.nv, fs.model.nu
+        body_parentid, body_jntadr, body_jntnum = fs.model.body_parentid, fs.model.body_jntadr, fs.model.body_jntnum
+        jnt_qposadr, actuator_trnid = fs.model.jnt_qposadr, fs.model.actuator_trnid
+        body_mocapid = np.array([0 if n == "target_red" else 1 if n == "target_blue" else -1 for n in fs.model.body_names])
+
+    class MjData:
+        def __init__(self, m):
+            d = fs.data
+            self.qpos, self.qvel, self.qacc, self.qM = d.qpos, d.qvel, d.qacc, d.qM
+            self.qfrc_bias, self.sensordata, self.ctrl, self.xfrc_applied = d.qfrc_bias, d.sensordata, d.ctrl, d.xfrc_applied
+            self.xpos, self.xquat = d.body_xpos, d.body_xquat
+            self.site_xmat = np.array([d.site_xmat[s].reshape(-1) for s in sites])
+            self.mocap_pos = np.zeros((2, 3))
+
+    def name2id(m, kind, name):
+        table = {1: fs.model.body_names, 3: fs.model.joint_names, 6: sites}[kind]
+        return table.index(name) if name in table else -1
+
+    def jac(m, d, jp, jr, bid):
+        jp[:] = fs.data.body_jacp[bid].reshape(3, -1)
+        jr[:] = fs.data.body_jacr[bid].reshape(3, -1)
+
+    def objvel(m, d, kind, bid, out, local):
+        out[3:] = fs.data.body_xvelp[bid]
+
+    def fullM(m, dst, qM):
+        dst[:] = np.asarray(qM).reshape(dst.shape)
+
+    calls = []
+    mj.MjModel, mj.MjData = MjModel, MjData
+    mj.mj_name2id, mj.mj_id2name = name2id, lambda m, kind, i: fs.model.joint_names[i]
+    mj.mj_jacBody, mj.mj_objectVelocity, mj.mj_fullM = jac, objvel, fullM
+    mj.mj_forward = lambda m, d: calls.append("forward")
+    mj.mj_step = lambda m, d: calls.append("step")
+    mj.mj_inverse = lambda m, d: calls.append("inverse")
+    mj._calls = calls
+    return mj
+
+
+def test_adapter_serves_the_member_set_and_the_host_assembly(monkeypatch):
+    import irl_control_amd as ic
+    from irl_control_amd import backend
+    from irl_control_amd.mujoco_backend import MujocoSim
+    fs = fakesim.randomize(fakesim.FakeSim(), np.random.default_rng(3), wrench=True)
+    mj = _fake_mujoco(fs)
+    monkeypatch.setitem(sys.modules, "mujoco", mj)
+    sim = MujocoSim(mj.MjModel())
+    assert backend.backend_of(sim) == "injected"
+    assert sim.model.body_name2id("ur_EE_ur5left") == fs.model.body_name2id("ur_EE_ur5left")
+    with pytest.raises(ValueError, match='No "body" with name nope exists'):
+        sim.model.body_name2id("nope")
+    assert sim.data.get_body_jacp("ur_EE_ur5right").shape == (3 * fs.model.nv,)
+    assert np.array_equal(sim.data.get_site_xmat("ft_frame_ur5left"), fs.data.site_xmat["ft_frame_ur5left"])
+    assert np.array_equal(sim.fullM(), fs.fullM())
+    sim.forward(); sim.step(); sim.inverse()
+    assert mj._calls == ["forward", "step", "inverse"]
+    sim.data.set_mocap_pos("target_blue", [1, 2, 3])
+    assert np.array_equal(sim.mj_data.mocap_pos[1], [1, 2, 3])
+    # the whole state assembly (Device / Robot) on the adapter equals the same on FakeSim, bit for bit
+    app_a = ic.MujocoApp("default_xyz_abg.yaml", None, sim=sim)
+    app_f = ic.MujocoApp("default_xyz_abg.yaml", None, sim=fs)
+    sa, sf = app_a.get_robot("DualUR5").get_all_states(), app_f.get_robot("DualUR5").get_all_states()
+    assert np.array_equal(sa[ic.RobotState.M], sf[ic.RobotState.M]) and np.array_equal(sa[ic.RobotState.DQ], sf[ic.RobotState.DQ])
+    for nm in ("base", "ur5right", "ur5left"):
+        assert np.array_equal(sa[ic.RobotState.J][0][nm], sf[ic.RobotState.J][0][nm])
+        for key in (ic.DeviceState.EE_XYZ, ic.DeviceState.EE_QUAT, ic.DeviceState.FORCE, ic.DeviceState.TORQUE):
+            assert np.array_equal(sa[nm][key], sf[nm][key])
