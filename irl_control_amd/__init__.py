@@ -13,3 +13,4 @@ from .batched import BatchedOSC  # noqa: F401
 from .osc import OSC  # noqa: F401
 from .mujoco_app import MujocoApp  # noqa: F401
 from .fakesim import FakeSim  # noqa: F401
+from .action_sequence import ActionSequenceRunner  # noqa: F401

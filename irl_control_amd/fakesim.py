@@ -62,7 +62,7 @@ def dual_ur5_actuated_joints():
 
 class FakeModel:
     def __init__(self, body_names, body_parent, body_joints, actuated_joints,
-                 n_free_bodies: int = 0):
+                 n_free_bodies: int = 0, free_joint_names=None):
         self.body_names = list(body_names)
         self.body_parentid = np.asarray(body_parent, dtype=np.int32)
         self.joint_names: List[str] = []
@@ -78,7 +78,12 @@ class FakeModel:
         self.n_free_bodies = n_free_bodies
         self.nv = self.nq_robot + 6 * n_free_bodies
         self.nq = self.nq_robot + 7 * n_free_bodies
-        self.jnt_qposadr = np.arange(self.nq_robot, dtype=np.int32)
+        # free joints (7 qpos / 6 dofs each) behind the robot's hinges; named so that action objects can be addressed
+        # (action_sequence_configs/insertion_task.yaml: joint_name)
+        self.free_joint_names = list(free_joint_names) if free_joint_names is not None else \
+            [f"free_joint_{i}" for i in range(n_free_bodies)]
+        assert len(self.free_joint_names) == n_free_bodies
+        self.jnt_qposadr = np.concatenate([np.arange(self.nq_robot), self.nq_robot + 7 * np.arange(n_free_bodies)]).astype(np.int32)
         trn = [self.joint_names.index(j) for j in actuated_joints]
         self.actuator_trnid = np.stack([np.asarray(trn, dtype=np.int32),
                                         np.full(len(trn), -1, dtype=np.int32)], axis=1)
@@ -95,6 +100,8 @@ class FakeModel:
         return self.joint_names[int(jid)]
 
     def joint_name2id(self, name: str) -> int:
+        if name in self.free_joint_names:
+            return self.nq_robot + self.free_joint_names.index(name)
         return self.joint_names.index(name)
 
 
@@ -128,16 +135,24 @@ class FakeData:
     def set_mocap_pos(self, name, pos):
         self.body_xpos[self._bid(name)] = pos
 
+    def get_joint_qpos(self, name):
+        """qpos of a joint: one value for a hinge, pos + quat (7) for a free joint (mujoco_py's MjSimState helper)."""
+        m = self._model
+        adr = m.jnt_qposadr[m.joint_name2id(name)]
+        return self.qpos[adr:adr + 7] if name in m.free_joint_names else self.qpos[adr]
+
 
 class FakeSim:
     """``MjSim`` look-alike.  ``dynamics`` (optional) is called by forward()/step() to refresh the
     derived arrays from qpos/qvel; without it the arrays are whatever the caller wrote."""
 
     def __init__(self, model: Optional[FakeModel] = None, n_free_bodies: int = 0,
-                 dynamics: Optional[Callable[["FakeSim"], None]] = None):
+                 dynamics: Optional[Callable[["FakeSim"], None]] = None, free_joint_names=None):
         if model is None:
             names, parent, joints = dual_ur5_tree()
-            model = FakeModel(names, parent, joints, dual_ur5_actuated_joints(), n_free_bodies)
+            if free_joint_names is not None:
+                n_free_bodies = len(free_joint_names)
+            model = FakeModel(names, parent, joints, dual_ur5_actuated_joints(), n_free_bodies, free_joint_names)
         self.model = model
         self.data = FakeData(model, ["ft_frame_ur5right", "ft_frame_ur5left"])
         self.dynamics = dynamics
@@ -248,6 +263,7 @@ class ToyDynamics:
         self.goal_xyz: Dict[str, np.ndarray] = {}
         self.goal_quat: Dict[str, np.ndarray] = {}
         self.ft_bodies = {"left_outer_knuckle_ur5right": 0, "left_outer_knuckle_ur5left": 6}   # body -> sensordata offset
+        self.goal_provider = None     # optional callable -> (goal_xyz dict, goal_quat dict), asked at every step
         self.t = 0
         self._init = None
 
@@ -259,6 +275,8 @@ class ToyDynamics:
             self._init = (d.body_jacp.copy(), d.body_jacr.copy(), d.qvel.copy(), d.qfrc_bias.copy(), d.sensordata.copy())
         jp0, jr0, qv0, b0, s0 = self._init
         self.t += 1
+        if self.goal_provider is not None:
+            self.goal_xyz, self.goal_quat = self.goal_provider()
         for body, xyz in self.goal_xyz.items():
             b = sim.model.body_name2id(body)
             d.body_xpos[b] += self.rate * (np.asarray(xyz, dtype=np.float64) - d.body_xpos[b])

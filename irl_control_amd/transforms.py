@@ -76,3 +76,21 @@ def euler2quat(ai, aj, ak):
     ck, sk = math.cos(ak), math.sin(ak)
     cc, cs, sc, ss = ci * ck, ci * sk, si * ck, si * sk
     return np.array([cj * cc + sj * ss, cj * sc - sj * cs, cj * ss + sj * cc, cj * cs - sj * sc])
+
+
+def euler2mat(ai, aj, ak):
+    """'sxyz' Euler angles -> rotation matrix (transforms3d.euler.euler2mat): Rz(ak) Ry(aj) Rx(ai)."""
+    si, sj, sk = math.sin(ai), math.sin(aj), math.sin(ak)
+    ci, cj, ck = math.cos(ai), math.cos(aj), math.cos(ak)
+    cc, cs, sc, ss = ci * ck, ci * sk, si * ck, si * sk
+    return np.array([[cj * ck, sj * sc - cs, sj * cc + ss],
+                     [cj * sk, sj * ss + cc, sj * cs - sc],
+                     [-sj, cj * si, cj * ci]])
+
+
+def compose(T, R, Z):
+    """4 x 4 affine from translation, rotation matrix and zooms (transforms3d.affines.compose, no shear)."""
+    A = np.eye(4)
+    A[:3, :3] = np.asarray(R, dtype=np.float64) * np.asarray(Z, dtype=np.float64)[None, :]
+    A[:3, 3] = T
+    return A

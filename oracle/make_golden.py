@@ -283,6 +283,63 @@ def make_loop_case(name, seed, ticks, kind, cfg_file, dev_gain_names, admittance
     print(f"{name:28s} {ticks} ticks of the {kind} loop{extra} -> {os.path.getsize(path) // 1024} KiB")
 
 
+INSERTION_FREE_JOINTS = ["free_joint_grommet_11mm", "free_joint_dual_peg", "free_joint_female", "free_joint_male"]
+
+
+def insertion_wp_sequence():
+    """The WP entries of the reference's insertion action list (the GRIP entries run on a wall-clock timer in the
+    reference, insertion_task.py:193-205, so their tick counts are not reproducible and they are left out of the golden)."""
+    with open("/root/reference/irl_control/action_sequence_configs/insertion_task.yaml") as f:
+        cfg = yaml.safe_load(f)
+    return cfg, [e for e in cfg["insertion_action_sequence"] if e["action"] == "WP"]
+
+
+def make_insertion_golden(name, seed, active_arm="right", objects="nist_action_objects", rate=0.08):
+    """Per-tick golden of the action-sequence state machine: the REFERENCE's own
+    InsertionTask methods (set_waypoint_targets, go_to_waypoint, send_forces, initialize_action_objects, run_sequence;
+    examples/insertion_task.py:146-318) on a FakeSim with free joints and ToyDynamics.  The object is created without
+    its constructor (which loads MuJoCo and opens a viewer); everything it would have set up is supplied here."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_insertion_task", "/root/reference/irl_control/examples/insertion_task.py")
+    it_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(it_mod)
+    from mujoco_py.mjviewer import MjViewer
+    rng = np.random.default_rng(seed)
+    cfg = load_cfg("default_xyz_abg.yaml")
+    dyn = fakesim.ToyDynamics(rate=rate)
+    sim = fakesim.randomize(fakesim.FakeSim(free_joint_names=INSERTION_FREE_JOINTS, dynamics=dyn), rng)
+    robot, osc = build_reference(cfg, sim, G_GAIN, True, True, False)
+    it = it_mod.InsertionTask.__new__(it_mod.InsertionTask)
+    it.sim, it.model, it.robot, it.controller = sim, sim.model, robot, osc
+    it.ur5right, it.ur5left = robot.get_device("ur5right"), robot.get_device("ur5left")
+    it.set_active_arm(active_arm)
+    it.errors = dict()
+    it.viewer = MjViewer(sim)
+    it.action_map = it.get_action_map()
+    it.DEFAULT_PARAMS = dict([(a, it.get_default_action_ctrl_params(a)) for a in it_mod.Action])
+    it.targets = {it.active_arm.name: RefTarget(), it.passive_arm.name: RefTarget()}
+    it.timer_running = False
+    acfg, seq = insertion_wp_sequence()
+    it.action_objects = acfg[objects]
+    it.initialize_action_objects()
+    ee = {"ur5right": "ur_EE_ur5right", "ur5left": "ur_EE_ur5left"}
+    dyn.goal_provider = lambda: ({ee[n]: t.get_xyz() for n, t in it.targets.items()},
+                                 {ee[n]: t.get_quat() for n, t in it.targets.items()})
+    rec = dict(ctrl=[], max_vel=[])
+
+    def on_render():
+        rec["ctrl"].append(np.array(sim.data.ctrl))
+        rec["max_vel"].append(float(it.active_arm.max_vel[0]))
+    it.viewer.on_render = on_render
+    it.run_sequence(seq)
+    meta = dict(seed=seed, active_arm=active_arm, objects=objects, rate=rate, free_joints=INSERTION_FREE_JOINTS,
+                n_wp=len(seq), ticks=len(rec["ctrl"]))
+    arrays = dict(ctrl=np.asarray(rec["ctrl"]), max_vel=np.asarray(rec["max_vel"]), layout_json=np.array(json.dumps(meta)))
+    path = os.path.join(OUT_DIR, f"{name}.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name:28s} {len(seq)} WP actions, {len(rec['ctrl'])} ticks -> {os.path.getsize(path) // 1024} KiB")
+
+
 RLB = ("ur5right", "ur5left", "base")
 BRL = ("base", "ur5right", "ur5left")
 G_GAIN = [("base", "osc0"), ("ur5right", "osc2"), ("ur5left", "osc2")]
@@ -318,5 +375,6 @@ if __name__ == "__main__":
                    n_free_bodies=2, push_window=(40, 80))
     make_loop_case("loop_force_test", 0, 240, "force_test", "default_xyz_abg.yaml",
                    [("ur5right", "osc1"), ("ur5left", "osc1")], admittance=True, n_free_bodies=1)
+    make_insertion_golden("loop_insertion_wp", 0)
     make_case("k13_no_max_vel", S + 12, 8, "default_xyz_abg.yaml", RLB, G_GAIN, all_actuated=True,
               no_max_vel=("ur5left",))

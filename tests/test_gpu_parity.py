@@ -792,3 +792,17 @@ def test_force_test_loop_matches_reference_tick_by_tick():
     assert np.array_equal(rec["ft"], g["ft"])
     err = np.abs(rec["forces"] - g["forces"]).max(axis=1) / np.abs(g["forces"]).max(axis=1)
     assert err.max() <= TOL64, float(err.max())
+
+
+def test_insertion_action_sequence_matches_reference_tick_by_tick():
+    """examples/insertion_task.py:146-318 headless: the eight WP actions of the insertion sequence (object-relative
+    waypoints, error-adaptive max_vel) run by ActionSequenceRunner with OSC.generate on the HIP path, against the golden
+    the REFERENCE's own InsertionTask methods produced on the same FakeSim: same number of ticks, same velocity limit
+    and same ctrl vector on every tick."""
+    g, meta = _load_loop_golden("loop_insertion_wp")
+    mod = _load_example("insertion_task_headless")
+    rec = mod.run(seed=meta["seed"], active_arm=meta["active_arm"], objects=meta["objects"], rate=meta["rate"], verbose=False)
+    assert rec["ticks"] == meta["ticks"] == len(g["ctrl"]) and rec["n_actions"] == meta["n_wp"]
+    assert np.allclose(rec["max_vel"], g["max_vel"], rtol=1e-9, atol=0)
+    err = np.abs(rec["ctrl"] - g["ctrl"]).max(axis=1) / np.abs(g["ctrl"]).max(axis=1)
+    assert err.max() <= TOL64, float(err.max())
