@@ -806,3 +806,20 @@ def test_insertion_action_sequence_matches_reference_tick_by_tick():
     assert np.allclose(rec["max_vel"], g["max_vel"], rtol=1e-9, atol=0)
     err = np.abs(rec["ctrl"] - g["ctrl"]).max(axis=1) / np.abs(g["ctrl"]).max(axis=1)
     assert err.max() <= TOL64, float(err.max())
+
+
+def test_tick_latency_b1_is_bounded():
+    """The B = 1 drop-in path costs one library call and one synchronisation per tick (42 us
+    median on the row16 kernel); bound it generously so that a regression to several round trips shows."""
+    import time
+    lay, gains, g = synth.make_batch("k13", 16, seed=1)
+    osc = BatchedOSC(lay, 1, dtype=np.float64)
+    osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+    a = [g[k][:1] for k in ("M", "J", "dq", "bias", "ee_pose", "tgt_pose")]
+    for _ in range(50):
+        osc.tick(*a)
+    t = []
+    for _ in range(200):
+        t0 = time.perf_counter(); osc.tick(*a); t.append(time.perf_counter() - t0)
+    osc.close()
+    assert np.median(t) < 250e-6, float(np.median(t))
