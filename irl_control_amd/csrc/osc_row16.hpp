@@ -180,16 +180,19 @@ __device__ __forceinline__ double matvec16(const double x, const double (&Ac)[K]
 }
 
 // t = pinv(A, rcond 1e-5) w for the rows of the wave with `flagged` set (osc.py:55; A symmetric positive semi-definite):
-//   lambda_max by power iteration (Rayleigh quotient; iterated further only where a candidate sits within 2 % of the cut),
-//   the eigenpairs under 1e-5 lambda_max one at a time by deflated inverse iteration through the factorisation the
-//   caller already has (A + 2^-40 ||A||_F I is factored here instead where that one broke down: exactly singular J),
-//   t = P A^-1 P w with P the projector off those eigenvectors.  More than three of them: give up (-> Jacobi).
+//   the eigenpairs under the "net" 4e-5 ||A||_F one at a time by deflated inverse iteration through the factorisation
+//   the caller already has (A + 2^-40 ||A||_F I is factored here instead where that one broke down: exactly singular J);
+//   the search stops as soon as trace(A^-1) minus the candidates found proves that nothing else can lie under the net;
+//   Rayleigh-Ritz on the span of the candidates when there are several; lambda_max is only bracketed
+//   (max diagonal <= lambda_max <= ||A||_F) unless a candidate falls inside the bracket of the cut, in which case it is
+//   computed (power iteration + Rayleigh quotient, iterated further only where a candidate sits within 2 % of the cut);
+//   t = P A^-1 P w with P the projector off the eigenvectors at or under 1e-5 lambda_max.  Net full: give up (-> Jacobi).
 // Every quantity is uniform over the 16 lanes of an instance and frozen at the instance's own convergence, so a
 // result never depends on the other instances of the wave (sharding a batch differently changes no bit).
 template <int K>
 __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], double (&G)[K], double& invd_own, const bool pdA,
-                                        const double nA2, const double w, const int l, const bool flagged, double& t,
-                                        uint32_t& fl, bool& giveup) {
+                                        const double nA2, const double trA, const double w, const int l, const bool flagged,
+                                        double& t, uint32_t& fl, bool& giveup) {
     const double hi = sqrt(nA2);
     double sigma = 0.0;
     giveup = flagged && !(hi > 0.0 && t_finite(hi));
@@ -205,29 +208,26 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
         ldl16<K>(A2, l, sigma, F, G, invd_own, pd2, det2);
         giveup = giveup || (use && !pd2);
     }
-    // lambda_max
-    const double sc = rcp_refined(hi > 0.0 ? hi : 1.0);
-    double xp = l < K ? 0.2 + 0.05 * (double)((l * 7) % 5) : 0.0;
-    for (int it = 0; it < 24; ++it) xp = matvec16<K>(xp, Ac) * sc;
-    auto rayleigh = [&](double& x) {
-        const double n2 = row_sum(x * x);
-        x *= rsq_refined(n2 > 0.0 ? n2 : 1.0);
-        const double y = matvec16<K>(x, Ac);
-        const double lm = row_sum(x * y);
-        return (lm > 0.0 && lm <= hi * 1.0000001) ? lm : hi;
-    };
-    double lmax = rayleigh(xp);
-    double cutoff = 1e-5 * lmax;
-    // Candidate eigenpairs: everything under FOUR times the cut, one at a time by deflated inverse iteration.  The net
-    // is wider than the cut on purpose: two eigenvalues straddling the cut converge towards each other's mixtures
-    // (ratio close to 1), but the SPAN of the candidates converges at the rate of the gap to the first eigenvalue
-    // outside the net (<= 1/4 per iteration), and the Rayleigh-Ritz step below then separates them exactly.
+    // bracket of lambda_max: the largest diagonal entry is a Rayleigh quotient, the Frobenius norm an upper bound
+    double diag = 0.0;
+#pragma unroll
+    for (int r = 0; r < K; ++r) diag = (l == r) ? Ac[r] : diag;
+    double lo = diag;
+    lo = fmax(lo, dpp_mov64<0xB1>(lo)); lo = fmax(lo, dpp_mov64<0x4E>(lo));
+    lo = fmax(lo, dpp_mov64<0x141>(lo)); lo = fmax(lo, dpp_mov64<0x140>(lo));
+    lo = (lo > 0.0 && lo <= hi) ? lo : hi * 0.25;
+    const double net = 4e-5 * hi;
+    // Candidate eigenpairs: everything under the net, one at a time by deflated inverse iteration.  The net is wider than
+    // the cut on purpose: two eigenvalues straddling the cut converge towards each other's mixtures (ratio close to 1),
+    // but the SPAN of the candidates converges at the rate of the gap to the first eigenvalue outside the net (<= 1/4
+    // per iteration), and the Rayleigh-Ritz step below then separates them exactly.
     constexpr int NV = 4;
     double v[NV] = {0.0, 0.0, 0.0, 0.0};
     double th[NV] = {0.0, 0.0, 0.0, 0.0};      // Ritz value of v[i]
     bool has[NV] = {false, false, false, false};
     int m = 0;
     bool active = flagged && !giveup;
+    double rem = (pdA && sigma == 0.0 && trA > 0.0) ? trA : -1.0;      // trace(A^-1) minus 1/mu of the candidates found
 #pragma unroll
     for (int slot = 0; slot < NV; ++slot) {
         if (!__any(active)) break;
@@ -244,14 +244,14 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
             const double n2 = row_sum(xn * xn);
             const double rn = rsq_refined(n2 > 0.0 ? n2 : 1.0);
             const double lamn = rn - sigma;                 // 1 / ||(A + sigma)^-1 x|| -> lambda + sigma (from above)
-            const bool settled = fabs(lamn - lam_prev) <= 1e-10 * fabs(lamn) || lamn > 16.0 * cutoff;
+            const bool settled = fabs(lamn - lam_prev) <= 1e-10 * fabs(lamn) || lamn > 4.0 * net;
             x = fin ? x : xn * rn;
             lam = fin ? lam : lamn;
             lam_prev = lam;
             fin = fin || (it >= 3 && settled);
             if (!__any(!fin)) break;
         }
-        const bool cand = active && (lam <= 4.0 * cutoff);
+        const bool cand = active && (lam <= net);
         // final clean-up against the earlier vectors (the last solve re-introduced rounding-level components)
 #pragma unroll
         for (int s0 = 0; s0 < NV - 1; ++s0) {
@@ -265,7 +265,12 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
         th[slot] = cand ? lam : 0.0;
         has[slot] = cand;
         m += cand ? 1 : 0;
-        active = cand;
+        // what is left of trace(A^-1) bounds the next eigenvalue from below: lambda_next >= 1 / rem.  If that clears the
+        // net there is nothing more to find.  The candidate's eigenvalue is settled to 1e-10 relative, so the difference is
+        // trusted while it keeps 1e-7 of the minuend (three digits of margin).
+        rem = (cand && rem > 0.0 && lam > 0.0) ? rem - rcp_refined(lam) : (cand ? -1.0 : rem);
+        const bool exhausted = rem > 1e-7 * trA && rem * net < 1.0;
+        active = cand && !exhausted;
     }
     giveup = giveup || (m == NV);               // the net is full: there may be more under it (-> Jacobi)
     // Rayleigh-Ritz on the span of the candidates whenever an instance has more than one: H = V^T A V (4 x 4, the
@@ -312,17 +317,36 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
 #pragma unroll
         for (int i = 0; i < NV; ++i) th[i] = (m >= 2 && has[i]) ? h[i][i] - 0.0 : th[i];
     }
-    // a Ritz value within 2 % of the cut: sharpen lambda_max before deciding (rare; only those instances move)
-    bool amb = false;
+    // lambda_max itself is only needed where a Ritz value lies inside the bracket of the cut [1e-5 lo, 1e-5 hi]: then by
+    // power iteration + Rayleigh quotient, and further where the value still sits within 2 % of the cut.  An instance
+    // outside the bracket decides the same way for every lambda_max in [lo, hi], so nothing depends on its wave-mates.
+    double lmax = lo;
+    bool inside = false;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) amb = amb || (has[i] && fabs(th[i] - cutoff) < 0.02 * cutoff);
-    if (__any(amb)) {
-        for (int it = 0; it < 200; ++it) xp = matvec16<K>(xp, Ac) * sc;
-        double xq2 = xp;
-        const double lm2 = rayleigh(xq2);
-        lmax = (amb && lm2 > lmax) ? lm2 : lmax;
-        cutoff = 1e-5 * lmax;
+    for (int i = 0; i < NV; ++i) inside = inside || (has[i] && th[i] > 0.98e-5 * lo && th[i] < 1.02e-5 * hi);
+    if (__any(inside)) {
+        const double sc = rcp_refined(hi > 0.0 ? hi : 1.0);
+        double xp = l < K ? 0.2 + 0.05 * (double)((l * 7) % 5) : 0.0;
+        auto rayleigh = [&](double x) {
+            const double n2 = row_sum(x * x);
+            x *= rsq_refined(n2 > 0.0 ? n2 : 1.0);
+            const double y = matvec16<K>(x, Ac);
+            const double lm = row_sum(x * y);
+            return (lm > 0.0 && lm <= hi * 1.0000001) ? lm : hi;
+        };
+        for (int it = 0; it < 24; ++it) xp = matvec16<K>(xp, Ac) * sc;
+        const double lm1 = rayleigh(xp);
+        lmax = inside ? fmax(lm1, lo) : lmax;
+        bool amb = false;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) amb = amb || (inside && has[i] && fabs(th[i] - 1e-5 * lmax) < 0.02e-5 * lmax);
+        if (__any(amb)) {
+            for (int it = 0; it < 200; ++it) xp = matvec16<K>(xp, Ac) * sc;
+            const double lm2 = rayleigh(xp);
+            lmax = (amb && lm2 > lmax) ? lm2 : lmax;
+        }
     }
+    const double cutoff = 1e-5 * lmax;
     // the pinv cut (osc.py:55): drop the Ritz pairs at or under 1e-5 lambda_max
     int ncut = 0;
 #pragma unroll
@@ -369,6 +393,16 @@ __device__ __forceinline__ void apply_gains6_fast(const double* __restrict__ g, 
             e[3 + i] *= ko;
         }
     }
+}
+
+// LDS hand-over inside ONE wave (64-thread blocks): DS operations of a wave execute in order, so a compile-time
+// ordering point plus "all my DS operations are done" is a complete synchronisation.  __syncthreads() would also drain
+// every global load in flight (its fence covers all address spaces: s_waitcnt vmcnt(0)), i.e. the prefetched M stream.
+__device__ __forceinline__ void lds_sync() {
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xF | (0x7 << 4) | (0x0 << 8) | (0x3 << 14));      // lgkmcnt(0), vmcnt / expcnt untouched
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
 }
 
 }  // namespace r16
@@ -424,7 +458,7 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
     const TIN bias0_in = (use_g ? p.bias + (size_t)bc * N + l : zeros)[0];
     const TIN bias1_in = (use_g && v1 ? p.bias + (size_t)bc * N + 16 + l : zeros)[0];
     Wl[q][l] = 0.0;
-    __syncthreads();
+    lds_sync();
 
     // ---- task-space signal, part 1 (osc.py:101-118,70-99,160-168): quad d of the row = device d -------------------
     // Lane a of the quad evaluates ONE of the three Euler angles (the fp64 atan2 is the expensive part), the quad
@@ -511,7 +545,7 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
         Jq[K * N + 16 + l] = 0.0;
     }
     const double dq0 = (double)dq0_in, dq1 = (double)dq1_in;
-    __syncthreads();
+    lds_sync();
     __builtin_amdgcn_sched_barrier(0);
 
     IRLOSC_TS(2);
@@ -571,7 +605,7 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
     IRLOSC_TS(4);
     // ---- task-space signal, part 2: target-velocity branch B and the admittance wrench (osc.py:173-185) -----------
     Dxl[q][l] = dx;
-    __syncthreads();
+    lds_sync();
     if ((own_brB || has_wr) && ang_id == 0 && dv < NDEV) {
         const double kv = Kvl[q][dv];
         const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * NDEV * IRLOSC_GAIN_WORDS : 0) + dd * IRLOSC_GAIN_WORDS;
@@ -591,7 +625,7 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
             }
         }
     }
-    __syncthreads();
+    lds_sync();
     // w = u_task_all [+ ext_f] - kvn * dx  (null-space term folded in: osc_generic.hpp header)
     const double w = Wl[q][l] - kvn * dx;
 
@@ -652,7 +686,7 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
     if (__any(!plain)) {
         double t2 = 0.0;
         uint32_t f2 = 0;
-        eigen16<K>(Ac, F, G, invd_own, pdA, nA2, w, l, !plain, t2, f2, giveup);
+        eigen16<K>(Ac, F, G, invd_own, pdA, nA2, trA, w, l, !plain, t2, f2, giveup);
         t = plain ? t : t2;
         flags |= plain ? 0u : f2;
     }
