@@ -69,6 +69,7 @@ struct irlosc_ctx {
     int r16_parity = 0;
     // rigid-body front end (irlosc_set_model): device copy of the tables, resident joint coordinates per slot
     FeModel* dmodel = nullptr;
+    size_t fe_smem = 0;
     std::vector<double*> dqpos, dqvel;
     std::vector<int> has_q;
     // irlosc_tick: one pinned host block and one device block per direction, grown on demand
@@ -876,6 +877,7 @@ extern "C" int irlosc_set_model(irlosc_ctx* c, const irlosc_model* m) {
     }
     HIPCHK(c, hipSetDevice(c->cfg.hip_device));
     if (!c->dmodel) HIPCHK(c, hipMalloc((void**)&c->dmodel, sizeof(FeModel)));
+    c->fe_smem = frontend_smem_bytes(m->nb, m->nj);
     HIPCHK(c, hipMemcpyAsync(c->dmodel, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->dqpos.empty()) {
@@ -914,10 +916,10 @@ static int frontend_launch(irlosc_ctx* c, int slot, int B) {
     const dim3 grid(std::min(B, 1 << 20));
     if (c->cfg.dtype == IRLOSC_F64) {
         const FeOut<double> o{(double*)c->dM[slot], (double*)c->dJ[slot], (double*)c->ddq[slot], (double*)c->dbias[slot], (double*)c->dee[slot]};
-        hipLaunchKernelGGL(osc_frontend_kernel<double>, grid, dim3(64), 0, c->stream, c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B);
+        hipLaunchKernelGGL(osc_frontend_kernel<double>, grid, dim3(64), c->fe_smem, c->stream, c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B);
     } else {
         const FeOut<float> o{(float*)c->dM[slot], (float*)c->dJ[slot], (float*)c->ddq[slot], (float*)c->dbias[slot], (float*)c->dee[slot]};
-        hipLaunchKernelGGL(osc_frontend_kernel<float>, grid, dim3(64), 0, c->stream, c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B);
+        hipLaunchKernelGGL(osc_frontend_kernel<float>, grid, dim3(64), c->fe_smem, c->stream, c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B);
     }
     HIPCHK(c, hipGetLastError());
     c->uploaded[slot] = std::max(c->uploaded[slot], B);

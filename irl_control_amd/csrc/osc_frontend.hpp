@@ -65,7 +65,10 @@ __device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
               a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
 }
 __device__ __forceinline__ Q4 qnormalized(Q4 q) {
-    const double r = 1.0 / sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    const double n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+    const double s0 = __builtin_amdgcn_rsq(n2);                  // 2^-24 seed, one cubic correction -> fp64
+    const double e = fma(-(n2 * s0), s0, 1.0);
+    const double r = fma(s0 * e, fma(0.375, e, 0.5), s0);
     return Q4{q.w * r, q.x * r, q.y * r, q.z * r};
 }
 // rotation matrix of a unit quaternion, row major into m[9]
@@ -94,16 +97,23 @@ __global__ __launch_bounds__(64) void osc_frontend_kernel(const FeModel* __restr
                                                           const double* __restrict__ qvel, const FeOut<TOUT> out, const int B) {
     typedef const __attribute__((address_space(4))) FeModel* cmodel_t;
     const cmodel_t md = (cmodel_t)model_;
-    __shared__ double s_q[FE_MAXJ], s_qd[FE_MAXJ];
-    __shared__ double s_xpos[FE_MAXB][3], s_xmat[FE_MAXB][9], s_xq[FE_MAXB][4];
-    __shared__ double s_vel[FE_MAXB][6], s_acc[FE_MAXB][6];                     // spatial velocity / acceleration of a body
-    __shared__ double s_S[FE_MAXJ][6], s_p[FE_MAXJ][3];                         // (a, p x a) and the anchor p of a hinge
-    __shared__ double s_f[FE_MAXB][6];                                          // force on the body, then on its whole subtree
-    __shared__ double s_I[FE_MAXB][10];                                         // (m, m c, I about the origin) of the subtree
-    __shared__ double s_F[FE_MAXJ][6];                                          // composite inertia of the subtree times S_j
-    __shared__ double s_M[FE_MAXJ * FE_MAXJ];
+    // LDS sized by the model (frontend_smem_bytes): it bounds the waves per CU of this latency-bound kernel
+    extern __shared__ __align__(16) unsigned char fe_smem_raw[];
     const int lane = threadIdx.x;
     const int nb = md->nb, nj = md->nj;
+    double* sp = reinterpret_cast<double*>(fe_smem_raw);
+    double* s_q = sp; sp += nj;
+    double* s_qd = sp; sp += nj;
+    double (*s_xpos)[3] = reinterpret_cast<double (*)[3]>(sp); sp += nb * 3;
+    double (*s_xmat)[9] = reinterpret_cast<double (*)[9]>(sp); sp += nb * 9;
+    double (*s_xq)[4] = reinterpret_cast<double (*)[4]>(sp); sp += nb * 4;
+    double (*s_vel)[6] = reinterpret_cast<double (*)[6]>(sp); sp += nb * 6;      // spatial velocity / acceleration of a body
+    double (*s_acc)[6] = reinterpret_cast<double (*)[6]>(sp); sp += nb * 6;
+    double (*s_S)[6] = reinterpret_cast<double (*)[6]>(sp); sp += nj * 6;        // (a, p x a) and the anchor p of a hinge
+    double (*s_p)[3] = reinterpret_cast<double (*)[3]>(sp); sp += nj * 3;
+    double (*s_f)[6] = reinterpret_cast<double (*)[6]>(sp); sp += nb * 6;        // force on the body, then on its whole subtree
+    double (*s_I)[10] = reinterpret_cast<double (*)[10]>(sp); sp += nb * 10;     // (m, m c, I about the origin) of the subtree
+    double* s_M = sp;
     const int b = lane;
     const bool isb = b < nb;
     const int dep = isb ? md->depth[b] : -1;
@@ -270,6 +280,10 @@ __global__ __launch_bounds__(64) void osc_frontend_kernel(const FeModel* __restr
         for (int e = lane; e < nj * nj; e += 64) Mo[e] = (TOUT)s_M[e];
         __syncthreads();
     }
+}
+
+inline size_t frontend_smem_bytes(int nb, int nj) {
+    return sizeof(double) * ((size_t)2 * nj + (size_t)nb * (3 + 9 + 4 + 6 + 6 + 6 + 10) + (size_t)nj * (6 + 3) + (size_t)nj * nj);
 }
 
 }  // namespace irlosc
