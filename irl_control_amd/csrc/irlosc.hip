@@ -64,8 +64,8 @@ struct irlosc_ctx {
     // fp64 row16 path: zero page for the padding lanes, worklist of the instances handed to the generic kernel, and
     // two counters used alternately (the worklist pass of a step zeroes the counter of the next one)
     void* dzeros = nullptr;
-    int32_t* dr16_list = nullptr;
-    int32_t* dr16_count = nullptr;
+    int32_t* dr16_list[R16_TRAIN] = {};    // give-up list of each step of a train
+    int32_t* dr16_count = nullptr;         // [2 banks][R16_TRAIN]: trains alternate banks, a train's give-up pass zeroes the other one
     int r16_parity = 0;
     // rigid-body front end (irlosc_set_model): device copy of the tables, resident joint coordinates per slot
     FeModel* dmodel = nullptr;
@@ -169,7 +169,7 @@ static void free_all(irlosc_ctx* c) {
     if (c->tick_hout) (void)hipHostFree(c->tick_hout);
     if (c->tick_dout) (void)hipFree(c->tick_dout);
     if (c->dzeros) (void)hipFree(c->dzeros);
-    if (c->dr16_list) (void)hipFree(c->dr16_list);
+    for (int k = 0; k < R16_TRAIN; ++k) if (c->dr16_list[k]) (void)hipFree(c->dr16_list[k]);
     if (c->dr16_count) (void)hipFree(c->dr16_count);
     if (c->dgains) (void)hipFree(c->dgains);
     if (c->dnullkv) (void)hipFree(c->dnullkv);
@@ -211,6 +211,10 @@ static int create_impl(irlosc_ctx* c) {
         c->train = 8;                       // 16 gains another ~1 % at twice the output-set memory
         c->nsets = 2 * c->train;
     }
+    if (c->kernel == IRLOSC_KERNEL_ROW16) {
+        c->train = R16_TRAIN;
+        c->nsets = R16_TRAIN;               // a train completes (give-up pass included) before the next one starts
+    }
     for (int k2 = 0; k2 < c->nsets; ++k2) {
         HIPCHK(nullptr, hipMalloc(&c->du_set[k2], B * n * e));
         HIPCHK(nullptr, hipMalloc((void**)&c->dflags_set[k2], B * sizeof(uint32_t)));
@@ -229,9 +233,9 @@ static int create_impl(irlosc_ctx* c) {
         constexpr size_t ZB = 64 * 1024;
         HIPCHK(nullptr, hipMalloc(&c->dzeros, ZB));
         HIPCHK(nullptr, hipMemsetAsync(c->dzeros, 0, ZB, c->stream));
-        HIPCHK(nullptr, hipMalloc((void**)&c->dr16_list, B * sizeof(int32_t)));
-        HIPCHK(nullptr, hipMalloc((void**)&c->dr16_count, 2 * sizeof(int32_t)));
-        HIPCHK(nullptr, hipMemsetAsync(c->dr16_count, 0, 2 * sizeof(int32_t), c->stream));
+        for (int k2 = 0; k2 < R16_TRAIN; ++k2) HIPCHK(nullptr, hipMalloc((void**)&c->dr16_list[k2], B * sizeof(int32_t)));
+        HIPCHK(nullptr, hipMalloc((void**)&c->dr16_count, 2 * R16_TRAIN * sizeof(int32_t)));
+        HIPCHK(nullptr, hipMemsetAsync(c->dr16_count, 0, 2 * R16_TRAIN * sizeof(int32_t), c->stream));
     }
     c->du = c->du_set[0];
     c->dflags = c->dflags_set[0];
@@ -599,6 +603,31 @@ static int flush_pending(irlosc_ctx* c, hipStream_t st) {
     return rc;
 }
 
+// fp64-arithmetic path: one launch for a train of n steps (ps[i] complete with its own outputs), whatever the storage
+// type T of the records.  All instances run on the row16 kernel; the few it gives up on (net of eigen-candidates full,
+// degenerate A) are recomputed by the generic kernel (Jacobi, fp64 arithmetic) from the lists it leaves behind.
+template <typename T>
+static int row16_train(irlosc_ctx* c, const KParams<T>* ps, int n, hipStream_t st) {
+    if (n < 1 || n > R16_TRAIN) return fail(c, IRLOSC_ERR_STATE, "train of %d steps", n);
+    Row16Train<T> tr;
+    memset(&tr, 0, sizeof tr);
+    int32_t* bank = c->dr16_count + c->r16_parity * R16_TRAIN;
+    int32_t* other = c->dr16_count + (c->r16_parity ^ 1) * R16_TRAIN;
+    c->r16_parity ^= 1;
+    for (int i = 0; i < n; ++i) {
+        tr.p[i] = ps[i];
+        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[i], bank + i};
+    }
+    if (c->tev_begin) HIPCHK(c, hipEventRecord(c->tev_begin, st));
+    int rc = launch_row16<T>(tr, n, st);
+    if (rc) return fail(c, IRLOSC_ERR_HIP, "row16 kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    hipLaunchKernelGGL((osc_generic_worklist_kernel<double, T>), dim3(64, n), dim3(64),
+                       generic_smem_bytes<double>(ps[0].n, ps[0].k, ps[0].ndev), st, tr, other);
+    HIPCHK(c, hipGetLastError());
+    if (c->tev_end) HIPCHK(c, hipEventRecord(c->tev_end, st));
+    return IRLOSC_OK;
+}
+
 template <typename T>
 static int launch_t(irlosc_ctx* c, int B, const void* M, const void* J, const void* dq, const void* bias,
                     const void* ee, const void* tgt, const void* tvel, const void* wrench, void* u,
@@ -615,21 +644,7 @@ static int launch_t(irlosc_ctx* c, int B, const void* M, const void* J, const vo
             return fail(c, IRLOSC_ERR_ARG, "no fp64 group kernel");
         }
     }
-    if (c->kernel == IRLOSC_KERNEL_ROW16) {
-        // fp64 arithmetic whatever the storage type T of the records.  All instances on the row16 kernel; the few it
-        // gives up on (more than three eigenvalues under the pinv cut, degenerate A) are recomputed by the generic
-        // kernel (Jacobi, fp64 arithmetic) from the worklist it leaves behind.
-        int32_t* cnt = c->dr16_count + c->r16_parity;
-        int32_t* nxt = c->dr16_count + (c->r16_parity ^ 1);
-        c->r16_parity ^= 1;
-        const Row16Extra x{c->dzeros, c->dr16_list, cnt};
-        int rc = launch_row16<T>(p, x, st);
-        if (rc) return fail(c, IRLOSC_ERR_HIP, "row16 kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-        hipLaunchKernelGGL((osc_generic_worklist_kernel<double, T>), dim3(std::min(B, 256)), dim3(64),
-                           generic_smem_bytes<double>(p.n, p.k, p.ndev), st, p, c->dr16_list, cnt, nxt);
-        HIPCHK(c, hipGetLastError());
-        return IRLOSC_OK;
-    }
+    if (c->kernel == IRLOSC_KERNEL_ROW16) return row16_train<T>(c, &p, 1, st);
     size_t smem = generic_smem_bytes<T>(p.n, p.k, p.ndev);
     hipLaunchKernelGGL(osc_generic_kernel<T>, dim3(B), dim3(64), smem, st, p);
     HIPCHK(c, hipGetLastError());
@@ -757,6 +772,38 @@ static int resident_trains(irlosc_ctx* c, int first_slot, int B, int iters, cons
     return flush_pending(c, c->stream);
 }
 
+// `iters` steps on the row16 path, chained R16_TRAIN per launch (step i of a train writes output set i); events (if any)
+// go around the launches from number `skip` on.
+template <typename T>
+static int row16_resident(irlosc_ctx* c, int first_slot, int B, int iters, const std::vector<hipEvent_t>* evs, int skip) {
+    int done = 0, launch_no = 0;
+    while (done < iters) {
+        const int n = std::min((int)R16_TRAIN, iters - done);
+        KParams<T> ps[R16_TRAIN];
+        for (int i = 0; i < n; ++i) {
+            const int slot = (first_slot + done + i) % c->cfg.n_slots;
+            int rcf = check_slot_filled(c, slot, B);
+            if (rcf) return rcf;
+            fill_params<T>(c, ps[i], B, c->dM[slot], c->dJ[slot], c->ddq[slot], c->dbias[slot], c->dee[slot], c->dtgt[slot],
+                           c->has_tvel[slot] ? c->dtvel[slot] : nullptr, c->has_wrench[slot] ? c->dwrench[slot] : nullptr,
+                           c->du_set[i], c->dflags_set[i]);
+        }
+        if (evs && launch_no >= skip && 2 * (launch_no - skip) + 1 < (int)evs->size()) {
+            c->tev_begin = (*evs)[2 * (launch_no - skip)];
+            c->tev_end = (*evs)[2 * (launch_no - skip) + 1];
+        }
+        int rc = row16_train<T>(c, ps, n, c->stream);
+        c->tev_begin = c->tev_end = nullptr;
+        if (rc) return rc;
+        c->cur = n - 1;
+        done += n;
+        ++launch_no;
+    }
+    c->du = c->du_set[c->cur];
+    c->dflags = c->dflags_set[c->cur];
+    return IRLOSC_OK;
+}
+
 extern "C" int irlosc_step_resident(irlosc_ctx* c, int32_t first_slot, int32_t B, int32_t iters, float* ms_total,
                                     float* ms_kernel_avg) {
     if (!c) return IRLOSC_ERR_ARG;
@@ -771,6 +818,10 @@ extern "C" int irlosc_step_resident(irlosc_ctx* c, int32_t first_slot, int32_t B
         // output sets), and their stage 2 rides in the next launch; the last train is flushed before returning.
         rc = flush_pending(c, c->stream);
         if (!rc) rc = resident_trains(c, first_slot, B, iters, nullptr, 0);
+        if (rc) return rc;
+    } else if (c->kernel == IRLOSC_KERNEL_ROW16 && B > 0) {
+        rc = c->cfg.dtype == IRLOSC_F64 ? row16_resident<double>(c, first_slot, B, iters, nullptr, 0)
+                                        : row16_resident<float>(c, first_slot, B, iters, nullptr, 0);
         if (rc) return rc;
     } else {
         for (int i = 0; i < iters; ++i) {
@@ -789,7 +840,7 @@ extern "C" int irlosc_step_resident(irlosc_ctx* c, int32_t first_slot, int32_t B
 
 extern "C" int irlosc_steps_per_launch(const irlosc_ctx* c) {
     if (!c) return IRLOSC_ERR_ARG;
-    return c->kernel == IRLOSC_KERNEL_GROUP ? c->train : 1;
+    return c->kernel == IRLOSC_KERNEL_GENERIC ? 1 : c->train;
 }
 
 extern "C" int irlosc_time_dominant_kernel(irlosc_ctx* c, int32_t slot, int32_t B, int32_t iters, float* ms_avg) {
@@ -798,7 +849,7 @@ extern "C" int irlosc_time_dominant_kernel(irlosc_ctx* c, int32_t slot, int32_t 
     if (rc) return rc;
     if (iters < 1 || iters > 256 || !ms_avg) return fail(c, IRLOSC_ERR_ARG, "iters must be in [1,256] and ms_avg non-NULL");
     HIPCHK(c, hipSetDevice(c->cfg.hip_device));
-    if (c->kernel != IRLOSC_KERNEL_GROUP || B == 0) {          // generic path: a step IS the dominant kernel
+    if (c->kernel == IRLOSC_KERNEL_GENERIC || B == 0) {        // generic path: a step IS the dominant kernel
         float tot = 0.f;
         rc = irlosc_step_resident(c, slot, B, iters, &tot, ms_avg);
         return rc;
@@ -815,8 +866,13 @@ extern "C" int irlosc_time_dominant_kernel(irlosc_ctx* c, int32_t slot, int32_t 
         c->tev_pool.push_back(ev);
     }
     std::vector<hipEvent_t> evs(c->tev_pool.begin(), c->tev_pool.begin() + 2 * launches);
-    rc = flush_pending(c, c->stream);
-    if (!rc) rc = resident_trains(c, slot, B, (launches + 1) * c->train, &evs, 1);
+    if (c->kernel == IRLOSC_KERNEL_ROW16) {       // row16 path: a train of steps + its give-up pass per launch pair
+        rc = c->cfg.dtype == IRLOSC_F64 ? row16_resident<double>(c, slot, B, (launches + 1) * c->train, &evs, 1)
+                                        : row16_resident<float>(c, slot, B, (launches + 1) * c->train, &evs, 1);
+    } else {
+        rc = flush_pending(c, c->stream);
+        if (!rc) rc = resident_trains(c, slot, B, (launches + 1) * c->train, &evs, 1);
+    }
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     double tot = 0.0;

@@ -415,10 +415,23 @@ struct Row16Extra {
     int32_t* workcount;        // counter of this step (zero on entry)
 };
 
+// One launch = a TRAIN of up to R16_TRAIN steps (blockIdx.y = step): consecutive steps of irlosc_step_resident are
+// independent batches (different resident slots, different output sets), so chaining them in one grid removes the
+// launch gap, the ramp-up and the tail between them (a step's last waves - those with eigen-stage instances - finish
+// while the next step's first waves already run).  A train of one step is the plain single-step launch.
+constexpr int R16_TRAIN = 8;
+template <typename TIN>
+struct Row16Train {
+    KParams<TIN> p[R16_TRAIN];
+    Row16Extra x[R16_TRAIN];
+};
+
 // TIN = storage type of the records (double, or float for the mixed path); arithmetic is double throughout.
 template <int K, int NDEV, typename TIN, int N>
-__global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, const Row16Extra x) {
+__global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> tr) {
     using namespace r16;
+    const KParams<TIN>& p = tr.p[blockIdx.y];
+    const Row16Extra& x = tr.x[blockIdx.y];
     static_assert(N > 16 && N <= 32 && K >= 1 && K <= 16 && NDEV >= 1 && NDEV <= 4, "shape");
     constexpr int N1 = N - 16;                 // real rows in slot 1
     constexpr int PF = 8;                      // rows of M in flight ahead of the column being eliminated
@@ -740,7 +753,7 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
     IRLOSC_TS(7);
     if (p.dbg && lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) p.dbg[(size_t)blockIdx.x * 10 + i] = ts[i];
+        for (int i = 0; i < 8; ++i) p.dbg[(size_t)blockIdx.x * 10 + i] = ts[i];      // (the last step of a train wins)
         p.dbg[(size_t)blockIdx.x * 10 + 8] = rt0;
         p.dbg[(size_t)blockIdx.x * 10 + 9] = __builtin_amdgcn_s_memrealtime();
     }
@@ -750,12 +763,13 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const KParams<TIN> p, 
 // The generic kernel over a worklist: instance ids list[0..*count); zeroes *reset for the step after.
 // T = arithmetic type, S = storage type of the records (S = float, T = double on the mixed path).
 template <typename T, typename S>
-__global__ __launch_bounds__(64) void osc_generic_worklist_kernel(const KParams<S> p, const int32_t* __restrict__ list,
-                                                                   const int32_t* __restrict__ count, int32_t* __restrict__ reset) {
+__global__ __launch_bounds__(64) void osc_generic_worklist_kernel(const Row16Train<S> tr, int32_t* __restrict__ reset) {
     extern __shared__ __align__(16) unsigned char smem_raw_w[];
     T* smem = reinterpret_cast<T*>(smem_raw_w);
-    const int n = *count;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && reset) *reset = 0;
+    const KParams<S>& p = tr.p[blockIdx.y];
+    const int32_t* __restrict__ list = tr.x[blockIdx.y].worklist;
+    const int n = *tr.x[blockIdx.y].workcount;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && reset) reset[blockIdx.y] = 0;      // the other bank: the next train's counters
     for (int it = blockIdx.x; it < n; it += gridDim.x) generic_instance<T>(p, list[it], smem);
 }
 
@@ -764,13 +778,15 @@ inline bool row16_kernel_supports(int dtype, int n, int k, int ndev) {
     return n == 25 && ((k == 13 && ndev == 3) || (k == 12 && ndev == 2) || (k == 7 && ndev == 3));
 }
 
+// nsteps steps of equal batch size B (the steps of one train), blockIdx.y = step
 template <typename TIN>
-inline int launch_row16(const KParams<TIN>& p, const Row16Extra& x, hipStream_t st) {
-    if (p.B <= 0) return 0;
-    const dim3 grid((p.B + 3) / 4);
-    if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25>), grid, dim3(64), 0, st, p, x);
-    else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<12, 2, TIN, 25>), grid, dim3(64), 0, st, p, x);
-    else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<7, 3, TIN, 25>), grid, dim3(64), 0, st, p, x);
+inline int launch_row16(const Row16Train<TIN>& tr, int nsteps, hipStream_t st) {
+    const KParams<TIN>& p = tr.p[0];
+    if (p.B <= 0 || nsteps <= 0) return 0;
+    const dim3 grid((p.B + 3) / 4, nsteps);
+    if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25>), grid, dim3(64), 0, st, tr);
+    else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<12, 2, TIN, 25>), grid, dim3(64), 0, st, tr);
+    else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<7, 3, TIN, 25>), grid, dim3(64), 0, st, tr);
     else return (int)hipErrorNotSupported;
     return (int)hipGetLastError();
 }

@@ -263,17 +263,19 @@ def test_group_vs_generic_fp32_kernels_agree():
     assert (((fg ^ fe) & _lib.FLAG_TRUNCATED) != 0).mean() < 0.02
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("iters", [1, 2, 7, 8, 9, 17, 24])
-def test_step_resident_trains_equal_single_steps(iters):
-    """irlosc_step_resident chains several steps (8 by default) per launch and lets their eigen-path stage ride in the next
-    launch; whatever the train split, the outputs left behind are bit-for-bit those of a plain single step on the
-    last slot visited (n_slots = 3 distinct batches, truncation-heavy data so that stage 2 has work in every step)."""
+def test_step_resident_trains_equal_single_steps(iters, dtype):
+    """irlosc_step_resident chains several steps (8) per launch on both throughput paths (fp32 group: the eigen-path stage
+    rides in the next launch; fp64 row16: blockIdx.y = step, one give-up pass per train); whatever the train split, the
+    outputs left behind are bit-for-bit those of a plain single step on the last slot visited (n_slots = 3 distinct
+    batches, truncation-heavy data so that the eigen stage has work in every step)."""
     nslots, B = 3, 1024 + 16
     lay = synth.make_layout("k13")
-    osc = BatchedOSC(lay, B, dtype=np.float32, n_slots=nslots)
+    osc = BatchedOSC(lay, B, dtype=dtype, n_slots=nslots)
     batches = []
     for sl in range(nslots):
-        _, gains, g = synth.make_batch("k13", B, seed=100 + sl, dtype=np.float32)
+        _, gains, g = synth.make_batch("k13", B, seed=100 + sl, dtype=dtype)
         osc.upload(g["M"], g["J"], g["dq"], g["bias"], g["ee_pose"], g.get("wrench"), slot=sl)
         osc.set_targets(g["tgt_pose"], g.get("tgt_vel"), slot=sl)
         batches.append(g)
