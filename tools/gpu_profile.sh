@@ -5,7 +5,7 @@
 tag=${1:-rXX}; kern=${2:-osc_row16}; key=${3:-osc_row16_f64_n25_k13}
 shift; shift; shift
 export TMPDIR=/tmp
-B="python bench.py --steps 60 --warmup 10 --preroll 100 --no-cpu-baseline --no-secondary --no-from-q $*"
+B="python bench.py --steps 64 --warmup 8 --preroll 96 --no-cpu-baseline --no-secondary --no-from-q $*"
 rm -rf gpurun_out/prof_$tag gpurun_out/pmc_fetch_$tag gpurun_out/pmc_write_$tag
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o prof -- $B > gpurun_out/bench_prof_$tag.log 2>&1
 grep -a "^{\"metric\"" gpurun_out/bench_prof_$tag.log | tail -1 > gpurun_out/bench_under_rocprof_$tag.json

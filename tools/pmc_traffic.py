@@ -13,6 +13,8 @@ def avg(db, counter, sub):
     rows = con.execute("select value from counters_collection where counter_name=? and kernel_name like ?",
                        (counter, f"%{sub}%")).fetchall()
     vals = [r[0] for r in rows]
+    top = max(vals)                                   # the same kernel also runs shorter launches (a train of fewer steps,
+    vals = [v for v in vals if v >= 0.9 * top]        # the single step of a download): keep the full-size launches only
     return sum(vals) / len(vals), len(vals)
 
 

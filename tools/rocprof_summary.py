@@ -24,7 +24,7 @@ def main(path):
     if "grid_x" in ix:      # the fused train kernel is launched in several shapes (full train, first train, flush):
         by = {}             # break the dominant kernel down by grid size so like is compared with like
         for r in rows:
-            key = (r[ix[name_c]], r[ix["grid_x"]])
+            key = (r[ix[name_c]], (r[ix["grid_x"]], r[ix["grid_y"]]) if "grid_y" in ix else r[ix["grid_x"]])
             a = by.setdefault(key, [0, 0.0])
             a[0] += 1; a[1] += (r[ix["end"]] - r[ix["start"]]) / 1e3
     print(f"{'kernel':70s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}  extra")
@@ -38,10 +38,10 @@ def main(path):
               f"{a['mx']:10.2f} {100 * a['tot'] / tot_all:6.2f}  {extra}")
     if "grid_x" in ix:
         dom = max(agg.items(), key=lambda kv: kv[1]["tot"])[0]
-        print(f"# dominant kernel by launch shape (grid_x = 64 x blocks): full trains / first train of a call / flushes")
+        print(f"# dominant kernel by launch shape (grid_x = 64 x blocks, grid_y = steps of the train where it has one)")
         for (nm, gx), (n, tot) in sorted(by.items(), key=lambda kv: -kv[1][1]):
             if nm == dom:
-                print(f"#   grid_x={gx:9d} calls={n:5d} avg_us={tot / n:10.2f}")
+                print(f"#   grid={str(gx):>16s} calls={n:5d} avg_us={tot / n:10.2f}")
 
 
 if __name__ == "__main__":
