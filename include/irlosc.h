@@ -233,6 +233,10 @@ int irlosc_upload_q(irlosc_ctx* ctx, int32_t slot, int32_t B, const double* qpos
 /* Run the front end on the slot's (qpos, qvel): fills its M, J, dq, bias, ee_pose records (asynchronous, context's
  * stream); irlosc_set_targets + irlosc_step then work as after irlosc_upload. */
 int irlosc_frontend(irlosc_ctx* ctx, int32_t slot, int32_t B);
+/* Copy records of slot `slot` back to the host (any pointer may be NULL): what irlosc_upload put there, or what the front
+ * end / irlosc_upload_raw assembled on the GPU.  Same layouts and element type as irlosc_upload. */
+int irlosc_download_records(irlosc_ctx* ctx, int32_t slot, int32_t B, void* M, void* J, void* dq, void* bias,
+                            void* ee_pose);
 /* Benchmark form of the whole path from joint coordinates: `iters` x (front end + step) on resident (qpos, qvel),
  * slot = (first_slot + i) % n_slots; HIP-event time of the region on the library's stream. */
 int irlosc_step_resident_from_q(irlosc_ctx* ctx, int32_t first_slot, int32_t B, int32_t iters, float* ms_total,

@@ -22,7 +22,7 @@ EXPORTS = ["irlosc_abi_version", "irlosc_device_count", "irlosc_create", "irlosc
            "irlosc_steps_per_launch", "irlosc_upload_raw", "irlosc_assemble_device", "irlosc_device_sync",
            "irlosc_tick", "irlosc_comm_unique_id", "irlosc_comm_create", "irlosc_comm_destroy",
            "irlosc_comm_last_error", "irlosc_bench_allreduce", "irlosc_comm_allgather_u64", "irlosc_set_model",
-           "irlosc_upload_q", "irlosc_frontend", "irlosc_step_resident_from_q"]
+           "irlosc_upload_q", "irlosc_frontend", "irlosc_step_resident_from_q", "irlosc_download_records"]
 COMM_ID_BYTES = 128
 
 
@@ -94,6 +94,7 @@ def load():
     lib.irlosc_set_model.argtypes = [vp, C.POINTER(Model)]
     lib.irlosc_upload_q.argtypes = [vp, i32, i32, vp, vp]
     lib.irlosc_frontend.argtypes = [vp, i32, i32]
+    lib.irlosc_download_records.argtypes = [vp, i32, i32] + [vp] * 5
     lib.irlosc_step_resident_from_q.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.irlosc_tick.argtypes = [vp, i32] + [vp] * 10
     lib.irlosc_comm_unique_id.argtypes = [vp]

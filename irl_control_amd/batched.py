@@ -178,6 +178,14 @@ class BatchedOSC:
         """(qpos, qvel) of the slot -> its M, J, dq, bias, ee_pose records (on the GPU)."""
         self._chk(self.lib.irlosc_frontend(self._h, slot, self._B[slot]))
 
+    def download_records(self, slot: int = 0):
+        """-> dict(M, J, dq, bias, ee_pose) of the slot as it sits in HBM (uploaded, or assembled by the front end)."""
+        L, B = self.layout, self._B[slot]
+        out = dict(M=np.empty((B, L.n, L.n), self.dtype), J=np.empty((B, L.k, L.n), self.dtype), dq=np.empty((B, L.n), self.dtype),
+                   bias=np.empty((B, L.n), self.dtype), ee_pose=np.empty((B, L.ndev, 7), self.dtype))
+        self._chk(self.lib.irlosc_download_records(self._h, slot, B, *[_lib.ptr(out[k]) for k in ("M", "J", "dq", "bias", "ee_pose")]))
+        return out
+
     def step_from_q(self, qpos, qvel, tgt_pose, tgt_vel=None, return_flags: bool = False):
         """One tick from joint coordinates: upload (qpos, qvel), front end, step, download."""
         self.upload_q(qpos, qvel)

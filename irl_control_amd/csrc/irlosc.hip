@@ -990,6 +990,24 @@ extern "C" int irlosc_frontend(irlosc_ctx* c, int32_t slot, int32_t B) {
     return frontend_launch(c, slot, B);
 }
 
+extern "C" int irlosc_download_records(irlosc_ctx* c, int32_t slot, int32_t B, void* M, void* J, void* dq, void* bias,
+                                       void* ee_pose) {
+    if (!c) return IRLOSC_ERR_ARG;
+    int rc = check_slot(c, slot, B);
+    if (rc) return rc;
+    if (B > std::max(0, c->uploaded[slot])) return fail(c, IRLOSC_ERR_STATE, "slot %d holds state for %d instances", slot, std::max(0, c->uploaded[slot]));
+    if (B == 0) return IRLOSC_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    const size_t b = (size_t)B, n = (size_t)c->cfg.n, k = (size_t)c->k, nd = (size_t)c->cfg.ndev, e = c->esz;
+    if (M) HIPCHK(c, hipMemcpyAsync(M, c->dM[slot], b * n * n * e, hipMemcpyDeviceToHost, c->stream));
+    if (J) HIPCHK(c, hipMemcpyAsync(J, c->dJ[slot], b * k * n * e, hipMemcpyDeviceToHost, c->stream));
+    if (dq) HIPCHK(c, hipMemcpyAsync(dq, c->ddq[slot], b * n * e, hipMemcpyDeviceToHost, c->stream));
+    if (bias) HIPCHK(c, hipMemcpyAsync(bias, c->dbias[slot], b * n * e, hipMemcpyDeviceToHost, c->stream));
+    if (ee_pose) HIPCHK(c, hipMemcpyAsync(ee_pose, c->dee[slot], b * nd * 7 * e, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return IRLOSC_OK;
+}
+
 extern "C" int irlosc_step_resident_from_q(irlosc_ctx* c, int32_t first_slot, int32_t B, int32_t iters, float* ms_total,
                                            float* ms_step_avg) {
     if (!c) return IRLOSC_ERR_ARG;

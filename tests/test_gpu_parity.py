@@ -825,3 +825,17 @@ def test_tick_latency_b1_is_bounded():
         t0 = time.perf_counter(); osc.tick(*a); t.append(time.perf_counter() - t0)
     osc.close()
     assert np.median(t) < 250e-6, float(np.median(t))
+
+
+def test_closed_loop_converges_on_targets():
+    """examples/closed_loop_headless.py: 12 robots, the front end as the physics (M, bias read back from HBM, host-side
+    integration of M qacc = u - bias), the HIP controller in the loop for 2 000 ticks.  The end effectors must converge
+    onto their Cartesian targets: this closes the sign conventions of controller and front end against each other
+    (bias compensation, J^T Mx direction, null-space damping), which no open-loop parity test does."""
+    mod = _load_example("closed_loop_headless")
+    r = mod.run(robots=12, ticks=2000, seed=0, verbose=False)
+    assert np.all(np.isfinite(r["q"])) and np.all(np.isfinite(r["err"]))
+    worst = r["err"].max(axis=1)                      # per robot: the worse of its two arms
+    assert r["err0"].max(axis=1).min() > 0.02         # every robot started away from its targets
+    assert (worst < 5e-3).mean() >= 0.75, np.sort(worst)
+    assert np.median(worst) < 1e-3
