@@ -160,3 +160,136 @@ class ActionSequenceRunner:
         for entry in action_sequence:
             entry = copy.deepcopy(entry)
             {"WP": self.go_to_waypoint, "GRIP": self.grip}[entry["action"]](entry)
+
+
+# ---- the same state machine for a fleet: B robots, B independent object placements, one GPU step per tick --------------
+def _calc_error_batch(ee_pose, tgt_pose):
+    """OSC.calc_error (osc.py:101-118) for B poses: [xyz error, sxyz Euler angles of q_ee * conj(normalised q_tgt)]."""
+    from .transforms import normalized_vector, qconjugate, qmult, quat2euler
+    e = np.zeros((len(ee_pose), 6))
+    e[:, :3] = ee_pose[:, :3] - tgt_pose[:, :3]
+    for b in range(len(ee_pose)):
+        q_r = np.array(qmult(normalized_vector(tgt_pose[b, 3:]), qconjugate(ee_pose[b, 3:])))
+        e[b, 3:] = quat2euler(qconjugate(q_r))
+    return e
+
+
+class FleetActionSequenceRunner:
+    """B robots run the SAME WP / GRIP action list, each on its own action objects (randomised poses), in lockstep on the
+    batched controller: per tick one `BatchedOSC` step from joint coordinates (rigid-body front end on the GPU) with
+    PER-INSTANCE gains, because the error-adaptive velocity limit of insertion_task.py:293-295 differs per robot.
+    An instance that has finished its list holds its last targets.  The physics is whatever `integrate(q, qd, u, rec)`
+    does (examples/insertion_fleet_headless.py: M qacc = u - bias with M, bias read back from HBM).
+
+    Semantics per instance are those of ActionSequenceRunner (and the kernels make an instance's result independent of
+    its batch-mates), so robot b of a fleet follows, bit for bit, the trajectory it follows alone
+    (tests/test_gpu_parity.py::test_fleet_action_sequence_lockstep_equals_solo_runs)."""
+
+    def __init__(self, osc, base_gains: Dict, objects: List[Dict], sequence: List[Dict], active_arm: str = "right",
+                 tick_seconds: float = 0.001, passive_hold_orientation: bool = False):
+        self.osc, self.lay = osc, osc.layout
+        # the reference sends the passive arm to DEFAULT_EE_QUAT at every waypoint (insertion_task.py:213), which suits the
+        # start pose of its scene; with arbitrary start poses holding the current orientation keeps that arm where it is
+        self.passive_hold_orientation = passive_hold_orientation
+        self.B = len(objects)
+        self.objects = objects                      # per instance: {name: {"pos": xyz, "quat": wxyz, **offsets, "grip_yaw"}}
+        self.seq = [copy.deepcopy(e) for e in sequence]
+        for e in self.seq:
+            ActionSequenceRunner._with_defaults(e, Action.WP if e["action"] == "WP" else Action.GRIP)
+        self.arm = "ur5right" if active_arm == "right" else "ur5left"
+        self.other = "ur5left" if active_arm == "right" else "ur5right"
+        self.ia, self.io = self.lay.dev_names.index(self.arm), self.lay.dev_names.index(self.other)
+        self.base_gains = base_gains
+        self.tick_seconds = tick_seconds
+        self.action = np.zeros(self.B, dtype=int)                 # index of the action each instance is in
+        self.grip_left = np.zeros(self.B, dtype=int)              # ticks left in a GRIP action
+        self.err = np.full(self.B, np.inf)
+        self.max_vel0 = np.zeros(self.B)
+        self.gripper_force = np.zeros(self.B)
+        self.tgt = None
+        self.start_pos = None
+        self.entered = np.full(self.B, -1)                        # action whose targets are currently set
+        self.ticks = 0
+
+    def _waypoint_target(self, b, params, ee_pose_b):
+        obj = self.objects[b]
+        offset = params.get("offset", [0.0, 0.0, 0.0])
+        txyz = params["target_xyz"]
+        if isinstance(txyz, str):
+            if txyz == "start_pos":
+                xyz = self.start_pos[b]
+            else:
+                o = obj[txyz]
+                xyz = np.asarray(o["pos"]) + np.asarray(o[offset] if isinstance(offset, str) else offset)
+        else:
+            xyz = np.asarray(txyz, dtype=np.float64) + np.asarray(offset, dtype=np.float64)
+        if "target_abg" in params:
+            tabg = params["target_abg"]
+            if isinstance(tabg, str):
+                o = obj[tabg]
+                grip_eul = DEFAULT_EE_ROT + [0, 0, np.deg2rad(o["grip_yaw"])]
+                R = quat2mat(o["quat"]) @ euler2mat(*grip_eul)
+                quat = euler2quat(*mat2euler(R))
+            else:
+                quat = euler2quat(*np.deg2rad(tabg))
+        else:
+            quat = DEFAULT_EE_QUAT
+        return np.concatenate([xyz, quat])
+
+    def done(self):
+        return self.action >= len(self.seq)
+
+    def tick(self, q, qd):
+        """One control tick for the fleet: returns (u[B,n], records) for the integrator."""
+        osc = self.osc
+        osc.upload_q(q, qd)
+        osc.frontend()
+        rec = osc.download_records()
+        ee = rec["ee_pose"].astype(np.float64)
+        if self.tgt is None:
+            self.tgt = ee.copy()
+            self.start_pos = ee[:, self.ia, :3].copy()
+        for b in range(self.B):
+            a = self.action[b]
+            if a >= len(self.seq) or self.entered[b] == a:
+                continue
+            p = self.seq[a]
+            self.entered[b] = a
+            self.gripper_force[b] = p["gripper_force"]
+            if p["action"] == "WP":
+                self.tgt[b, self.io, :3] = ee[b, self.io, :3]            # passive arm holds position (insertion_task.py:212-213)
+                self.tgt[b, self.io, 3:] = ee[b, self.io, 3:] if self.passive_hold_orientation else DEFAULT_EE_QUAT
+                self.tgt[b, self.ia] = self._waypoint_target(b, p, ee[b])
+                self.err[b] = np.inf
+            else:
+                self.grip_left[b] = max(1, int(round(p["gripper_duration"] / self.tick_seconds)))
+        # error-adaptive velocity limit of the active arm, per instance
+        mv = np.broadcast_to(np.asarray(self.base_gains["max_vel"], dtype=np.float64), (self.B, self.lay.ndev, 2)).copy()
+        for b in range(self.B):
+            a = self.action[b]
+            if a < len(self.seq) and self.seq[a]["action"] == "WP":
+                p = self.seq[a]
+                self.max_vel0[b] = max(p["min_speed_xyz"], min(p["max_speed_xyz"], p["kp"] * self.err[b]))
+            mv[b, self.ia, 0] = self.max_vel0[b] if self.max_vel0[b] > 0 else mv[b, self.ia, 0]
+        g = self.base_gains
+        osc.set_gains(g["kp"], g["kv"], g["ko"], g["k"], g["d"], mv, np.full(self.B, g["null_kv"]) if np.ndim(g["null_kv"]) == 0 else g["null_kv"])
+        osc.set_targets(self.tgt)
+        u = osc.step()
+        self.ticks += 1
+        return u, rec
+
+    def after_step(self, ee_pose):
+        """Bookkeeping after the simulator step (errors are measured on the new state, as in send_forces)."""
+        e = np.linalg.norm(_calc_error_batch(ee_pose[:, self.ia], self.tgt[:, self.ia]), axis=1)
+        for b in range(self.B):
+            a = self.action[b]
+            if a >= len(self.seq):
+                continue
+            self.err[b] = e[b]
+            if self.seq[a]["action"] == "WP":
+                if self.err[b] <= self.seq[a]["max_error"]:
+                    self.action[b] += 1
+            else:
+                self.grip_left[b] -= 1
+                if self.grip_left[b] <= 0:
+                    self.action[b] += 1

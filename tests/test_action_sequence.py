@@ -67,3 +67,56 @@ def test_waypoint_adapts_max_vel_and_grip_counts_ticks():
     assert min(seen[:n_wp]) == 0.1                             # near the goal: kp * error under min_speed_xyz
     assert all(0.1 <= v <= 0.7 for v in seen)
     assert sim.data.ctrl[GRIPPER_CTRL_IDX["ur5left"]] == 0.2 and ctrl.calls == len(seen) == r.ticks
+
+
+class _StubBatched:
+    """What FleetActionSequenceRunner needs of BatchedOSC, on the CPU: records whose ee_pose is a state the test moves."""
+
+    def __init__(self, lay, B):
+        self.layout, self.B = lay, B
+        self.ee = np.zeros((B, lay.ndev, 7))
+        self.ee[:, :, 3] = 1.0
+        self.gains, self.targets = None, None
+
+    def upload_q(self, q, qd): pass
+    def frontend(self): pass
+    def download_records(self): return dict(ee_pose=self.ee.copy())
+    def set_gains(self, *a): self.gains = a
+    def set_targets(self, t): self.targets = np.array(t)
+    def step(self): return np.zeros((self.B, self.layout.n))
+
+
+def test_fleet_runner_state_machine_per_instance():
+    """Each instance advances on ITS error: adaptive velocity limits differ per robot, a finished robot holds its target,
+    GRIP counts ticks (insertion_task.py:264-318 per instance)."""
+    from irl_control_amd import synth
+    from irl_control_amd.action_sequence import FleetActionSequenceRunner, _calc_error_batch
+    lay = synth.make_layout("k13")
+    _, gains, _ = synth.make_batch("k13", 1, seed=0)
+    B = 3
+    objs = [{"obj": dict(pos=[0.1 * (b + 1), 0.0, 0.0], quat=[1, 0, 0, 0], grip_yaw=0.0, up=[0, 0, 0.05])} for b in range(B)]
+    seq = [dict(action="WP", target_xyz="obj", offset="up", max_error=0.01, kp=2.0, min_speed_xyz=0.05, max_speed_xyz=1.0),
+           dict(action="GRIP", gripper_force=0.3, gripper_duration=0.003)]
+    osc = _StubBatched(lay, B)
+    r = FleetActionSequenceRunner(osc, gains, objs, seq, active_arm="right", passive_hold_orientation=True)
+    ia = lay.dev_names.index("ur5right")
+    q = np.zeros((B, lay.n))
+    r.tick(q, q)
+    assert np.allclose(osc.targets[:, ia, :3], [[0.1, 0, 0.05], [0.2, 0, 0.05], [0.3, 0, 0.05]])
+    # orientation error only: all three are still off by the DEFAULT_EE rotation, so nobody advances
+    r.after_step(osc.ee)
+    assert (r.action == 0).all() and np.isfinite(r.err).all()
+    osc.ee[0, ia] = osc.targets[0, ia]                 # robot 0 arrives
+    r.tick(q, q)
+    mv = osc.gains[5]
+    assert mv.shape == (B, lay.ndev, 2)
+    want = [max(0.05, min(1.0, 2.0 * e)) for e in r.err]
+    assert np.allclose(mv[:, ia, 0], want)
+    r.after_step(osc.ee)
+    assert list(r.action) == [1, 0, 0]
+    for _ in range(3):
+        r.tick(q, q); r.after_step(osc.ee)
+    assert list(r.action) == [2, 0, 0] and list(r.done()) == [True, False, False]
+    assert r.gripper_force[0] == 0.3
+    e = _calc_error_batch(osc.ee[:, ia], osc.targets[:, ia])
+    assert np.allclose(e[0], 0) and abs(e[1, 0] + 0.2) < 1e-12

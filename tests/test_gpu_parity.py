@@ -839,3 +839,25 @@ def test_closed_loop_converges_on_targets():
     assert r["err0"].max(axis=1).min() > 0.02         # every robot started away from its targets
     assert (worst < 5e-3).mean() >= 0.75, np.sort(worst)
     assert np.median(worst) < 1e-3
+
+
+@pytest.mark.gpu
+def test_fleet_action_sequence_lockstep_equals_solo_runs():
+    """f4 batched over randomised object poses (examples/insertion_fleet_headless.py): every robot of a fleet walks the
+    WP / GRIP list to its end, and a robot's torque trajectory inside the fleet is the one it produces alone, bit for
+    bit (instances share nothing but the launch)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("insertion_fleet_headless",
+                                                  os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                               "examples", "insertion_fleet_headless.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fleet = mod.run(robots=6, max_ticks=14000, verbose=False, sequence=mod.SHORT_SEQUENCE)
+    assert fleet["done"].all(), (fleet["action"], fleet["ticks"])
+    assert np.isfinite(fleet["u"]).all()
+    for b in (0, 4):
+        solo = mod.run(robots=6, max_ticks=600, verbose=False, sequence=mod.SHORT_SEQUENCE, only=[b])
+        n = solo["u"].shape[0]
+        assert n == 600
+        assert np.array_equal(solo["u"][:, 0], fleet["u"][:n, b])
