@@ -20,6 +20,8 @@
 #include "osc_assemble.hpp"
 #include "osc_row16.hpp"
 #include "osc_frontend.hpp"
+#include "osc_frontend_lane.hpp"
+#include "topo_dual_ur5.hpp"
 
 using namespace irlosc;
 
@@ -70,6 +72,8 @@ struct irlosc_ctx {
     // rigid-body front end (irlosc_set_model): device copy of the tables, resident joint coordinates per slot
     FeModel* dmodel = nullptr;
     size_t fe_smem = 0;
+    int fe_lane = 0;                  // 1: the model has the compiled Dual-UR5 shape -> lane-per-instance front end
+    double* fe_side = nullptr;        // side buffer of the lane kernel: [wave][entry][64]
     std::vector<double*> dqpos, dqvel;
     std::vector<int> has_q;
     // irlosc_tick: one pinned host block and one device block per direction, grown on demand
@@ -162,6 +166,7 @@ static void free_all(irlosc_ctx* c) {
         if (c->dtable[k]) (void)hipFree(c->dtable[k]);
     if (c->draw) (void)hipFree(c->draw);
     if (c->dmodel) (void)hipFree(c->dmodel);
+    if (c->fe_side) (void)hipFree(c->fe_side);
     for (double* p : c->dqpos) if (p) (void)hipFree(p);
     for (double* p : c->dqvel) if (p) (void)hipFree(p);
     if (c->tick_hin) (void)hipHostFree(c->tick_hin);
@@ -924,6 +929,28 @@ extern "C" int irlosc_set_model(irlosc_ctx* c, const irlosc_model* m) {
         for (int b = 0; b < m->nb; ++b) if ((h.anc_mask[b] >> j) & 1u) h.sub_mask[j] |= 1ull << b;
     }
     for (int i = 0; i < 3; ++i) h.gravity[i] = m->gravity[i];
+    {   // derived tables of the lane-per-instance kernel
+        auto q2m_host = [](const double* q, double* R) {
+            const double w = q[0], x = q[1], y = q[2], z = q[3];
+            R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+            R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+            R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
+        };
+        for (int b = 0; b < m->nb; ++b) {
+            double R[9];
+            const int jb = h.joint_of_body[b];
+            if (jb >= 0) {
+                q2m_host(h.quat[b], R);
+                for (int r = 0; r < 3; ++r) h.jpos_par[jb][r] = R[r * 3] * h.jpos[jb][0] + R[r * 3 + 1] * h.jpos[jb][1] + R[r * 3 + 2] * h.jpos[jb][2];
+            }
+            for (int j = 0; j < m->nj; ++j) if ((h.anc_mask[b] >> j) & 1u) h.cmass[j] += h.mass[b];
+            q2m_host(h.iquat[b], R);
+            int e = 0;
+            for (int r = 0; r < 3; ++r)
+                for (int cc = r; cc < 3; ++cc)
+                    h.icb[b][e++] = R[r * 3] * h.inertia[b][0] * R[cc * 3] + R[r * 3 + 1] * h.inertia[b][1] * R[cc * 3 + 1] + R[r * 3 + 2] * h.inertia[b][2] * R[cc * 3 + 2];
+        }
+    }
     int row = 0;
     for (int d = 0; d < c->cfg.ndev; ++d) {
         if (m->ee_body[d] < 0 || m->ee_body[d] >= m->nb) return fail(c, IRLOSC_ERR_ARG, "ee_body[%d]=%d out of range", d, m->ee_body[d]);
@@ -934,6 +961,14 @@ extern "C" int irlosc_set_model(irlosc_ctx* c, const irlosc_model* m) {
     HIPCHK(c, hipSetDevice(c->cfg.hip_device));
     if (!c->dmodel) HIPCHK(c, hipMalloc((void**)&c->dmodel, sizeof(FeModel)));
     c->fe_smem = frontend_smem_bytes(m->nb, m->nj);
+    {
+        const char* e = getenv("IRLOSC_FRONTEND");           // "generic": force the wave-per-instance kernel (A/B measurements)
+        c->fe_lane = frontend_lane_matches<TopoDualUr5>(h) && !(e && !strcmp(e, "generic"));
+    }
+    if (c->fe_lane && !c->fe_side) {
+        const size_t waves = ((size_t)c->cfg.max_batch + 63) / 64;
+        HIPCHK(c, hipMalloc((void**)&c->fe_side, waves * FeTopo<TopoDualUr5>::n_side() * 64 * sizeof(double)));
+    }
     HIPCHK(c, hipMemcpyAsync(c->dmodel, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->dqpos.empty()) {
@@ -969,13 +1004,15 @@ static int frontend_launch(irlosc_ctx* c, int slot, int B) {
     if (!c->has_q[slot]) return fail(c, IRLOSC_ERR_STATE, "slot %d: irlosc_upload_q must precede irlosc_frontend", slot);
     if (B == 0) { c->uploaded[slot] = -1; return IRLOSC_OK; }
     if (B > c->has_q[slot]) return fail(c, IRLOSC_ERR_STATE, "slot %d holds joint coordinates of %d instances, front end asked for %d", slot, std::max(0, c->has_q[slot]), B);
-    const dim3 grid(std::min(B, 1 << 20));
+    const dim3 grid(std::min(B, 1 << 20)), lgrid((B + 63) / 64);
     if (c->cfg.dtype == IRLOSC_F64) {
         const FeOut<double> o{(double*)c->dM[slot], (double*)c->dJ[slot], (double*)c->ddq[slot], (double*)c->dbias[slot], (double*)c->dee[slot]};
-        hipLaunchKernelGGL(osc_frontend_kernel<double>, grid, dim3(64), c->fe_smem, c->stream, c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B);
+        if (c->fe_lane) hipLaunchKernelGGL((osc_frontend_lane_kernel<TopoDualUr5, double>), lgrid, dim3(64), 0, c->stream, c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B, c->fe_side);
+        else hipLaunchKernelGGL(osc_frontend_kernel<double>, grid, dim3(64), c->fe_smem, c->stream, c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B);
     } else {
         const FeOut<float> o{(float*)c->dM[slot], (float*)c->dJ[slot], (float*)c->ddq[slot], (float*)c->dbias[slot], (float*)c->dee[slot]};
-        hipLaunchKernelGGL(osc_frontend_kernel<float>, grid, dim3(64), c->fe_smem, c->stream, c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B);
+        if (c->fe_lane) hipLaunchKernelGGL((osc_frontend_lane_kernel<TopoDualUr5, float>), lgrid, dim3(64), 0, c->stream, c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B, c->fe_side);
+        else hipLaunchKernelGGL(osc_frontend_kernel<float>, grid, dim3(64), c->fe_smem, c->stream, c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B);
     }
     HIPCHK(c, hipGetLastError());
     c->uploaded[slot] = std::max(c->uploaded[slot], B);

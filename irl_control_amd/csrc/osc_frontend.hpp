@@ -47,6 +47,10 @@ struct FeModel {
     int32_t row0[IRLOSC_MAX_DEV];
     int32_t k;
     int32_t pad;
+    // derived at set_model for the lane-per-instance kernel (osc_frontend_lane.hpp)
+    double jpos_par[FE_MAXJ][3];         // hinge anchor in the PARENT body's frame offset: R(quat_b) jpos
+    double icb[FE_MAXB][6];              // body-frame inertia about the centre of mass: Ri diag(inertia) Ri^T (xx xy xz yy yz zz)
+    double cmass[FE_MAXJ];               // mass of everything hinge j moves
 };
 
 struct V3 { double x, y, z; };

@@ -94,6 +94,8 @@ def main():
     acts = [a.get("joint") for a in root.find("actuator")]
     out = dict(source="ir-lab/irl_control @ 2024_10_08, irl_control/scenes/dual_ur5.xml:51-297, via tools/parse_mjcf.py",
                gravity=[0.0, 0.0, -9.81], bodies=bodies, sites=sites, joint_names=joint_names, actuator_joints=acts,
+               # device name -> end-effector body (the `EE:` entries of irl_control/robot_configs/default_xyz*.yaml)
+               ee_bodies={"base": "ur_stand_dummy", "ur5right": "ur_EE_ur5right", "ur5left": "ur_EE_ur5left"},
                notes="parent -1 = world; body frames relative to the parent; euler -> quat with MuJoCo's intrinsic xyz; "
                      "bodies with geom_inertia_missing get their inertia from mesh geoms in MuJoCo (not reproduced)")
     with open(OUT, "w") as f:
