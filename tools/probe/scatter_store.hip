@@ -48,6 +48,15 @@ __global__ __launch_bounds__(64) void k(double* out, double seed) {
 #pragma unroll 8
                 for (int it = 0; it < 64; ++it) p[(size_t)it * REC7 + ch * 64] = v + it;
         }
+    } else if constexpr (MODE == 10) {
+        // line-aligned emission of 8-byte-aligned records: robot li's windows start at 48 c - (li mod 16) doubles, 48 lanes each
+        double* p = out + (size_t)blockIdx.x * 64 * 625;
+        for (int ch = 0; ch < 14; ++ch)
+#pragma unroll 8
+            for (int it = 0; it < 64; ++it) {
+                const int f = 48 * ch - (it & 15) + lane;
+                if (lane < 48 && f >= 0 && f < 625) p[(size_t)it * 625 + f] = v + it;
+            }
     } else if constexpr (MODE == 5) {                 // rows of 25, the first 13 of each written as a run, the rest never (gaps)
         double* p = out + inst * REC;
 #pragma unroll 2
@@ -107,6 +116,7 @@ int main() {
     run<7>(d, "512 B per robot per instr, robots 5000 B apart, chunk-major");
     run<8>(d, "512 B per robot per instr, robots 5120 B apart, chunk-major");
     run<9>(d, "512 B per robot per instr, robots 5000 B apart, robot-major");
+    run<10>(d, "384 B line-aligned windows per robot per instr (625 dbl/robot; rate per 448)");
     run<5>(d, "per-lane, 34 rows: 13 of 25 written, 12 skipped (N=442)");
     run<6>(d, "per-lane, 34 rows written whole (850 stores; rate per 448)");
     return 0;
