@@ -216,7 +216,7 @@ def measure_from_q(BatchedOSC, synth, args, B, local_rank):
         _, ms_osc = osc.step_resident(steps)
         esz = np.dtype(dt).itemsize
         res = dict(value=B * steps / el, unit="steps/s", ms_per_step=el / steps * 1e3, ms_per_step_events=ms_step,
-                   ms_osc_step_alone=ms_osc, ms_front_end=ms_step - ms_osc, kernel="osc_frontend + " + osc.kernel_name,
+                   ms_osc_step_alone=ms_osc, ms_front_end=ms_step - ms_osc, kernel=osc.frontend_name + " + " + osc.kernel_name,
                    input_bytes_per_step_per_instance=2 * lay.n * 8 + 7 * lay.ndev * esz,
                    note="per step: rigid-body front end (FK, EE Jacobians, CRBA, RNEA) from resident (qpos, qvel), then the OSC "
                         "step on the records it wrote; nothing crosses PCIe")

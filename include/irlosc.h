@@ -116,6 +116,7 @@ int irlosc_create(const irlosc_cfg* cfg, irlosc_ctx** out);
 void irlosc_destroy(irlosc_ctx* ctx);
 const char* irlosc_last_error(const irlosc_ctx* ctx); /* ctx may be NULL: last create() error */
 const char* irlosc_kernel_name(const irlosc_ctx* ctx); /* name of the kernel irlosc_step launches */
+const char* irlosc_frontend_name(const irlosc_ctx* ctx); /* name of the kernel irlosc_frontend launches ("" before irlosc_set_model) */
 
 /* gains[nb][ndev][IRLOSC_GAIN_WORDS] and null_kv[nb] as double; nb == 1 broadcasts one gain set to
  * every instance (kept in constant/SGPR space), nb == max_batch gives per-instance gains. */

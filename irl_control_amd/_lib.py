@@ -16,7 +16,7 @@ FLAG_M_NOT_PD, FLAG_PINV_BRANCH, FLAG_EIGEN_PATH, FLAG_TRUNCATED = 1, 2, 4, 8
 FLAG_VEL_BRANCH_B, FLAG_BAD_JIDX, FLAG_NONFINITE = 16, 32, 64
 
 EXPORTS = ["irlosc_abi_version", "irlosc_device_count", "irlosc_create", "irlosc_destroy",
-           "irlosc_last_error", "irlosc_kernel_name", "irlosc_set_gains", "irlosc_upload",
+           "irlosc_last_error", "irlosc_kernel_name", "irlosc_frontend_name", "irlosc_set_gains", "irlosc_upload",
            "irlosc_set_targets", "irlosc_step", "irlosc_step_resident", "irlosc_download",
            "irlosc_sync", "irlosc_step_device", "irlosc_time_dominant_kernel",
            "irlosc_steps_per_launch", "irlosc_upload_raw", "irlosc_assemble_device", "irlosc_device_sync",
@@ -78,6 +78,8 @@ def load():
     lib.irlosc_last_error.restype = C.c_char_p
     lib.irlosc_kernel_name.argtypes = [vp]
     lib.irlosc_kernel_name.restype = C.c_char_p
+    lib.irlosc_frontend_name.argtypes = [vp]
+    lib.irlosc_frontend_name.restype = C.c_char_p
     lib.irlosc_set_gains.argtypes = [vp, vp, vp, i32]
     lib.irlosc_upload.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.irlosc_set_targets.argtypes = [vp, i32, i32, vp, vp]

@@ -59,6 +59,11 @@ class BatchedOSC:
     def kernel_name(self) -> str:
         return self.lib.irlosc_kernel_name(self._h).decode()
 
+    @property
+    def frontend_name(self) -> str:
+        """Kernel `frontend()` launches: the lane-per-robot one when the model has the compiled Dual-UR5 shape, else the generic one."""
+        return self.lib.irlosc_frontend_name(self._h).decode()
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.irlosc_destroy(self._h)

@@ -121,6 +121,13 @@ extern "C" const char* irlosc_last_error(const irlosc_ctx* ctx) {
     return ctx ? ctx->err.c_str() : g_create_error.c_str();
 }
 
+extern "C" const char* irlosc_frontend_name(const irlosc_ctx* ctx) {
+    if (!ctx || !ctx->dmodel) return "";
+    const bool f64 = ctx->cfg.dtype == IRLOSC_F64;
+    if (ctx->fe_lane) return f64 ? "osc_frontend_lane_dual_ur5_f64out" : "osc_frontend_lane_dual_ur5_f32out";
+    return f64 ? "osc_frontend_generic_f64out" : "osc_frontend_generic_f32out";
+}
+
 extern "C" const char* irlosc_kernel_name(const irlosc_ctx* ctx) {
     return ctx ? ctx->kernel_name.c_str() : "";
 }

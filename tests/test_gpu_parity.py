@@ -769,7 +769,9 @@ def test_frontend_records_themselves(fe, B, dtype, monkeypatch):
     recs = [rb.records(om, lay.as_oracle_dict(), DUAL_UR5_EE, qpos[b], qvel[b]) for b in range(B)]
     R = {k: np.array([r[k] for r in recs]) for k in ("M", "J", "dq", "bias", "ee_pose")}
     osc = BatchedOSC(lay, B, dtype=dtype)
+    assert osc.frontend_name == ""
     osc.set_model(model)
+    assert ("_lane_" in osc.frontend_name) == (fe == "lane") and ("_generic_" in osc.frontend_name) == (fe == "generic")
     junk = {k: rng.normal(size=v.shape) * 7.0 + 3.0 for k, v in R.items()}
     junk["M"] = junk["M"] + junk["M"].transpose(0, 2, 1)
     junk["ee_pose"][:, :, 3:] = [1.0, 0.0, 0.0, 0.0]
