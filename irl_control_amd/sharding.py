@@ -123,6 +123,69 @@ class RcclComm:
                     pass
 
 
+class FileComm:
+    """The same three collectives through files in TMPDIR (one node): what bench.py falls back to when RCCL cannot be
+    brought up, so that a multi-GPU run still reports its line (and says so).  Every operation has a sequence number;
+    a rank publishes `<base>_op<seq>_r<rank>` (atomic rename), then reads all `world` files of that operation."""
+
+    def __init__(self, rank: int, world: int, tag: Optional[str] = None, timeout_s: float = 300.0):
+        self.rank, self.world, self.timeout_s = rank, world, timeout_s
+        self._base = rendezvous_path(tag) + "_file"
+        self._seq = 0
+
+    def _name(self, seq: int, r: int) -> str:
+        return f"{self._base}_op{seq}_r{r}"
+
+    def _exchange(self, payload: bytes) -> List[bytes]:
+        seq = self._seq
+        self._seq += 1
+        tmp = self._name(seq, self.rank) + ".tmp"
+        with open(tmp, "wb") as f:
+            f.write(payload)
+        os.replace(tmp, self._name(seq, self.rank))
+        out, t0 = [], time.time()
+        for r in range(self.world):
+            while True:
+                try:
+                    with open(self._name(seq, r), "rb") as f:
+                        data = f.read()
+                    if len(data) == len(payload):
+                        out.append(data)
+                        break
+                except OSError:
+                    pass
+                if time.time() - t0 > self.timeout_s:
+                    raise TimeoutError(f"rank {self.rank}: rank {r} never reached operation {seq}")
+                time.sleep(0.002)
+        if seq >= 2:                                   # everybody has published seq - 1, hence finished reading seq - 2
+            try:
+                os.remove(self._name(seq - 2, self.rank))
+            except OSError:
+                pass
+        return out
+
+    def reduce(self, steps_done: float, elapsed_s: float) -> Tuple[float, float]:
+        vals = [np.frombuffer(b, dtype=np.float64) for b in self._exchange(np.array([steps_done, elapsed_s], dtype=np.float64).tobytes())]
+        return float(sum(v[0] for v in vals)), float(max(v[1] for v in vals))
+
+    def barrier(self):
+        self.reduce(0.0, 0.0)
+
+    def allgather_u64(self, mine: int) -> List[int]:
+        return [int(np.frombuffer(b, dtype=np.uint64)[0]) for b in self._exchange(np.array([mine & (2 ** 64 - 1)], dtype=np.uint64).tobytes())]
+
+    def close(self):
+        """Two closing barriers: once the second is through, everybody has finished reading the first, so everything up
+        to it can go.  The (16-byte) files of the very last operation stay: no rank can know when the others have read them."""
+        self.barrier()
+        self.barrier()
+        for seq in range(max(0, self._seq - 3), self._seq - 1):
+            try:
+                os.remove(self._name(seq, self.rank))
+            except OSError:
+                pass
+
+
 def reduce_throughput(steps_done: float, elapsed_s: float, comm=None):
     """-> (total steps over all ranks, max elapsed over ranks, whole-job steps/s).  `comm` = anything with
     reduce(steps, elapsed) -> (sum, max) (RcclComm on the GPU box); None = single process."""

@@ -96,3 +96,36 @@ def test_reduce_throughput_single_process_and_env_defaults():
     assert sharding.reduce_throughput(10, 2.0) == (10.0, 2.0, 5.0)
     a = np.arange(12, dtype=np.float64)
     assert sharding.checksum_u64(a) == sharding.checksum_u64(a.copy()) != sharding.checksum_u64(a[::-1])
+
+
+def _filecomm_worker(rank, world, tag, q):
+    from irl_control_amd import sharding
+    c = sharding.FileComm(rank, world, tag=tag, timeout_s=60.0)
+    out = []
+    for it in range(5):                                   # several operations in a row: files of old operations are recycled
+        out.append(c.reduce(10.0 * (rank + 1) + it, 0.5 + rank + it))
+    c.barrier()
+    out.append(c.allgather_u64((0xdeadbeef00000000 + rank) & (2 ** 64 - 1)))
+    c.close()
+    q.put((rank, out))
+
+
+def test_filecomm_fallback_three_ranks(tmp_path, monkeypatch):
+    """bench.py's fallback when RCCL cannot be brought up: sum / max / all-gather through files, three processes."""
+    import multiprocessing as mp
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    ps = [ctx.Process(target=_filecomm_worker, args=(r, world, "t1", q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+    for r in range(world):
+        for it in range(5):
+            assert res[r][it] == (10.0 * 6 + 3 * it, 0.5 + 2 + it)
+        assert res[r][5] == [0xdeadbeef00000000 + k for k in range(world)]
+    import os
+    assert len([f for f in os.listdir(tmp_path) if "_file_op" in f]) <= world     # only the last operation's files stay
