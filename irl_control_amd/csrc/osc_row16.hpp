@@ -184,8 +184,8 @@ __device__ __forceinline__ double matvec16(const double x, const double (&Ac)[K]
 //   the caller already has (A + 2^-40 ||A||_F I is factored here instead where that one broke down: exactly singular J);
 //   the search stops as soon as trace(A^-1) minus the candidates found proves that nothing else can lie under the net;
 //   Rayleigh-Ritz on the span of the candidates when there are several; lambda_max is only bracketed
-//   (max diagonal <= lambda_max <= ||A||_F) unless a candidate falls inside the bracket of the cut, in which case it is
-//   computed (power iteration + Rayleigh quotient, iterated further only where a candidate sits within 2 % of the cut);
+//   (max diagonal <= lambda_max <= ||A||_F); a candidate inside the bracket of the cut is decided exactly by the inertia
+//   of (1e5 th) I - A;
 //   t = P A^-1 P w with P the projector off the eigenvectors at or under 1e-5 lambda_max.  Net full: give up (-> Jacobi).
 // Every quantity is uniform over the 16 lanes of an instance and frozen at the instance's own convergence, so a
 // result never depends on the other instances of the wave (sharding a batch differently changes no bit).
@@ -196,14 +196,18 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
     const double hi = sqrt(nA2);
     double sigma = 0.0;
     giveup = flagged && !(hi > 0.0 && t_finite(hi));
-    if (__any(flagged && !pdA)) {
-        // Some instance's plain factorisation broke down (exactly singular J): the wave factors again, that instance
-        // with sigma = 2^-40 ||A||_F on the diagonal, the others with sigma = 0 (which reproduces their factors).
+    // The plain factorisation is unusable when a pivot is non-positive -- or positive at rounding level: J singular to working
+    // precision leaves a pivot of +-1e-17 ||A||, and the sign is luck (tools/parity_sweep.py --stress found the positive ones:
+    // errors up to 200x).  trace(A^-1) ||A||_F >= cond(A) tells: beyond 1e11 the factorisation is redone on A + sigma.
+    const bool broken = !pdA || !(trA * hi < 1e11);
+    if (__any(flagged && broken)) {
+        // The wave factors again, that instance with sigma = 2^-40 ||A||_F on the diagonal (cond <= 1.1e12; the retained
+        // eigenvalues, >= 1e-5 lambda_max, move by <= 3e-7 relative), the others with sigma = 0 (which reproduces their factors).
         double A2[K], det2;
         bool pd2;
 #pragma unroll
         for (int r = 0; r < K; ++r) A2[r] = Ac[r];
-        const bool use = flagged && !pdA;
+        const bool use = flagged && broken;
         sigma = use ? hi * 0x1p-40 : 0.0;
         ldl16<K>(A2, l, sigma, F, G, invd_own, pd2, det2);
         giveup = giveup || (use && !pd2);
@@ -250,6 +254,23 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
             lam_prev = lam;
             fin = fin || (it >= 3 && settled);
             if (!__any(!fin)) break;
+        }
+        // The eigenvalue is settled to 1e-10, which leaves the VECTOR at ~1e-5 -- and what leaks past the projector is
+        // amplified by 1 / lambda_cut: two more steps (each gains at least the factor 4 of the net, typically far more) for
+        // every instance, whenever its loop froze (tools/parity_sweep.py --stress --layout k7: errors of 1.2e-5 .. 1.6e-5).
+#pragma unroll
+        for (int ex = 0; ex < 2; ++ex) {
+            double xn = x;
+#pragma unroll
+            for (int s0 = 0; s0 < NV - 1; ++s0) {
+                if (s0 < slot) xn = fma(-row_sum(v[s0] * xn), v[s0], xn);
+            }
+            solve16<K>(xn, F, G, invd_own);
+            const double n2 = row_sum(xn * xn);
+            const double rn = rsq_refined(n2 > 0.0 ? n2 : 1.0);
+            const bool ok = n2 > 0.0 && t_finite(rn);
+            x = ok ? xn * rn : x;
+            lam = (ok && lam <= 4.0 * net) ? rn - sigma : lam;
         }
         const bool cand = active && (lam <= net);
         // final clean-up against the earlier vectors (the last solve re-introduced rounding-level components)
@@ -317,64 +338,28 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
 #pragma unroll
         for (int i = 0; i < NV; ++i) th[i] = (m >= 2 && has[i]) ? h[i][i] - 0.0 : th[i];
     }
-    // lambda_max itself is only needed where a Ritz value lies inside the bracket of the cut [1e-5 lo, 1e-5 hi].  A Rayleigh
-    // quotient of power iterates only ever grows towards lambda_max, so it is a LOWER bound: a value at or under 1e-5 of it
-    // is cut for certain, whereas "kept" is only provisional -- the bound may still rise past it.  (A +-2 % window around
-    // the 24-step estimate decided this in an earlier version: with lambda_2 / lambda_1 = 0.85 that estimate is 6 % low
-    // and an eigenvalue 3 % under the cut was kept, tools/debug_parity.py on the 4 096-instance batch.)  So an instance
-    // with a provisionally kept value inside the bracket iterates on, in blocks of 16 steps, until the value is cut or twice
-    // what the quotient can still gain (geometric extrapolation of its last two gains) no longer reaches it; if 60 blocks
-    // do not settle that, the instance goes to the give-up list (exact Jacobi spectrum in the generic kernel).  An instance outside the bracket decides the same way for
-    // every lambda_max in [lo, hi], and each instance freezes at its own verdict: nothing depends on its wave-mates.
-    double lmax = lo;
-    bool inside = false;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) inside = inside || (has[i] && th[i] > 0.98e-5 * lo && th[i] < 1.02e-5 * hi);
-    if (__any(inside)) {
-        const double sc = rcp_refined(hi > 0.0 ? hi : 1.0);
-        double xp = l < K ? 0.2 + 0.05 * (double)((l * 7) % 5) : 0.0;
-        auto rayleigh = [&](double x) {
-            const double n2 = row_sum(x * x);
-            x *= rsq_refined(n2 > 0.0 ? n2 : 1.0);
-            const double y = matvec16<K>(x, Ac);
-            const double lm = row_sum(x * y);
-            return (lm > 0.0 && lm <= hi * 1.0000001) ? lm : hi;
-        };
-        // smallest provisionally kept value inside the bracket, as a bound on lambda_max: th / 1e-5 (infinity: none)
-        auto kept_bound = [&](double lb) {
-            double need = 1e300;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) need = (has[i] && th[i] > 1e-5 * lb && th[i] < 1.02e-5 * hi) ? fmin(need, th[i] * 1e5) : need;
-            return need;
-        };
-        for (int it = 0; it < 24; ++it) xp = matvec16<K>(xp, Ac) * sc;
-        double rho = fmax(rayleigh(xp), lo);
-        lmax = inside ? rho : lmax;
-        bool fin = !inside || !(kept_bound(rho) < 1e299);
-        double gain_prev = -1.0;
-        for (int blk = 0; blk < 60; ++blk) {
-            if (!__any(!fin)) break;
-            for (int it = 0; it < 16; ++it) xp = matvec16<K>(xp, Ac) * sc;
-            const double rn = fmax(rayleigh(xp), rho);
-            const double gain = rn - rho;
-            const double need = kept_bound(rn);
-            // the gains of successive blocks shrink geometrically (ratio q): what is still to come is gain q / (1 - q)
-            const double q = fmin(gain_prev > 0.0 ? gain * rcp_refined(gain_prev) : 1.0, 0.999);
-            const double to_come = gain * q * rcp_refined(1.0 - q);
-            const bool settled = !(need < 1e299) || (gain_prev >= 0.0 && 2.0 * to_come < need - rn);
-            lmax = fin ? lmax : rn;
-            rho = rn;
-            gain_prev = gain;
-            fin = fin || settled;
-        }
-        giveup = giveup || !fin;
-    }
-    const double cutoff = 1e-5 * lmax;
-    // the pinv cut (osc.py:55): drop the Ritz pairs at or under 1e-5 lambda_max
+    // The pinv cut (osc.py:55): drop the Ritz pairs at or under 1e-5 lambda_max.  lambda_max itself is never computed: it is
+    // bracketed by [lo, hi], a value at or under 1e-5 lo is cut and one over 1e-5 hi is kept whatever it is, and for a value
+    // th in between the question "th <= 1e-5 lambda_max" is "lambda_max >= beta = 1e5 th", i.e. "beta I - A is NOT positive
+    // definite" (Sylvester's law of inertia): one more L D L^T in the layout at hand, exact to rounding.  (Two estimates
+    // stood here before -- a 24-step power iteration with a +-2 % ambiguity window, then a growing Rayleigh quotient with
+    // a geometric extrapolation of what it could still gain -- and tools/parity_sweep.py broke both: lambda_2 / lambda_1 =
+    // 0.85 leaves the first 6 % short, a mix of fast and slow modes fools the second.)  Every instance asks about its own
+    // values only, so nothing depends on its wave-mates.
     int ncut = 0;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const bool cut = has[i] && th[i] <= cutoff;
+        const bool below = has[i] && th[i] <= 1e-5 * lo;
+        const bool ask = has[i] && !below && th[i] <= 1e-5 * hi;
+        bool cut = below;
+        if (__any(ask)) {
+            double A2[K], Ft[K], Gt[K], invt = 0.0, dett = 1.0;
+            bool pdt = true;
+#pragma unroll
+            for (int r = 0; r < K; ++r) A2[r] = -Ac[r];
+            ldl16<K>(A2, l, ask ? th[i] * 1e5 : 4.0 * hi, Ft, Gt, invt, pdt, dett);
+            cut = cut || (ask && !pdt);
+        }
         v[i] = cut ? v[i] : 0.0;
         ncut += cut ? 1 : 0;
     }

@@ -124,6 +124,40 @@ def test_row16_cut_decision_when_power_iteration_is_slow(dtype):
 
 
 @pytest.mark.parametrize("cfg", ["k13", "k7", "k12_admit"])
+def test_row16_stress_eigenvalues_all_around_the_cut(cfg):
+    """tools/parity_sweep.py --stress in small: 1-3 task rows of J per instance scaled by 10^U(-3.5, -1.5) (picked with
+    repetition: down to 1e-10, i.e. singular to working precision), so that nearly every instance truncates and the
+    eigenvalues of J M^-1 J^T sit anywhere around the cut.  The row16 kernel against the generic kernel (exact Jacobi
+    spectrum) on all of them, disagreements over 1e-5 only where the oracle has a singular value within 1 % of the cut.
+    This is what found: rounding-level positive pivots, eigenvectors settled to 1e-5 only, two lambda_max estimates."""
+    B = 16384
+    lay, gains, g = synth.make_batch(cfg, B, seed=777000 + 131 * 7)
+    rng = np.random.default_rng(4242 + 7)
+    k = g["J"].shape[1]
+    nrows = rng.integers(1, 4, size=B)
+    for j in range(3):
+        rows = rng.integers(0, k, size=B)
+        f = np.where(nrows > j, 10.0 ** rng.uniform(-3.5, -1.5, size=B), 1.0)
+        g["J"][np.arange(B), rows, :] *= f[:, None]
+    u, fl, kname = run_gpu(lay, gains, g, np.float64, kernel=_lib.KERNEL_ROW16)
+    ug, flg, gname = run_gpu(lay, gains, g, np.float64, kernel=1)
+    assert "row16" in kname and "generic" in gname
+    assert ((fl & 0x8) != 0).mean() > 0.8                                    # nearly everything truncates
+    err = rel_err(u, ug)
+    for b in np.nonzero(~(err <= TOL64))[0]:
+        Mx, Minv, Mxi, det = osc_oracle.task_inertia(g["J"][b], g["M"][b])
+        assert not in_parity_domain(Mxi, det), (kname, b, err[b])
+    idx = np.arange(0, B, 64)                                                # and the generic kernel against the oracle itself
+    ref = osc_oracle.generate_batch(lay.as_oracle_dict(), gains, g["M"], g["J"], g["dq"], g["bias"], g["ee_pose"], g["tgt_pose"],
+                                    g.get("wrench"), g.get("tgt_vel"), idx=idx)
+    eo = rel_err(ug[idx], ref[idx])
+    for b, e in zip(idx, eo):
+        if not e <= TOL64:
+            Mx, Minv, Mxi, det = osc_oracle.task_inertia(g["J"][b], g["M"][b])
+            assert not in_parity_domain(Mxi, det), (gname, b, e)
+
+
+@pytest.mark.parametrize("cfg", ["k13", "k7", "k12_admit"])
 def test_fp32_vs_oracle_on_fp32_inputs(cfg):
     """fp32 path (BASELINE config[2]).  Compared with the float64 oracle evaluated on the SAME
     float32-rounded inputs, so what is measured is the kernel's arithmetic, not input rounding.

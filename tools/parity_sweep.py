@@ -18,12 +18,23 @@ ap.add_argument("--seeds", type=int, default=16)
 ap.add_argument("--batch", type=int, default=65536)
 ap.add_argument("--layout", default="k13")
 ap.add_argument("--mode", default="f64", choices=["f64", "mixed"])
+ap.add_argument("--per-instance-gains", action="store_true")
+ap.add_argument("--stress", action="store_true", help="scale 1-3 task rows of J per instance by 10^U(-3.5, -1.5): eigenvalues of "
+                "J M^-1 J^T spread all over the neighbourhood of the pinv cut, up to three of them under it")
 a = ap.parse_args()
 dt = np.float64 if a.mode == "f64" else np.float32
 B = a.batch
 tot = bad_in = bad_out = 0
 for sd in range(a.seeds):
-    lay, gains, g = synth.make_batch(a.layout, B, seed=777000 + 131 * sd, dtype=dt)
+    lay, gains, g = synth.make_batch(a.layout, B, seed=777000 + 131 * sd, dtype=dt, per_instance_gains=a.per_instance_gains)
+    if a.stress:
+        rng = np.random.default_rng(4242 + sd)
+        k = g["J"].shape[1]
+        nrows = rng.integers(1, 4, size=B)
+        for j in range(3):
+            rows = rng.integers(0, k, size=B)
+            f = np.where(nrows > j, 10.0 ** rng.uniform(-3.5, -1.5, size=B), 1.0)
+            g["J"][np.arange(B), rows, :] = (g["J"][np.arange(B), rows, :] * f[:, None]).astype(dt)
     res = {}
     # the reference for float32 records is the generic kernel in float64 on the SAME (rounded) numbers
     g64 = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in g.items()}
