@@ -23,6 +23,8 @@ ap.add_argument("--band", type=float, default=1e-2, help="a singular value this 
 ap.add_argument("--per-instance-gains", action="store_true")
 ap.add_argument("--physical", action="store_true", help="M, J, bias, EE poses of random joint states of the Dual-UR5 model (rigid-body "
                 "front end on the GPU) instead of the synthetic records: the conditioning of real kinematics, singular poses included")
+ap.add_argument("--stress-rows", type=int, default=3, help="with --stress: up to this many rows (more than 3 under the cut sends an instance "
+                "to the give-up list, i.e. through the generic kernel)")
 ap.add_argument("--stress", action="store_true", help="scale 1-3 task rows of J per instance by 10^U(-3.5, -1.5): eigenvalues of "
                 "J M^-1 J^T spread all over the neighbourhood of the pinv cut, up to three of them under it")
 a = ap.parse_args()
@@ -53,8 +55,8 @@ for sd in range(a.seeds):
     if a.stress:
         rng = np.random.default_rng(4242 + sd)
         k = g["J"].shape[1]
-        nrows = rng.integers(1, 4, size=B)
-        for j in range(3):
+        nrows = rng.integers(1, a.stress_rows + 1, size=B)
+        for j in range(a.stress_rows):
             rows = rng.integers(0, k, size=B)
             f = np.where(nrows > j, 10.0 ** rng.uniform(-3.5, -1.5, size=B), 1.0)
             g["J"][np.arange(B), rows, :] = (g["J"][np.arange(B), rows, :] * f[:, None]).astype(dt)
