@@ -291,7 +291,7 @@ __device__ __forceinline__ void stage2_body(const S2Args a, int blk, int32_t* ld
             // (sharding a batch differently must not change a single bit): a lane FREEZES x and lambda at its own
             // convergence; the loop merely keeps running until the slowest lane of the wave is done.
             bool fin = !active;
-            for (int it = 0; it < 6; ++it) {
+            for (int it = 0; it < 32; ++it) {      // (6 until round 2: a neighbour 25 % above the cut needs ~30 steps to let go)
                 float xn[K];
 #pragma unroll
                 for (int i = 0; i < K; ++i) xn[i] = x[i];
