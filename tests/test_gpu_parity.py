@@ -157,6 +157,28 @@ def test_row16_stress_eigenvalues_all_around_the_cut(cfg):
             assert not in_parity_domain(Mxi, det), (gname, b, e)
 
 
+def test_fp32_group_path_has_no_gross_errors_beyond_the_straddling_pairs():
+    """float32 arithmetic cannot meet 1e-5 (error ~ eps32 * cond), but it must take the reference's BRANCH wherever float32
+    can tell: the bench batch against the generic kernel in float64 on the same rounded records, errors over 0.1 counted
+    outside a 5 % band around the pinv cut (and around the |det| = 1e-4 switch).  What is left are pairs of eigenvalues
+    straddling the cut within ~35 %: 4 per 65 536 (with lambda_max from 8 power steps it was 30: tools/parity_sweep.py)."""
+    B = 65536
+    lay, gains, g = synth.make_batch("k13", B, seed=777000, dtype=np.float32)
+    g64 = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in g.items()}
+    u, fl, kname = run_gpu(lay, gains, g, np.float32)
+    ug, flg, gname = run_gpu(lay, gains, g64, np.float64, kernel=1)
+    assert "group" in kname and "generic_f64" in gname
+    err = rel_err(u.astype(np.float64), ug)
+    n_in = 0
+    for b in np.nonzero(~(err <= 0.1))[0]:
+        Mx, Minv, Mxi, det = osc_oracle.task_inertia(g64["J"][b], g64["M"][b])
+        s = np.linalg.svd(Mxi, compute_uv=False)
+        near = np.any(np.abs(s / s[0] / 1e-5 - 1.0) < 0.05) or 0.5e-4 < abs(det) < 2e-4
+        n_in += not near
+    assert n_in <= 10, n_in
+    assert np.median(err) < 1e-4
+
+
 @pytest.mark.parametrize("cfg", ["k13", "k7", "k12_admit"])
 def test_fp32_vs_oracle_on_fp32_inputs(cfg):
     """fp32 path (BASELINE config[2]).  Compared with the float64 oracle evaluated on the SAME
