@@ -246,6 +246,8 @@ def main():
 
     from irl_control_amd import BatchedOSC, sharding, synth
     rank, world, local_rank = sharding.env_world()
+    if "IRLOSC_BENCH_DEVICE" in os.environ:                  # test hook: several ranks on ONE GPU (then RCCL refuses the duplicate
+        local_rank = int(os.environ["IRLOSC_BENCH_DEVICE"])  # device and the file-based reduction is what gets exercised)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
