@@ -20,8 +20,7 @@
 #include "osc_assemble.hpp"
 #include "osc_row16.hpp"
 #include "osc_frontend.hpp"
-#include "osc_frontend_lane.hpp"
-#include "topo_dual_ur5.hpp"
+#include "launchers.hpp"
 
 using namespace irlosc;
 
@@ -396,8 +395,7 @@ static int assemble_launch(irlosc_ctx* c, int slot, int B, const irlosc_raw_desc
     r.site_xmat = ft ? (const T*)dptr[7] : nullptr; r.sensordata = ft ? (const T*)dptr[8] : nullptr;
     r.M = (T*)c->dM[slot]; r.J = (T*)c->dJ[slot]; r.dq = (T*)c->ddq[slot]; r.bias = (T*)c->dbias[slot];
     r.ee = (T*)c->dee[slot]; r.wrench = (T*)c->dwrench[slot];
-    hipLaunchKernelGGL(osc_assemble_kernel<T>, dim3(std::min(B, 65536)), dim3(64), 0, st, d, r, B);
-    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, (hipError_t)launch_assemble<T>(d, r, B, st));
     return IRLOSC_OK;
 }
 
@@ -598,8 +596,7 @@ static int group_train(irlosc_ctx* c, const KParams<float>* ps, const int* sets,
             KParams<float> pt = ps[i];
             pt.index = nullptr;
             pt.b0 = nfast;
-            hipLaunchKernelGGL(osc_generic_kernel<float>, dim3(rem), dim3(64), generic_smem_bytes<float>(pt.n, pt.k, pt.ndev), st, pt);
-            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, (hipError_t)launch_generic<float>(pt, rem, st));
         }
     }
     c->pending = fresh;
@@ -633,9 +630,7 @@ static int row16_train(irlosc_ctx* c, const KParams<T>* ps, int n, hipStream_t s
     if (c->tev_begin) HIPCHK(c, hipEventRecord(c->tev_begin, st));
     int rc = launch_row16<T>(tr, n, st);
     if (rc) return fail(c, IRLOSC_ERR_HIP, "row16 kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-    hipLaunchKernelGGL((osc_generic_worklist_kernel<double, T>), dim3(64, n), dim3(64),
-                       generic_smem_bytes<double>(ps[0].n, ps[0].k, ps[0].ndev), st, tr, other);
-    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, (hipError_t)launch_row16_worklist<T>(tr, n, other, st));
     if (c->tev_end) HIPCHK(c, hipEventRecord(c->tev_end, st));
     return IRLOSC_OK;
 }
@@ -657,9 +652,7 @@ static int launch_t(irlosc_ctx* c, int B, const void* M, const void* J, const vo
         }
     }
     if (c->kernel == IRLOSC_KERNEL_ROW16) return row16_train<T>(c, &p, 1, st);
-    size_t smem = generic_smem_bytes<T>(p.n, p.k, p.ndev);
-    hipLaunchKernelGGL(osc_generic_kernel<T>, dim3(B), dim3(64), smem, st, p);
-    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, (hipError_t)launch_generic<T>(p, B, st));
     return IRLOSC_OK;
 }
 
@@ -970,11 +963,11 @@ extern "C" int irlosc_set_model(irlosc_ctx* c, const irlosc_model* m) {
     c->fe_smem = frontend_smem_bytes(m->nb, m->nj);
     {
         const char* e = getenv("IRLOSC_FRONTEND");           // "generic": force the wave-per-instance kernel (A/B measurements)
-        c->fe_lane = frontend_lane_matches<TopoDualUr5>(h) && !(e && !strcmp(e, "generic"));
+        c->fe_lane = frontend_lane_dual_ur5_matches(h) && !(e && !strcmp(e, "generic"));
     }
     if (c->fe_lane && !c->fe_side) {
         const size_t waves = ((size_t)c->cfg.max_batch + 63) / 64;
-        HIPCHK(c, hipMalloc((void**)&c->fe_side, waves * FeTopo<TopoDualUr5>::n_side() * 64 * sizeof(double)));
+        HIPCHK(c, hipMalloc((void**)&c->fe_side, waves * frontend_lane_dual_ur5_side_doubles_per_wave() * sizeof(double)));
     }
     HIPCHK(c, hipMemcpyAsync(c->dmodel, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1011,18 +1004,20 @@ static int frontend_launch(irlosc_ctx* c, int slot, int B) {
     if (!c->has_q[slot]) return fail(c, IRLOSC_ERR_STATE, "slot %d: irlosc_upload_q must precede irlosc_frontend", slot);
     if (B == 0) { c->uploaded[slot] = -1; return IRLOSC_OK; }
     if (B > c->has_q[slot]) return fail(c, IRLOSC_ERR_STATE, "slot %d holds joint coordinates of %d instances, front end asked for %d", slot, std::max(0, c->has_q[slot]), B);
-    const dim3 grid(std::min(B, 1 << 20)), lgrid((B + 63) / 64);
+    int rc;
     if (c->cfg.dtype == IRLOSC_F64) {
         const FeOut<double> o{(double*)c->dM[slot], (double*)c->dJ[slot], (double*)c->ddq[slot], (double*)c->dbias[slot], (double*)c->dee[slot]};
-        if (c->fe_lane) hipLaunchKernelGGL((osc_frontend_lane_kernel<TopoDualUr5, double>), lgrid, dim3(64), 0, c->stream, c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B, c->fe_side);
-        else hipLaunchKernelGGL(osc_frontend_kernel<double>, grid, dim3(64), c->fe_smem, c->stream, c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B);
+        rc = c->fe_lane ? launch_frontend_lane_dual_ur5<double>(c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B, c->fe_side, c->stream)
+                        : launch_frontend_generic<double>(c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B, c->fe_smem, c->stream);
     } else {
         const FeOut<float> o{(float*)c->dM[slot], (float*)c->dJ[slot], (float*)c->ddq[slot], (float*)c->dbias[slot], (float*)c->dee[slot]};
-        if (c->fe_lane) hipLaunchKernelGGL((osc_frontend_lane_kernel<TopoDualUr5, float>), lgrid, dim3(64), 0, c->stream, c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B, c->fe_side);
-        else hipLaunchKernelGGL(osc_frontend_kernel<float>, grid, dim3(64), c->fe_smem, c->stream, c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B);
+        rc = c->fe_lane ? launch_frontend_lane_dual_ur5<float>(c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B, c->fe_side, c->stream)
+                        : launch_frontend_generic<float>(c->dmodel, c->dqpos[slot], c->dqvel[slot], o, B, c->fe_smem, c->stream);
     }
-    HIPCHK(c, hipGetLastError());
-    c->uploaded[slot] = std::max(c->uploaded[slot], B);
+    HIPCHK(c, (hipError_t)rc);
+    // The records of this slot are now those of B robots: an earlier, larger upload must not vouch for instances the front
+    // end did not write (the wrench of the slot stays what the last irlosc_upload / irlosc_upload_raw put there).
+    c->uploaded[slot] = B;
     return IRLOSC_OK;
 }
 

@@ -1,0 +1,44 @@
+// Host-side launch functions of the kernels, one translation unit per kernel family (tu_*.hip) so that the library builds
+// in parallel and a change to one kernel recompiles one unit.  irlosc.hip (the C ABI) only sees these declarations.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "osc_common.hpp"
+
+namespace irlosc {
+
+// tu_group.hip -- fp32 group path (osc_group.hpp, osc_group_stage1.hpp)
+struct TrainStep;
+int launch_group_train(const TrainStep* dtable, int nsteps, int total_blocks, int k, int ndev, hipStream_t st);
+int launch_giveup_lists(const TrainStep* dtable, int nsteps, int n, int k, int ndev, hipStream_t st);
+
+// tu_generic.hip -- one wavefront per instance (osc_generic.hpp); T = float, double
+template <typename T>
+int launch_generic(const KParams<T>& p, int blocks, hipStream_t st);
+
+// tu_row16_f64.hip / tu_row16_f32.hip -- fp64-arithmetic row16 path (osc_row16.hpp); TIN = record type
+template <typename TIN> struct Row16Train;
+template <typename TIN>
+int launch_row16(const Row16Train<TIN>& tr, int nsteps, hipStream_t st);
+template <typename TIN>
+int launch_row16_worklist(const Row16Train<TIN>& tr, int nsteps, int32_t* reset, hipStream_t st);
+
+// tu_frontend.hip / tu_frontend_lane.hip -- rigid-body front end (osc_frontend.hpp, osc_frontend_lane.hpp); TOUT = record type
+struct FeModel;
+template <typename TOUT> struct FeOut;
+template <typename TOUT>
+int launch_frontend_generic(const FeModel* dmodel, const double* qpos, const double* qvel, const FeOut<TOUT>& out, int B, size_t smem,
+                            hipStream_t st);
+template <typename TOUT>
+int launch_frontend_lane_dual_ur5(const FeModel* dmodel, const double* qpos, const double* qvel, const FeOut<TOUT>& out, int B,
+                                  double* side, hipStream_t st);
+size_t frontend_lane_dual_ur5_side_doubles_per_wave();
+bool frontend_lane_dual_ur5_matches(const FeModel& h);
+
+// tu_assemble.hip -- state assembly from raw simulator arrays (osc_assemble.hpp)
+struct RawDesc;
+template <typename T> struct RawPtrs;
+template <typename T>
+int launch_assemble(const RawDesc& d, const RawPtrs<T>& r, int B, hipStream_t st);
+
+}  // namespace irlosc

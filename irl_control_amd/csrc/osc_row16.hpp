@@ -777,26 +777,15 @@ __global__ __launch_bounds__(64) void osc_generic_worklist_kernel(const Row16Tra
     const KParams<S>& p = tr.p[blockIdx.y];
     const int32_t* __restrict__ list = tr.x[blockIdx.y].worklist;
     const int n = *tr.x[blockIdx.y].workcount;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && reset) reset[blockIdx.y] = 0;      // the other bank: the next train's counters
+    // The other bank = the next train's counters, ALL of them: a shorter train (step_resident with iters % R16_TRAIN != 0)
+    // would otherwise leave the counters beyond its own length at whatever an earlier, longer train counted.
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < R16_TRAIN && reset) reset[threadIdx.x] = 0;
     for (int it = blockIdx.x; it < n; it += gridDim.x) generic_instance<T>(p, list[it], smem);
 }
 
 inline bool row16_kernel_supports(int dtype, int n, int k, int ndev) {
     (void)dtype;     // fp64 records, or fp32 records with fp64 arithmetic (mixed path)
     return n == 25 && ((k == 13 && ndev == 3) || (k == 12 && ndev == 2) || (k == 7 && ndev == 3));
-}
-
-// nsteps steps of equal batch size B (the steps of one train), blockIdx.y = step
-template <typename TIN>
-inline int launch_row16(const Row16Train<TIN>& tr, int nsteps, hipStream_t st) {
-    const KParams<TIN>& p = tr.p[0];
-    if (p.B <= 0 || nsteps <= 0) return 0;
-    const dim3 grid((p.B + 3) / 4, nsteps);
-    if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25>), grid, dim3(64), 0, st, tr);
-    else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<12, 2, TIN, 25>), grid, dim3(64), 0, st, tr);
-    else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<7, 3, TIN, 25>), grid, dim3(64), 0, st, tr);
-    else return (int)hipErrorNotSupported;
-    return (int)hipGetLastError();
 }
 
 }  // namespace irlosc

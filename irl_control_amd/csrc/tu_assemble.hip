@@ -1,0 +1,16 @@
+// Translation unit of the state-assembly gather kernel, float and double.
+#include "osc_assemble.hpp"
+#include "launchers.hpp"
+
+namespace irlosc {
+
+template <typename T>
+int launch_assemble(const RawDesc& d, const RawPtrs<T>& r, int B, hipStream_t st) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(osc_assemble_kernel<T>, dim3(B < 65536 ? B : 65536), dim3(64), 0, st, d, r, B);
+    return (int)hipGetLastError();
+}
+template int launch_assemble<float>(const RawDesc&, const RawPtrs<float>&, int, hipStream_t);
+template int launch_assemble<double>(const RawDesc&, const RawPtrs<double>&, int, hipStream_t);
+
+}  // namespace irlosc

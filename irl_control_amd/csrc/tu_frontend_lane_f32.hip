@@ -1,0 +1,18 @@
+// Translation unit of the lane-per-robot rigid-body front end with the Dual-UR5 tree shape compiled in, float records
+// (one unit per record type: each instantiation is ~13 k fp64 instructions of straight-line code, ~100 s of compile time).
+#include "osc_frontend_lane.hpp"
+#include "topo_dual_ur5.hpp"
+#include "launchers.hpp"
+
+namespace irlosc {
+
+template <typename TOUT>
+int launch_frontend_lane_dual_ur5(const FeModel* dmodel, const double* qpos, const double* qvel, const FeOut<TOUT>& out, int B,
+                                  double* side, hipStream_t st) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL((osc_frontend_lane_kernel<TopoDualUr5, TOUT>), dim3((B + 63) / 64), dim3(64), 0, st, dmodel, qpos, qvel, out, B, side);
+    return (int)hipGetLastError();
+}
+template int launch_frontend_lane_dual_ur5<float>(const FeModel*, const double*, const double*, const FeOut<float>&, int, double*, hipStream_t);
+
+}  // namespace irlosc

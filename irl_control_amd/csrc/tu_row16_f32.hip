@@ -1,0 +1,34 @@
+// Translation unit of the fp64-arithmetic row16 path on float records: the three Dual-UR5 shapes and the give-up pass.
+#include "osc_generic.hpp"
+#include "osc_row16.hpp"
+#include "launchers.hpp"
+
+namespace irlosc {
+
+// nsteps steps of equal batch size B (the steps of one train), blockIdx.y = step
+template <typename TIN>
+int launch_row16(const Row16Train<TIN>& tr, int nsteps, hipStream_t st) {
+    const KParams<TIN>& p = tr.p[0];
+    if (p.B <= 0 || nsteps <= 0) return 0;
+    const dim3 grid((p.B + 3) / 4, nsteps);
+    if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25>), grid, dim3(64), 0, st, tr);
+    else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<12, 2, TIN, 25>), grid, dim3(64), 0, st, tr);
+    else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<7, 3, TIN, 25>), grid, dim3(64), 0, st, tr);
+    else return (int)hipErrorNotSupported;
+    return (int)hipGetLastError();
+}
+
+
+// The generic kernel (Jacobi, fp64 arithmetic) over the give-up lists of a train; zeroes the counters `reset` points at.
+template <typename TIN>
+int launch_row16_worklist(const Row16Train<TIN>& tr, int nsteps, int32_t* reset, hipStream_t st) {
+    const KParams<TIN>& p = tr.p[0];
+    hipLaunchKernelGGL((osc_generic_worklist_kernel<double, TIN>), dim3(64, nsteps), dim3(64),
+                       generic_smem_bytes<double>(p.n, p.k, p.ndev), st, tr, reset);
+    return (int)hipGetLastError();
+}
+
+template int launch_row16<float>(const Row16Train<float>&, int, hipStream_t);
+template int launch_row16_worklist<float>(const Row16Train<float>&, int, int32_t*, hipStream_t);
+
+}  // namespace irlosc

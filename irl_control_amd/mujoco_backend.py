@@ -8,7 +8,7 @@ listed in fakesim.py; this adapter provides exactly that set on top of ``mujoco.
   model: body_name2id, body_parentid, body_jntadr, body_jntnum, joint_id2name, joint_name2id, jnt_qposadr,
          actuator_trnid, nv, nu
   data : qpos, qvel, qacc, qM, qfrc_bias, sensordata, ctrl, xfrc_applied, get_body_xpos / xquat / xvelp / jacp / jacr,
-         get_site_xmat, set_mocap_pos
+         get_site_xmat, set_mocap_pos, get_joint_qpos / get_joint_qvel / set_joint_qpos / set_joint_qvel
   sim  : model, data, forward(), step(), fullM(), inverse()
 
 ``import mujoco`` happens only when an adapter is created, so the package works without MuJoCo (FakeSim, or the GPU
@@ -79,6 +79,32 @@ class _Data:
 
     def set_mocap_pos(self, name, pos):
         self._d.mocap_pos[self._m.body_mocapid[self._model.body_name2id(name)]] = pos
+
+    # mujoco_py's per-joint accessors (examples/insertion_task.py:227,251 read the pose of an action object's free joint):
+    # width by joint type -- mjJNT_FREE 7 qpos / 6 dofs, mjJNT_BALL 4 / 3, slide and hinge 1 / 1 (returned as a scalar).
+    _QPOS_WIDTH = {0: 7, 1: 4, 2: 1, 3: 1}
+    _QVEL_WIDTH = {0: 6, 1: 3, 2: 1, 3: 1}
+
+    def _joint_span(self, name, vel):
+        j = self._model.joint_name2id(name)
+        adr = int((self._m.jnt_dofadr if vel else self._m.jnt_qposadr)[j])
+        return adr, (self._QVEL_WIDTH if vel else self._QPOS_WIDTH)[int(self._m.jnt_type[j])]
+
+    def get_joint_qpos(self, name):
+        adr, w = self._joint_span(name, False)
+        return self._d.qpos[adr] if w == 1 else self._d.qpos[adr:adr + w]
+
+    def get_joint_qvel(self, name):
+        adr, w = self._joint_span(name, True)
+        return self._d.qvel[adr] if w == 1 else self._d.qvel[adr:adr + w]
+
+    def set_joint_qpos(self, name, value):
+        adr, w = self._joint_span(name, False)
+        self._d.qpos[adr:adr + w] = value
+
+    def set_joint_qvel(self, name, value):
+        adr, w = self._joint_span(name, True)
+        self._d.qvel[adr:adr + w] = value
 
 
 class MujocoSim:

@@ -420,6 +420,33 @@ def test_give_up_instances_inside_trains():
     assert np.median(d) < 1e-3 and np.quantile(d, 0.9) < 5e-2, (float(np.median(d)), float(d.max()))
 
 
+def test_row16_give_up_counters_do_not_go_stale_across_uneven_trains():
+    """step_resident(12) = a train of 8 and one of 4; the give-up pass of the SHORT train used to zero only four of the
+    other bank's eight counters, so the next 8-train appended its give-ups behind the lists of two trains ago and the
+    generic kernel recomputed those stale ids with the wrong step's data.  Three slots with DIFFERENT give-up sets (five
+    lost ranks: beyond the eigen stage's net), uneven calls, then bit-equality with a plain single step."""
+    nslots, B = 3, 512 + 4
+    lay = synth.make_layout("k13")
+    osc = BatchedOSC(lay, B, dtype=np.float64, n_slots=nslots)
+    assert "row16" in osc.kernel_name
+    for sl in range(nslots):
+        _, gains, g = synth.make_batch("k13", B, seed=300 + sl, dtype=np.float64)
+        bad = np.arange(sl, B, 7 + sl)
+        g["J"][bad, 8:13] = g["J"][bad, 0:5]
+        osc.upload(g["M"], g["J"], g["dq"], g["bias"], g["ee_pose"], g.get("wrench"), slot=sl)
+        osc.set_targets(g["tgt_pose"], g.get("tgt_vel"), slot=sl)
+        if sl == 0:
+            osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+    for rep in range(3):
+        osc.step_resident(12, first_slot=0)                      # 8 @ bank 0, 4 @ bank 1
+        osc.step_resident(8, first_slot=1 + rep)                 # 8 @ bank 0 again: step 7 runs slot (1 + rep + 7) % 3
+        u_train, f_train = osc.download(B)
+        osc.step(slot=(1 + rep + 7) % nslots)
+        u_one, f_one = osc.download(B)
+        assert np.array_equal(u_train, u_one) and np.array_equal(f_train, f_one), rep
+    osc.close()
+
+
 def test_time_dominant_kernel_leaves_complete_outputs():
     lay, gains, g = synth.make_batch("k13", 4096, seed=9, dtype=np.float32)
     osc = BatchedOSC(lay, 4096, dtype=np.float32)

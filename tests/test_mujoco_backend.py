@@ -21,6 +21,8 @@ def _fake_mujoco(fs: "fakesim.FakeSim"):
         nv, nu = fs.model.nv, fs.model.nu
         body_parentid, body_jntadr, body_jntnum = fs.model.body_parentid, fs.model.body_jntadr, fs.model.body_jntnum
         jnt_qposadr, actuator_trnid = fs.model.jnt_qposadr, fs.model.actuator_trnid
+        jnt_type = np.array([3] * fs.model.nq_robot + [0] * fs.model.n_free_bodies)          # mjJNT_HINGE, mjJNT_FREE
+        jnt_dofadr = np.concatenate([np.arange(fs.model.nq_robot), fs.model.nq_robot + 6 * np.arange(fs.model.n_free_bodies)])
         body_mocapid = np.array([0 if n == "target_red" else 1 if n == "target_blue" else -1 for n in fs.model.body_names])
 
     class MjData:
@@ -33,7 +35,7 @@ def _fake_mujoco(fs: "fakesim.FakeSim"):
             self.mocap_pos = np.zeros((2, 3))
 
     def name2id(m, kind, name):
-        table = {1: fs.model.body_names, 3: fs.model.joint_names, 6: sites}[kind]
+        table = {1: fs.model.body_names, 3: fs.model.joint_names + fs.model.free_joint_names, 6: sites}[kind]
         return table.index(name) if name in table else -1
 
     def jac(m, d, jp, jr, bid):
@@ -85,3 +87,37 @@ def test_adapter_serves_the_member_set_and_the_host_assembly(monkeypatch):
         assert np.array_equal(sa[ic.RobotState.J][0][nm], sf[ic.RobotState.J][0][nm])
         for key in (ic.DeviceState.EE_XYZ, ic.DeviceState.EE_QUAT, ic.DeviceState.FORCE, ic.DeviceState.TORQUE):
             assert np.array_equal(sa[nm][key], sf[nm][key])
+
+
+def test_action_sequence_runner_reads_object_poses_through_the_adapter(monkeypatch):
+    """ActionSequenceRunner.set_waypoint_targets reads an action object's free-joint pose with sim.data.get_joint_qpos
+    (insertion_task.py:227,251): with the official bindings that accessor is the adapter's, not MjData's."""
+    import irl_control_amd as ic
+    from irl_control_amd.action_sequence import ActionSequenceRunner, load_action_config
+    from irl_control_amd.mujoco_backend import MujocoSim
+    free = ["free_joint_grommet_11mm", "free_joint_dual_peg", "free_joint_female", "free_joint_male"]
+    fs = fakesim.randomize(fakesim.FakeSim(free_joint_names=free), np.random.default_rng(5))
+    mj = _fake_mujoco(fs)
+    monkeypatch.setitem(sys.modules, "mujoco", mj)
+    sim = MujocoSim(mj.MjModel())
+    app = ic.MujocoApp("default_xyz_abg.yaml", None, sim=sim)
+
+    class NoController:
+        pass
+    r = ActionSequenceRunner(app, NoController(), active_arm="left")
+    cfg = load_action_config()
+    r.action_objects = cfg["grommet_action_objects"]
+    r.initialize_action_objects()                                    # MujocoApp.set_free_joint_qpos on the adapter
+    male = cfg["grommet_action_objects"]["male_object"]
+    got = sim.data.get_joint_qpos(male["joint_name"])
+    assert got.shape == (7,) and np.allclose(got[:3], male["initial_pos_xyz"])
+    assert np.array_equal(got, fs.data.get_joint_qpos(male["joint_name"]))
+    assert np.isscalar(sim.data.get_joint_qpos("joint0_ur5right")) or np.ndim(sim.data.get_joint_qpos("joint0_ur5right")) == 0
+    assert np.shape(sim.data.get_joint_qvel(male["joint_name"])) == (6,)
+    sim.data.set_joint_qvel(male["joint_name"], np.arange(6.0))
+    dof0 = fs.model.nq_robot + 6 * free.index(male["joint_name"])
+    assert np.array_equal(fs.data.qvel[dof0:dof0 + 6], np.arange(6.0))
+    sim.data.set_joint_qpos("joint1_ur5left", 0.25)
+    assert fs.data.qpos[fs.model.joint_names.index("joint1_ur5left")] == 0.25
+    r.set_waypoint_targets(dict(action="WP", target_xyz="male_object", target_abg="male_object", offset="hover_offset"))
+    assert np.allclose(r.targets["ur5left"].get_xyz(), np.array(male["initial_pos_xyz"]) + male["hover_offset"])
