@@ -15,9 +15,10 @@ batches are rotated so that successive launches do not re-hit the 256 MiB Infini
 The JSON line's "dtype" is the arithmetic type ("f64" for f64 and mixed); config.records names the storage.
 
 Instances shard across GPUs with no data-path collective (weak scaling: B per GPU is fixed; `--total-batch T`
-divides T over the ranks instead, e.g. BASELINE configs[3]: --gpus 8 --total-batch 262144).  One process per GPU,
-launched as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`; the launcher only provides
-RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*.  No PyTorch here: the barrier, the sum of steps, the max of the elapsed
+divides T over the ranks instead, e.g. BASELINE configs[3]: --gpus 8 --total-batch 262144).  One process per GPU:
+either launched as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (the launcher only
+provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), or -- plain `python bench.py --gpus N` with no launcher
+environment -- bench.py starts its N workers itself.  No PyTorch here: the barrier, the sum of steps, the max of the elapsed
 time and the all-gather of per-rank output checksums are RCCL calls behind the C ABI (irlosc_bench_allreduce,
 irlosc_comm_allgather_u64), and the device synchronisation is hipDeviceSynchronize (irlosc_device_sync).
 Rank 0 prints ONE JSON line.
@@ -26,8 +27,14 @@ import argparse
 import json
 import multiprocessing as mp
 import os
+import subprocess
 import sys
 import time
+
+# The CPU baseline runs one oracle worker per core: the BLAS / OpenMP pools must be single-threaded BEFORE NumPy loads
+# its BLAS (threadpoolctl after the fact leaves the library's 256 spinning threads per worker behind).
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -35,6 +42,10 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 lanes x 2 flop (FMA) x 2.4 GHz: v_fma_f64 issues at the full VALU rate
+# Useful fp64 flops of one control step from joint coordinates (FMA = 2; DESIGN.md section 5 derives both figures):
+FLOPS_OSC_STEP = {"k13": 23.0e3, "k12_admit": 21.6e3, "k7": 14.6e3}    # Cholesky, substitution, J M^-1 J^T, k x k, torques
+FLOPS_FRONT_END = 21.5e3                                                # FK, EE Jacobians, CRBA, RNEA of the Dual-UR5 tree
 MODES = {   # --dtype -> (record dtype, arithmetic label, kernel id)
     "f64": (np.float64, "f64", 0),
     "mixed": (np.float32, "f64", 3),
@@ -47,15 +58,16 @@ def algorithmic_bytes(n, k, ndev, admittance, esz):
     return esz * (n * n + k * n + 2 * n + 14 * ndev + (6 * ndev if admittance else 0) + n)
 
 
-def measured_traffic(kernel_name):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/hbm_traffic.json: FETCH_SIZE x2-corrected + WRITE_SIZE), or None."""
+def measured_profile(kernel_name):
+    """What the committed rocprofv3 passes say about the dominant kernel (profiles/hbm_traffic.json): HBM bytes per launch
+    from the PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE) and the kernel trace's average
+    duration; {} when there is no entry."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(kernel_name, {}).get("traffic_bytes_per_launch")
+            return json.load(f).get(kernel_name, {}) or {}
     except (OSError, ValueError):
-        return None
+        return {}
 
 
 def baseline_config_of(layout, batch, world, mode):
@@ -74,74 +86,134 @@ def baseline_config_of(layout, batch, world, mode):
 _CPU = {}
 
 
-def _cpu_worker(args):
-    """One worker = one core: the op-for-op oracle over its share of instance ids, BLAS pinned to one thread."""
-    wid, nworkers, seconds = args
+def effective_cores():
+    """-> (usable cores, affinity count, cgroup quota in cores or None).  os.cpu_count() ignores both the affinity mask
+    and a container's CPU quota; a pool of cpu_count() workers on a quota of 16 cores measures the scheduler."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
     try:
-        from threadpoolctl import threadpool_limits
-        ctx = threadpool_limits(limits=1)
-    except ImportError:
-        ctx = None
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2
+            q, p = f.read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(p)
+    except (OSError, ValueError):
+        try:                                                            # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                p = int(f.read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    n = aff if quota is None else max(1, min(aff, int(quota)))
+    return n, aff, quota
+
+
+def _cpu_worker(wid, nworkers, seconds, barrier, q):
+    """One worker = one core: the op-for-op oracle over its share of instance ids (BLAS single-threaded by the
+    environment set at the top of this file).  Warm-up, then everybody starts the measured window together."""
     from oracle import osc_oracle
     a, od, gains = _CPU["a"], _CPU["od"], _CPU["gains"]
     Btot = a["M"].shape[0]
-    done, t0 = 0, time.perf_counter()
     chunk = 64
     pos = (wid * (Btot // nworkers)) % Btot
-    while time.perf_counter() - t0 < seconds:
-        idx = [(pos + i) % Btot for i in range(chunk)]
+
+    def run(p):
+        idx = [(p + i) % Btot for i in range(chunk)]
         osc_oracle.generate_batch(od, gains, a["M"], a["J"], a["dq"], a["bias"], a["ee_pose"], a["tgt_pose"],
                                   a.get("wrench"), a.get("tgt_vel"), idx=idx)
-        done += chunk
-        pos = (pos + chunk) % Btot
-    dt = time.perf_counter() - t0
-    if ctx is not None:
-        ctx.__exit__(None, None, None)
-    return done, dt
+    try:
+        run(pos)
+        barrier.wait(timeout=300)
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            pos = (pos + chunk) % Btot
+            run(pos)
+            done += chunk
+        q.put((wid, done, time.perf_counter() - t0))
+    except Exception as e:                                  # noqa: BLE001
+        q.put((wid, 0, 0.0, str(e)))
+
+
+def _rb_worker(args):
+    """Chained oracles for the from_q parity leg: rigid-body oracle -> records -> OSC oracle, one robot at a time."""
+    lo, hi = args
+    from oracle import osc_oracle, rigid_body as rb
+    from irl_control_amd.rigid_body import DUAL_UR5_EE
+    c = _CPU
+    om = rb.Model()
+    recs = [rb.records(om, c["od"], DUAL_UR5_EE, c["qpos"][b], c["qvel"][b]) for b in range(lo, hi)]
+    st = {k: np.array([r[k] for r in recs]) for k in ("M", "J", "dq", "bias", "ee_pose")}
+    return osc_oracle.generate_batch(c["od"], c["gains"], st["M"], st["J"], st["dq"], st["bias"], st["ee_pose"],
+                                     c["tgt_pose"][lo:hi], None, None)
+
+
+def from_q_reference(lay, gains, qpos, qvel, tgt_pose, nrobots, ncores):
+    """Reference torques of the path from joint coordinates for the first `nrobots` robots (forked workers: the
+    rigid-body oracle is ~13 ms of NumPy per robot)."""
+    n = int(min(nrobots, qpos.shape[0]))
+    w = max(1, min(ncores, 64, n // 16))
+    _CPU.update(od=lay.as_oracle_dict(), gains=gains, qpos=qpos, qvel=qvel, tgt_pose=np.asarray(tgt_pose, dtype=np.float64))
+    try:
+        spans = [(n * i // (4 * w), n * (i + 1) // (4 * w)) for i in range(4 * w)]
+        with mp.get_context("fork").Pool(w) as pool:
+            parts = pool.map(_rb_worker, [sp for sp in spans if sp[1] > sp[0]])
+        return np.concatenate(parts, axis=0)
+    finally:
+        _CPU.clear()
 
 
 def cpu_baseline(lay, gains, arrays, seconds_single=8.0, seconds_all=8.0):
-    """-> (cpu_baseline dict, reference outputs, their instance ids).  Three figures:
-    all host cores (one oracle worker per core, os.cpu_count() stated) = the headline; one core; and the stacked-LAPACK
-    restatement as a stronger single-process comparator."""
+    """-> (cpu_baseline dict, reference outputs, their instance ids).  Three figures: all usable
+    host cores (one oracle worker per core; affinity mask and cgroup quota honoured, all three counts stated) = the
+    headline; one core; and the stacked-LAPACK restatement as a stronger single-process comparator."""
     from oracle import osc_oracle
-    try:
-        from threadpoolctl import threadpool_limits
-    except ImportError:
-        threadpool_limits = None
     a64 = {k: v.astype(np.float64) for k, v in arrays.items()}
     od = lay.as_oracle_dict()
 
     def run(idx):
         return osc_oracle.generate_batch(od, gains, a64["M"], a64["J"], a64["dq"], a64["bias"], a64["ee_pose"],
                                          a64["tgt_pose"], a64.get("wrench"), a64.get("tgt_vel"), idx=idx)
-    ctx = threadpool_limits(limits=1) if threadpool_limits else None
-    try:
-        run(range(0, 64))                                   # warm-up
-        t0 = time.perf_counter(); run(range(64, 576)); dt = time.perf_counter() - t0
-        nsamp = int(max(512, min(a64["M"].shape[0] - 576, seconds_single / (dt / 512))))
-        t0 = time.perf_counter(); ref = run(range(576, 576 + nsamp)); dt = time.perf_counter() - t0
-    finally:
-        if ctx is not None:
-            ctx.__exit__(None, None, None)
+    run(range(0, 64))                                   # warm-up
+    t0 = time.perf_counter(); run(range(64, 576)); dt = time.perf_counter() - t0
+    nsamp = int(max(512, min(a64["M"].shape[0] - 576, seconds_single / (dt / 512))))
+    t0 = time.perf_counter(); ref = run(range(576, 576 + nsamp)); dt = time.perf_counter() - t0
+    blas = os.environ.get("OPENBLAS_NUM_THREADS", "?")
     single = dict(value=nsamp / dt, unit="steps/s", cores=1,
                   sample=f"{nsamp} of the {a64['M'].shape[0]} instances of slot 0, oracle/osc_oracle.py "
-                         f"(float64 NumPy, OPENBLAS threads=1), {dt:.1f} s")
+                         f"(float64 NumPy, OPENBLAS_NUM_THREADS={blas}), {dt:.1f} s")
     out = dict(single)
     out["kind"] = "port"
-    # whole host: one worker per core, fork (the arrays are inherited, not pickled)
-    ncores = os.cpu_count() or 1
+    # whole host: one worker per usable core, forked (the arrays are inherited, not pickled); the window starts at a
+    # barrier all workers reach after their warm-up, so process start-up is not in it
+    ncores, aff, quota = effective_cores()
     try:
         _CPU.update(a=a64, od=od, gains=gains)
-        with mp.get_context("fork").Pool(ncores) as pool:
-            t0 = time.perf_counter()
-            res = pool.map(_cpu_worker, [(w, ncores, seconds_all) for w in range(ncores)])
-            wall = time.perf_counter() - t0
-        total = sum(r[0] for r in res)
-        out = dict(value=total / wall, unit="steps/s", cores=ncores, kind="port",
-                   sample=f"{total} oracle steps by {ncores} worker processes (os.cpu_count() = {ncores}, one per core, "
-                          f"BLAS threads = 1 each) in {wall:.1f} s wall incl. pool start-up, instances of slot 0",
-                   single_core=single)
+        ctx = mp.get_context("fork")
+        barrier, q = ctx.Barrier(ncores), ctx.Queue()
+        procs = [ctx.Process(target=_cpu_worker, args=(w, ncores, seconds_all, barrier, q), daemon=True) for w in range(ncores)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=600) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+        errs = [r[3] for r in res if len(r) > 3]
+        if errs:
+            raise RuntimeError(errs[0])
+        total, window = sum(r[1] for r in res), max(r[2] for r in res)
+        rates = sorted(r[1] / r[2] for r in res)
+        value = total / window
+        eff = value / (single["value"] * ncores)
+        out = dict(value=value, unit="steps/s", cores=ncores, kind="port",
+                   sample=f"{total} oracle steps by {ncores} worker processes in a {window:.1f} s window that starts after "
+                          f"every worker's warm-up (cores: os.cpu_count() = {os.cpu_count()}, affinity mask = {aff}, cgroup CPU "
+                          f"quota = {'none' if quota is None else '%.1f' % quota} -> {ncores} workers, OPENBLAS_NUM_THREADS={blas} "
+                          f"each); per worker {rates[0]:.0f} / {rates[len(rates) // 2]:.0f} / {rates[-1]:.0f} steps/s (min / median "
+                          f"/ max) against {single['value']:.0f} for one worker alone: parallel efficiency {eff:.2f}"
+                          + ("" if eff >= 0.5 else " (the workers share SMT siblings, L3 and memory bandwidth: every step "
+                             "streams its instance's 8.5 KB through NumPy temporaries)") + "; instances of slot 0",
+                   parallel_efficiency=eff, single_core=single)
     except Exception as e:                                  # the baseline must never break the bench line
         out["all_cores_error"] = str(e)
     finally:
@@ -157,40 +229,50 @@ def cpu_baseline(lay, gains, arrays, seconds_single=8.0, seconds_all=8.0):
         osc_oracle_batched.generate_batch(od, gb, sl["M"], sl["J"], sl["dq"], sl["bias"], sl["ee_pose"], sl["tgt_pose"],
                                           sl.get("wrench"), sl.get("tgt_vel"))
         dtb = time.perf_counter() - t0
-        out["vectorised"] = dict(value=nb / dtb, unit="steps/s", cores="one process, BLAS threads at the library default",
+        out["vectorised"] = dict(value=nb / dtb, unit="steps/s", cores=f"one process, OPENBLAS_NUM_THREADS={blas}",
                                  sample=f"{nb} instances, oracle/osc_oracle_batched.py (stacked np.linalg calls), {dtb:.1f} s")
     except Exception as e:
         out["vectorised"] = dict(error=str(e))
     return out, ref, range(576, 576 + nsamp)
 
 
-def parity_sample(lay, arr, u, ref, idx):
-    """GPU vs float64 oracle on the same (record-dtype-rounded) inputs; the instances over 1e-5 are then classified
-    against the parity domain (the reference's own answer well defined, no singular value within
-    1 % of the pinv cut)."""
+def oracle_reference(lay, gains, arrays, lo, hi):
+    """float64 oracle on the (record-dtype-rounded) inputs of instances [lo, hi) -> u[hi - lo, n]."""
+    from oracle import osc_oracle
+    a64 = {k: v[lo:hi].astype(np.float64) for k, v in arrays.items()}
+    return osc_oracle.generate_batch(lay.as_oracle_dict(), gains, a64["M"], a64["J"], a64["dq"], a64["bias"], a64["ee_pose"],
+                                     a64["tgt_pose"], a64.get("wrench"), a64.get("tgt_vel"))
+
+
+def parity_sample(arr, u, ref, idx, tol=1e-5, note=None):
+    """GPU vs float64 oracle on the same (record-dtype-rounded) inputs: u[i] against ref[i] for i in idx; the instances
+    over `tol` are then classified against the parity domain (the reference's own answer well
+    defined, no singular value within 1 % of the pinv cut)."""
     from oracle import osc_oracle
     idx = np.asarray(list(idx))
     err = np.max(np.abs(u[idx].astype(np.float64) - ref[idx]), axis=1) / np.max(np.abs(ref[idx]), axis=1)
-    over = idx[err > 1e-5]
+    over = idx[err > tol]
     in_dom = 0
     for b in over[:2000]:
         Mx, Minv, Mxi, det = osc_oracle.task_inertia(arr["J"][b].astype(np.float64), arr["M"][b].astype(np.float64))
-        s = np.linalg.svd(Mxi, compute_uv=False)
+        sv = np.linalg.svd(Mxi, compute_uv=False)
         if abs(det) >= 1e-4:
-            ok = s[-1] > 1e-12 * s[0]
+            ok = sv[-1] > 1e-12 * sv[0]
         else:
-            ok = not np.any(np.abs(s / s[0] / 1e-5 - 1.0) < 1e-2)
+            ok = not np.any(np.abs(sv / sv[0] / 1e-5 - 1.0) < 1e-2)
         in_dom += bool(ok)
-    return {"n": int(len(idx)), "median_rel_err": float(np.median(err)), "p99_rel_err": float(np.quantile(err, 0.99)),
-            "max_rel_err": float(err.max()), "n_over_1e-5": int(len(over)), "n_over_1e-5_in_parity_domain": int(in_dom),
-            "note": "GPU vs float64 oracle on the same (record-dtype-rounded) inputs; parity domain per SURVEY.md 8c"}
+    return {"n": int(len(idx)), "tolerance": tol, "median_rel_err": float(np.median(err)),
+            "p99_rel_err": float(np.quantile(err, 0.99)), "max_rel_err": float(err.max()), "n_over_tol": int(len(over)),
+            "n_over_tol_in_parity_domain": int(in_dom),
+            "note": note or "GPU vs float64 oracle on the same (record-dtype-rounded) inputs; parity domain per SURVEY.md 8c"}
 
 
-def measure_from_q(BatchedOSC, synth, args, B, local_rank):
+def measure_from_q(BatchedOSC, synth, args, B, local_rank, state0=None, ref_u=None):
     """The path from joint coordinates: per step the rigid-body front end computes M, J,
     bias and the EE poses from resident (qpos, qvel) on the GPU, then the OSC step runs on them.  What a host-side
     simulator would have to ship per step otherwise is the 8.5 KB of records (PCIe ceiling ~63 GB/s / 8 536 B = 7.4e6
-    steps/s in float64, 1.5e7 in float32)."""
+    steps/s in float64, 1.5e7 in float32).  The bound of this path is arithmetic, not HBM (568 B in, 200 B out per
+    robot): `roofline` prices it against the fp64 vector peak."""
     from irl_control_amd.rigid_body import RigidBodyModel
     try:
         dt, arith, kern = MODES[args.dtype]
@@ -198,11 +280,11 @@ def measure_from_q(BatchedOSC, synth, args, B, local_rank):
         model = RigidBodyModel.load("dual_ur5")
         osc = BatchedOSC(lay, B, dtype=dt, hip_device=local_rank, n_slots=args.slots, kernel=kern)
         osc.set_model(model)
-        rng = np.random.default_rng(20241008 + 77)
+        rng = np.random.default_rng(20241008 + 78)
         _, gains, arr = synth.make_batch(args.layout, B, seed=20241008 + 2000, dtype=dt)
         osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
         for s in range(args.slots):
-            qpos, qvel = model.random_state(rng, B)
+            qpos, qvel = state0 if (s == 0 and state0 is not None) else model.random_state(rng, B)
             osc.upload_q(qpos, qvel, slot=s)
             osc.frontend(slot=s)
             osc.set_targets(arr["tgt_pose"], arr.get("tgt_vel"), slot=s)
@@ -215,15 +297,62 @@ def measure_from_q(BatchedOSC, synth, args, B, local_rank):
         el = time.perf_counter() - t0
         _, ms_osc = osc.step_resident(steps)
         esz = np.dtype(dt).itemsize
+        flops = FLOPS_FRONT_END + FLOPS_OSC_STEP.get(args.layout, FLOPS_OSC_STEP["k13"])
+        achieved = flops * B / (ms_step * 1e-3) / 1e12
         res = dict(value=B * steps / el, unit="steps/s", ms_per_step=el / steps * 1e3, ms_per_step_events=ms_step,
                    ms_osc_step_alone=ms_osc, ms_front_end=ms_step - ms_osc, kernel=osc.frontend_name + " + " + osc.kernel_name,
                    input_bytes_per_step_per_instance=2 * lay.n * 8 + 7 * lay.ndev * esz,
+                   roofline=dict(bound="fp64_valu", achieved=achieved, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
+                                 frac=achieved / FP64_VALU_PEAK_TFLOPS, flops_per_step_per_instance=flops,
+                                 note="useful fp64 flops (FMA = 2) of front end + OSC step, DESIGN.md section 5; HBM sees "
+                                      "568 B in and 200 B out per robot, so the HBM roof is not the bound of this path"),
                    note="per step: rigid-body front end (FK, EE Jacobians, CRBA, RNEA) from resident (qpos, qvel), then the OSC "
-                        "step on the records it wrote; nothing crosses PCIe")
+                        "step; nothing crosses PCIe")
+        if ref_u is not None:                          # front end + step on slot 0 against the chained oracles
+            osc.frontend(slot=0)
+            osc.step(slot=0)
+            u, _ = osc.download(B)
+            res["parity_sample"] = _parity_plain(u, ref_u, 1e-5,
+                                                 "GPU front end + OSC step vs oracle/rigid_body.py -> oracle/osc_oracle.py chained "
+                                                 "on the same (qpos, qvel, targets) of the first robots of slot 0")
         osc.close()
         return res
     except Exception as e:                              # never break the bench line
         return dict(error=str(e))
+
+
+def _parity_plain(u, ref, tol, note):
+    n = len(ref)
+    err = np.max(np.abs(u[:n].astype(np.float64) - ref), axis=1) / np.max(np.abs(ref), axis=1)
+    return {"n": int(n), "tolerance": tol, "median_rel_err": float(np.median(err)), "p99_rel_err": float(np.quantile(err, 0.99)),
+            "max_rel_err": float(err.max()), "n_over_tol": int((err > tol).sum()), "note": note}
+
+
+def self_launch(args_list, n):
+    """`python bench.py --gpus N` without a launcher environment: start the N workers here, one per GPU, with the
+    variables a launcher would provide; rank 0's stdout (the JSON line) passes through.  -> exit code."""
+    import secrets
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    tag = f"self_{port}_{secrets.token_hex(4)}"
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), IRLOSC_RDV_TAG=tag)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + args_list, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    try:
+        from irl_control_amd import sharding
+        d = sharding.rendezvous_dir(tag)
+        for f in os.listdir(d):
+            os.remove(os.path.join(d, f))
+        os.rmdir(d)
+    except OSError:
+        pass
+    return next((rc for rc in rcs if rc), 0)
 
 
 def main():
@@ -244,25 +373,24 @@ def main():
     ap.add_argument("--no-from-q", action="store_true", help="skip the joint-coordinates path (front end + step)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
+
     from irl_control_amd import BatchedOSC, sharding, synth
     rank, world, local_rank = sharding.env_world()
     if "IRLOSC_BENCH_DEVICE" in os.environ:                  # test hook: several ranks on ONE GPU (then RCCL refuses the duplicate
         local_rank = int(os.environ["IRLOSC_BENCH_DEVICE"])  # device and the file-based reduction is what gets exercised)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
-                     "--master-port P bench.py --gpus N ...")
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     B = args.total_batch // world if args.total_batch else args.batch
-    comm, comm_note = None, "RCCL (through the C ABI)"
+    comm, comm_note = None, "single process"
     if world > 1:
-        try:
-            comm = sharding.RcclComm(rank, world, local_rank)
-        except Exception as e:                                # still report the line; say how it was reduced
-            comm = sharding.FileComm(rank, world)
-            comm_note = f"files in TMPDIR (RCCL could not be brought up: {e})"
+        comm, comm_note = sharding.make_comm(rank, world, local_rank)
 
-    def measure(mode, steps, warmup, with_check, preroll):
+    def make_slot(mode, s):
+        return synth.make_batch(args.layout, B, seed=20241008 + 1000 * 2 + 17 * s + 101 * rank, dtype=MODES[mode][0])
+
+    def measure(mode, steps, warmup, preroll):
         dt, arith, kern = MODES[mode]
         if args.kernel >= 0:
             kern = args.kernel
@@ -271,7 +399,7 @@ def main():
         osc = BatchedOSC(lay, B, dtype=dt, hip_device=local_rank, n_slots=args.slots, kernel=kern)
         slot0 = None
         for s in range(args.slots):
-            _, gains, arr = synth.make_batch(args.layout, B, seed=20241008 + 1000 * 2 + 17 * s + 101 * rank, dtype=dt)
+            _, gains, arr = make_slot(mode, s)
             osc.upload(arr["M"], arr["J"], arr["dq"], arr["bias"], arr["ee_pose"], arr.get("wrench"), slot=s)
             osc.set_targets(arr["tgt_pose"], arr.get("tgt_vel"), slot=s)
             if s == 0:
@@ -296,9 +424,9 @@ def main():
         elapsed = time.perf_counter() - t0
         total_steps, elapsed, rate = sharding.reduce_throughput(B * steps, elapsed, comm)
         bytes_step = algorithmic_bytes(lay.n, lay.k, lay.ndev, lay.admittance, esz) * B
-        spl = osc.steps_per_launch              # the fp32 group path chains this many steps into one launch
+        spl = osc.steps_per_launch              # the throughput paths chain this many steps into one launch
         bytes_launch = bytes_step * spl
-        # dominant kernel alone, HIP events on its stream (fp32 group: the fused train launch; else one step's kernel)
+        # dominant kernel alone, HIP events on its stream (one event pair per launch of a train)
         ms_dom = osc.time_dominant_kernel(min(200, max(10 * spl, steps // 2)))
         if comm:
             ms_dom = comm.reduce(0.0, ms_dom)[1]
@@ -310,30 +438,49 @@ def main():
             note = ":fused(stage 1 of %d chained steps + riding stage 2 of the previous launch)" % spl
         elif "row16" in kname:
             note = ":step(all instances incl. the in-kernel truncated-pinv stage; + the give-up list launch)"
+        prof = measured_profile(kname)
+        roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=achieved / HBM_PEAK_GBS, traffic=prof.get("traffic_bytes_per_launch"),
+                    kernel=kname + note, kernel_ms=ms_dom, steps_per_launch=spl, step_ms_events=ms_kernel,
+                    whole_step_achieved=bytes_step / (ms_kernel * 1e-3) / 1e9,
+                    algorithmic_bytes_per_launch=bytes_launch,
+                    algorithmic_bytes_per_step_per_instance=bytes_step // B)
+        if prof.get("rocprof_avg_us") and prof.get("steps_per_launch") == spl and prof.get("instances") == B:
+            # the committed kernel trace of the same command (profiles/): tracing serialises dispatches and adds its own
+            # overhead, so this is the conservative figure next to the live one (profiles/README.md has the timestamps)
+            roof["rocprof_kernel_ms"] = prof["rocprof_avg_us"] * 1e-3
+            roof["frac_rocprof"] = bytes_launch / (prof["rocprof_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
         res = dict(value=rate, ms_per_step=elapsed / steps * 1e3, kernel=kname, mode=mode, arith=arith,
-                   records="float64" if esz == 8 else "float32", layout=lay,
-                   roofline=dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                                 frac=achieved / HBM_PEAK_GBS, traffic=measured_traffic(kname),
-                                 kernel=kname + note, kernel_ms=ms_dom, steps_per_launch=spl, step_ms_events=ms_kernel,
-                                 whole_step_achieved=bytes_step / (ms_kernel * 1e-3) / 1e9,
-                                 algorithmic_bytes_per_launch=bytes_launch,
-                                 algorithmic_bytes_per_step_per_instance=bytes_step // B))
-        check = None
+                   records="float64" if esz == 8 else "float32", layout=lay, roofline=roof)
         osc.step(slot=0)
         u, fl = osc.download(B)
         res["checksum"] = sharding.checksum_u64(u)
-        if with_check:
-            check = (lay, gains, slot0, u, fl)
         osc.close()
-        return res, check
+        return res, (lay, gains, slot0, u, fl)
 
-    # CPU baseline first: its worker processes are forked before this process has initialised the HIP runtime
-    cb = None
+    # CPU legs first: their worker processes are forked before this process has initialised the HIP runtime
+    cb = ref = ref_idx = fq_state = fq_ref = None
+    sec_refs = {}
+    others = [m for m in ("f64", "mixed", "f32") if m != args.dtype] if (world == 1 and not args.no_secondary) else []
     if world == 1 and not args.no_cpu_baseline:
-        lay0, gains0, arr0 = synth.make_batch(args.layout, B, seed=20241008 + 1000 * 2 + 101 * rank, dtype=MODES[args.dtype][0])
+        lay0, gains0, arr0 = make_slot(args.dtype, 0)
         cb, ref, ref_idx = cpu_baseline(lay0, gains0, arr0)
+        # the same instances through the oracle on float32-rounded records, for the modes that store float32
+        NSEC = 4096
+        for other in others:
+            if MODES[other][0] != MODES[args.dtype][0] and MODES[other][0] not in sec_refs:
+                _, g_o, arr_o = make_slot(other, 0)
+                sec_refs[MODES[other][0]] = oracle_reference(lay0, g_o, arr_o, 0, min(NSEC, B))
+                del arr_o
+        if not args.no_from_q and args.layout in ("k13", "k7"):
+            from irl_control_amd.rigid_body import RigidBodyModel
+            model = RigidBodyModel.load("dual_ur5")
+            fq_state = model.random_state(np.random.default_rng(20241008 + 77), B)
+            _, gq, aq = synth.make_batch(args.layout, B, seed=20241008 + 2000, dtype=MODES[args.dtype][0])
+            fq_ref = from_q_reference(lay0, gq, fq_state[0], fq_state[1], aq["tgt_pose"], 4096, effective_cores()[0])
+            del aq
         del arr0
-    primary, chk = measure(args.dtype, args.steps, args.warmup, with_check=(rank == 0), preroll=args.preroll)
+    primary, chk = measure(args.dtype, args.steps, args.warmup, preroll=args.preroll)
     lay = primary.pop("layout")
     names = ", ".join(f"{nm}:{r}" for nm, r in zip(lay.dev_names, lay.dev_rows))
     out = {
@@ -351,33 +498,51 @@ def main():
                    "kernel": primary["kernel"], "preroll_steps": args.preroll,
                    "steps_per_launch": primary["roofline"]["steps_per_launch"],
                    "sharding": f"{world} x independent shards, no data-path collective; barrier and final sum(steps) / "
-                               f"max(elapsed) reduction: {comm_note if world > 1 else 'single process'}"},
+                               f"max(elapsed) reduction: {comm_note}"},
         "roofline": primary["roofline"],
     }
     # per-rank checksum of one step's outputs on slot 0 (rank r's data depend on r only, so its checksum must be the
     # same in the 1-, 2-, 4- and 8-GPU runs: sharding changes no bit)
     out["rank_checksums"] = [f"{v:016x}" for v in (comm.allgather_u64(primary["checksum"]) if comm else [primary["checksum"]])]
-    if rank == 0 and chk is not None:
+    if rank == 0:
         lay_, gains, arr, u, fl = chk
         out["flags"] = {"eigen_path_frac": float(((fl & 4) != 0).mean()), "pinv_branch_frac": float(((fl & 2) != 0).mean()),
                         "truncated_frac": float(((fl & 8) != 0).mean()), "nonfinite_frac": float(((fl & 64) != 0).mean())}
         if cb is not None:
             out["cpu_baseline"] = cb
-            out["parity_sample"] = parity_sample(lay_, arr, u, ref, ref_idx)
-    if world == 1 and not args.no_secondary:
+            out["parity_sample"] = parity_sample(arr, u, ref, ref_idx)
+    if others:
         out["secondary"] = []
-        for other in [m for m in ("f64", "mixed", "f32") if m != args.dtype]:
+        for other in others:
             try:
-                sec, _ = measure(other, max(20, min(200, args.steps // 4)), max(5, min(20, args.warmup // 4)),
-                                 with_check=False, preroll=min(args.preroll, 100))
+                sec, schk = measure(other, max(24, min(200, args.steps // 4)), max(8, min(24, args.warmup // 4)),
+                                    preroll=min(args.preroll, 100))
             except Exception as e:                       # e.g. a layout without a group kernel
                 out["secondary"].append({"mode": other, "error": str(e)})
                 continue
             sec.pop("layout")
-            out["secondary"].append({"mode": other, "dtype": sec["arith"], "records": sec["records"], "value": sec["value"],
-                                     "ms_per_step": sec["ms_per_step"], "kernel": sec["kernel"], "roofline": sec["roofline"]})
+            entry = {"mode": other, "dtype": sec["arith"], "records": sec["records"], "value": sec["value"],
+                     "ms_per_step": sec["ms_per_step"], "kernel": sec["kernel"], "roofline": sec["roofline"]}
+            rdt = MODES[other][0]
+            sref = sec_refs.get(rdt) if rdt != MODES[args.dtype][0] else (None if ref is None else ref)
+            if sref is not None:
+                _, _, sarr, su, _ = schk
+                if rdt != MODES[args.dtype][0]:
+                    n = len(sref)
+                    full = np.full((su.shape[0], su.shape[1]), np.nan)
+                    full[:n] = sref
+                    sidx = range(n)
+                else:
+                    full, sidx = sref, ref_idx
+                f32 = sec["arith"] == "f32"
+                entry["parity_sample"] = parity_sample(
+                    sarr, su, full, sidx, tol=1e-5,
+                    note=("float32 ARITHMETIC: error ~ eps32 * cond(J M^-1 J^T); this mode is the fastest one and does NOT meet "
+                          "north_star's 1e-5 (n_over_tol says by how much); " if f32 else "")
+                         + "GPU vs float64 oracle on the same float32-rounded records; parity domain per SURVEY.md 8c")
+            out["secondary"].append(entry)
     if world == 1 and not args.no_from_q:
-        out["from_q"] = measure_from_q(BatchedOSC, synth, args, B, local_rank)
+        out["from_q"] = measure_from_q(BatchedOSC, synth, args, B, local_rank, fq_state, fq_ref)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if comm:

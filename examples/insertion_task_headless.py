@@ -25,7 +25,7 @@ FREE_JOINTS = ["free_joint_grommet_11mm", "free_joint_dual_peg", "free_joint_fem
 EE_BODY = {"ur5right": "ur_EE_ur5right", "ur5left": "ur_EE_ur5left"}
 
 
-def build(seed=0, active_arm="right", rate=0.08, dtype=np.float64, on_tick=None):
+def build(seed=0, active_arm="right", rate=0.08, dtype=np.float64, on_tick=None, tick_seconds=0.001):
     dyn = ToyDynamics(rate=rate)
     sim = randomize(FakeSim(free_joint_names=FREE_JOINTS, dynamics=dyn), np.random.default_rng(seed))
     app = irl_control.MujocoApp("default_xyz_abg.yaml", None, sim=sim)
@@ -33,27 +33,29 @@ def build(seed=0, active_arm="right", rate=0.08, dtype=np.float64, on_tick=None)
     cfgs = [("base", app.get_controller_config("osc0")), ("ur5right", app.get_controller_config("osc2")),
             ("ur5left", app.get_controller_config("osc2"))]
     controller = irl_control.OSC(robot, sim, cfgs, app.get_controller_config("nullspace"), dtype=dtype)
-    runner = ActionSequenceRunner(app, controller, active_arm=active_arm, on_tick=on_tick)
+    runner = ActionSequenceRunner(app, controller, active_arm=active_arm, on_tick=on_tick, tick_seconds=tick_seconds)
     dyn.goal_provider = lambda: ({EE_BODY[n]: t.get_xyz() for n, t in runner.targets.items()},
                                  {EE_BODY[n]: t.get_quat() for n, t in runner.targets.items()})
     return sim, runner
 
 
-def run(seed=0, active_arm="right", objects="nist_action_objects", with_grip=False, rate=0.08, verbose=True, dtype=np.float64):
+def run(seed=0, active_arm="right", objects="nist_action_objects", with_grip=False, rate=0.08, verbose=True, dtype=np.float64,
+        tick_seconds=None):
     rec = dict(ctrl=[], max_vel=[])
 
     def on_tick(r, forces):
         rec["ctrl"].append(np.array(r.sim.data.ctrl))
         rec["max_vel"].append(float(r.active_arm.max_vel[0]))
-    sim, runner = build(seed, active_arm, rate, dtype, on_tick)
+    sim, runner = build(seed, active_arm, rate, dtype, on_tick, tick_seconds if tick_seconds else 0.001)
     cfg = load_action_config("insertion_task.yaml")
     runner.action_objects = cfg[objects]
     runner.initialize_action_objects()
     seq = cfg["insertion_action_sequence"]
     if not with_grip:
         seq = [e for e in seq if e["action"] == "WP"]
-    else:       # keep the example short: the GRIP holds last 20 ticks instead of 1000-2000
+    elif tick_seconds is None:       # keep the example short: the GRIP holds last 20 ticks instead of 1000-2000
         seq = [dict(e, gripper_duration=0.02) if e["action"] == "GRIP" else e for e in seq]
+    # (with tick_seconds given, a GRIP lasts gripper_duration / tick_seconds ticks: the golden's 0.04 s -> 25 / 50 ticks)
     runner.run_sequence(seq)
     if verbose:
         print(f"{len(seq)} actions, {runner.ticks} ticks, final error {runner.errors[runner.active_arm.name]:.4g}")

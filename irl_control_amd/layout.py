@@ -88,6 +88,7 @@ class OSCLayout:
         """The plain-dict form oracle/osc_oracle.generate_batch takes (tests only)."""
         return dict(n=self.n, dev_names=list(self.dev_names), dev_rows=self.dev_rows, ctrlr_dof=self.ctrlr_dof,
                     joint_ids=self.joint_ids, j_idx0=self.j_idx0, has_max_vel=self.has_max_vel,
+                    calc_xyz=[bool(x) for x in self.calc_xyz], calc_abg=[bool(x) for x in self.calc_abg],
                     use_g=self.use_g, admittance=self.admittance, nullspace=self.nullspace)
 
     @classmethod

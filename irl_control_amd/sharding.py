@@ -10,6 +10,8 @@ LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment.
 """
 import ctypes as C
 import os
+import stat
+import threading
 import time
 import zlib
 from typing import List, Optional, Tuple
@@ -41,11 +43,27 @@ def checksum_u64(a: np.ndarray) -> int:
     return (zlib.crc32(b[:h].tobytes()) << 32) | zlib.crc32(b[h:].tobytes())
 
 
+def rendezvous_dir(tag: Optional[str] = None) -> str:
+    """Private directory of THIS launch for the rendezvous files (RCCL unique id, transport markers, FileComm): every
+    worker of one launcher shares its parent process and MASTER_PORT (a self-launching bench.py hands its workers a
+    random IRLOSC_RDV_TAG instead), so both go into the name.  Created 0700; an existing path is accepted only if it is
+    a real directory owned by this user with no group / other access (a shared /tmp must not let another user plant or
+    redirect the files)."""
+    tag = tag or os.environ.get("IRLOSC_RDV_TAG") or f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+    d = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"irlosc_{os.getuid()}_{tag}")
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError(f"rendezvous directory {d} is not a private directory of uid {os.getuid()}")
+    return d
+
+
 def rendezvous_path(tag: Optional[str] = None) -> str:
-    """Where rank 0 leaves the RCCL unique id for the other ranks of THIS launch: every worker of one launcher shares
-    its parent process and MASTER_PORT, so both go into the name."""
-    tag = tag or f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
-    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"irlosc_rccl_id_{tag}")
+    """Where rank 0 leaves the RCCL unique id for the other ranks of this launch."""
+    return os.path.join(rendezvous_dir(tag), "rccl_id")
 
 
 def exchange_bytes(rank: int, payload: Optional[bytes], nbytes: int, path: str, timeout_s: float = 120.0) -> bytes:
@@ -184,6 +202,50 @@ class FileComm:
                 os.remove(self._name(seq, self.rank))
             except OSError:
                 pass
+
+
+def make_comm(rank: int, world: int, hip_device: int, tag: Optional[str] = None, init_timeout_s: float = 120.0):
+    """-> (communicator, note).  RCCL when EVERY rank brought it up, files otherwise: the choice is made collectively --
+    each rank publishes an ok / failed marker in the rendezvous directory and reads all of them -- because a job where
+    some ranks barrier through RCCL and others through files never finishes.  ncclCommInitRank runs in a helper thread
+    with a deadline (a rank whose peers failed early would wait in it forever); a communicator that came up on this rank
+    while another rank failed is abandoned, not destroyed (its destruction may wait for the missing peers too)."""
+    box = {}
+
+    def init():
+        try:
+            box["comm"] = RcclComm(rank, world, hip_device, tag)
+        except Exception as e:                                   # noqa: BLE001 - reported in the bench line
+            box["err"] = str(e)
+    th = threading.Thread(target=init, daemon=True)
+    th.start()
+    th.join(init_timeout_s)
+    ok = "comm" in box
+    why = box.get("err", "ncclCommInitRank did not return in %.0f s" % init_timeout_s) if not ok else ""
+    d = rendezvous_dir(tag)
+    tmp = os.path.join(d, f"transport_{rank}.tmp")
+    with open(tmp, "wb") as f:
+        f.write(b"1" if ok else b"0")
+    os.replace(tmp, os.path.join(d, f"transport_{rank}"))
+    votes, t0 = [], time.time()
+    for r in range(world):
+        while True:
+            try:
+                with open(os.path.join(d, f"transport_{r}"), "rb") as f:
+                    v = f.read()
+                if len(v) == 1:
+                    votes.append(v == b"1")
+                    break
+            except OSError:
+                pass
+            if time.time() - t0 > init_timeout_s + 60.0:
+                raise TimeoutError(f"rank {rank}: rank {r} never announced its transport")
+            time.sleep(0.01)
+    if all(votes):
+        return box["comm"], "RCCL (through the C ABI)"
+    failed = [r for r, v in enumerate(votes) if not v]
+    return FileComm(rank, world, tag), (f"files in TMPDIR (RCCL could not be brought up on rank(s) {failed}"
+                                        + (f": {why}" if why else "") + ")")
 
 
 def reduce_throughput(steps_done: float, elapsed_s: float, comm=None):

@@ -249,6 +249,64 @@ def make_e2e_case(name, seed, B, cfg_file, target_order, dev_gain_names, nullspa
     print(f"{name:28s} B={B:3d} (end-to-end sim state) -> {os.path.getsize(path) // 1024} KiB")
 
 
+def make_mutation_case(name, seed, B, cfg_file, target_order, dev_gain_names):
+    """Attributes of a LIVE Device changed between generate() calls on one OSC object, the way the reference's examples
+    do it: `ctrlr_dof_abg` switched off / on after construction (examples/ps_move_example.py:137-150: only calc_error's
+    angle block reacts, osc.py:113; the row mask `ctrlr_dof` was frozen in the constructor, device.py:34-36) and
+    `max_vel[0]` re-set before a tick (examples/insertion_task.py:294).  End-to-end format (RAW simulator arrays of one
+    state per instance) + per phase the targets and the reference's forces."""
+    rng = np.random.default_rng(seed)
+    cfg = load_cfg(cfg_file)
+    ee_bodies = ["ur_stand_dummy", "ur_EE_ur5right", "ur_EE_ur5left"]
+    OFF, ON = [False] * 3, [True] * 3
+    phases = [dict(), dict(abg={"ur5right": OFF}), dict(abg={"ur5left": OFF}), dict(abg={"ur5right": ON}),
+              dict(abg={"ur5left": ON}, max_vel0={"ur5left": 0.35}), dict(max_vel0={"ur5left": 2.5, "ur5right": 0.1})]
+    keys = ("qM", "qvel", "qfrc_bias", "sensordata", "jacp", "jacr", "xpos", "xquat", "xmat_right", "xmat_left",
+            "tgt_xyz", "tgt_quat", "forces_flat")
+    rec = {k: [] for k in keys}
+    meta = None
+    for b in range(B):
+        cfg = load_cfg(cfg_file)        # fresh per robot: Device keeps the YAML's max_vel LIST, which the phases below mutate
+        sim = fakesim.FakeSim()
+        fakesim.randomize(sim, rng)
+        robot, osc = build_reference(cfg, sim, dev_gain_names, True, True, False)
+        d = sim.data
+        bids = [sim.model.body_name2id(x) for x in ee_bodies]
+        rec["qM"].append(np.array(d.qM)); rec["qvel"].append(np.array(d.qvel))
+        rec["qfrc_bias"].append(np.array(d.qfrc_bias)); rec["sensordata"].append(np.array(d.sensordata))
+        rec["jacp"].append(d.body_jacp[bids]); rec["jacr"].append(d.body_jacr[bids])
+        rec["xpos"].append(d.body_xpos[bids]); rec["xquat"].append(d.body_xquat[bids])
+        rec["xmat_right"].append(d.site_xmat["ft_frame_ur5right"]); rec["xmat_left"].append(d.site_xmat["ft_frame_ur5left"])
+        txyz, tquat, forces_all = [], [], []
+        for ph in phases:
+            for dn, mask in ph.get("abg", {}).items():
+                robot.get_device(dn).ctrlr_dof_abg = list(mask)
+            for dn, v in ph.get("max_vel0", {}).items():
+                robot.get_device(dn).max_vel[0] = v
+            targets = {}
+            for dn in target_order:
+                dev = robot.get_device(dn)
+                t = RefTarget()
+                t.set_xyz(dev.get_state(RefDeviceState.EE_XYZ) + rng.normal(0.0, 0.2, 3))
+                t.set_abg(rng.uniform(-1.0, 1.0, 3))
+                targets[dn] = t
+            force_idxs, forces = osc.generate(targets)
+            txyz.append([targets[dn].get_xyz() for dn in target_order])
+            tquat.append([targets[dn].get_quat() for dn in target_order])
+            forces_all.append(np.concatenate(forces))
+        rec["tgt_xyz"].append(txyz); rec["tgt_quat"].append(tquat); rec["forces_flat"].append(forces_all)
+        if meta is None:
+            meta = dict(cfg_file=cfg_file, target_order=list(target_order), ee_bodies=ee_bodies,
+                        dev_gain_names=[list(x) for x in dev_gain_names], nullspace=True, use_g=True, admittance=False,
+                        n_free_bodies=0, seed=seed, phases=phases,
+                        force_idxs=[np.asarray(x).tolist() for x in force_idxs], force_lens=[len(f) for f in forces])
+    arrays = {k: np.asarray(v, dtype=np.float64) for k, v in rec.items()}
+    arrays["layout_json"] = np.array(json.dumps(meta))
+    path = os.path.join(OUT_DIR, f"{name}.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name:28s} B={B:3d} x {len(phases)} phases (live-device mutations) -> {os.path.getsize(path) // 1024} KiB")
+
+
 def make_loop_case(name, seed, ticks, kind, cfg_file, dev_gain_names, admittance=False, n_free_bodies=0,
                    push_window=(0, 0)):
     """Per-tick golden of a headless caller loop (harness rows): the REFERENCE's Device / Robot /
@@ -294,11 +352,17 @@ def insertion_wp_sequence():
     return cfg, [e for e in cfg["insertion_action_sequence"] if e["action"] == "WP"]
 
 
-def make_insertion_golden(name, seed, active_arm="right", objects="nist_action_objects", rate=0.08):
+def make_insertion_golden(name, seed, active_arm="right", objects="nist_action_objects", rate=0.08, with_grip=False,
+                          tick_seconds=0.04):
     """Per-tick golden of the action-sequence state machine: the REFERENCE's own
-    InsertionTask methods (set_waypoint_targets, go_to_waypoint, send_forces, initialize_action_objects, run_sequence;
-    examples/insertion_task.py:146-318) on a FakeSim with free joints and ToyDynamics.  The object is created without
-    its constructor (which loads MuJoCo and opens a viewer); everything it would have set up is supplied here."""
+    InsertionTask methods (set_waypoint_targets, go_to_waypoint, grip, send_forces, initialize_action_objects,
+    run_sequence; examples/insertion_task.py:146-318) on a FakeSim with free joints and ToyDynamics.  The object is
+    created without its constructor (which loads MuJoCo and opens a viewer); everything it would have set up is supplied
+    here.  with_grip: the whole action list, GRIP entries included.  The reference's `grip` (insertion_task.py:190-205)
+    loops `while self.timer_running` around a thread that sleeps for `gripper_duration` of WALL-CLOCK time; here the
+    thread is replaced by a tick budget -- start() raises timer_running, every rendered tick consumes one tick of
+    gripper_duration / tick_seconds, the last one lowers the flag -- so the reference's own loop body runs a stated,
+    reproducible number of ticks (what ActionSequenceRunner.grip does by construction)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("ref_insertion_task", "/root/reference/irl_control/examples/insertion_task.py")
     it_mod = importlib.util.module_from_spec(spec)
@@ -320,6 +384,19 @@ def make_insertion_golden(name, seed, active_arm="right", objects="nist_action_o
     it.targets = {it.active_arm.name: RefTarget(), it.passive_arm.name: RefTarget()}
     it.timer_running = False
     acfg, seq = insertion_wp_sequence()
+    budget = dict(left=0)
+    if with_grip:
+        seq = acfg["insertion_action_sequence"]
+
+        class TickBudgetThread:                                  # stands in for threading.Thread(target=self.sleep_for, args=(t,))
+            def __init__(self, target=None, args=()):
+                self.seconds = float(args[0])
+
+            def start(self):
+                assert it.timer_running is False                 # mujoco_app.py:38
+                budget["left"] = max(1, int(round(self.seconds / tick_seconds)))
+                it.timer_running = True
+        it_mod.threading = type("threading_stub", (), {"Thread": TickBudgetThread})
     it.action_objects = acfg[objects]
     it.initialize_action_objects()
     ee = {"ur5right": "ur_EE_ur5right", "ur5left": "ur_EE_ur5left"}
@@ -330,14 +407,19 @@ def make_insertion_golden(name, seed, active_arm="right", objects="nist_action_o
     def on_render():
         rec["ctrl"].append(np.array(sim.data.ctrl))
         rec["max_vel"].append(float(it.active_arm.max_vel[0]))
+        if it.timer_running:
+            budget["left"] -= 1
+            if budget["left"] <= 0:
+                it.timer_running = False
     it.viewer.on_render = on_render
     it.run_sequence(seq)
     meta = dict(seed=seed, active_arm=active_arm, objects=objects, rate=rate, free_joints=INSERTION_FREE_JOINTS,
-                n_wp=len(seq), ticks=len(rec["ctrl"]))
+                n_wp=len([e for e in seq if e["action"] == "WP"]), n_actions=len(seq), with_grip=bool(with_grip),
+                tick_seconds=tick_seconds, ticks=len(rec["ctrl"]))
     arrays = dict(ctrl=np.asarray(rec["ctrl"]), max_vel=np.asarray(rec["max_vel"]), layout_json=np.array(json.dumps(meta)))
     path = os.path.join(OUT_DIR, f"{name}.npz")
     np.savez_compressed(path, **arrays)
-    print(f"{name:28s} {len(seq)} WP actions, {len(rec['ctrl'])} ticks -> {os.path.getsize(path) // 1024} KiB")
+    print(f"{name:28s} {len(seq)} actions ({meta['n_wp']} WP), {len(rec['ctrl'])} ticks -> {os.path.getsize(path) // 1024} KiB")
 
 
 RLB = ("ur5right", "ur5left", "base")
@@ -347,6 +429,15 @@ G_ADMIT = [("ur5right", "osc2"), ("ur5left", "osc2")]
 
 if __name__ == "__main__":
     S = 20241008
+    # `--only a,b` re-mints just those fixtures (every fixture is a pure function of its arguments, so the full run gives
+    # the same arrays; this only spares rewriting the zip containers of the others)
+    if "--only" in sys.argv:
+        _only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
+
+        def _filtered(fn):
+            return lambda name, *a, **k: fn(name, *a, **k) if name in _only else None
+        make_case, make_e2e_case, make_loop_case = _filtered(make_case), _filtered(make_e2e_case), _filtered(make_loop_case)
+        make_insertion_golden, make_mutation_case = _filtered(make_insertion_golden), _filtered(make_mutation_case)
     # gain_test layout (examples/gain_test.py:27-36,124-128): arms xyz only, k = 7
     make_case("k7_gain_test", S + 1, 32, "default_xyz.yaml", RLB, G_GAIN, all_actuated=True)
     make_case("k7_real_actuators", S + 2, 8, "default_xyz.yaml", RLB, G_GAIN)
@@ -378,3 +469,7 @@ if __name__ == "__main__":
     make_insertion_golden("loop_insertion_wp", 0)
     make_case("k13_no_max_vel", S + 12, 8, "default_xyz_abg.yaml", RLB, G_GAIN, all_actuated=True,
               no_max_vel=("ur5left",))
+    # reference behaviours that only show when a live Device is changed between ticks (ps_move_example.py:137-150,
+    # insertion_task.py:294), and the GRIP actions of the insertion sequence on a stated tick budget
+    make_mutation_case("e2e_live_mutations", S + 23, 6, "default_xyz_abg.yaml", RLB, G_GAIN)
+    make_insertion_golden("loop_insertion_full", 0, with_grip=True, tick_seconds=0.04)

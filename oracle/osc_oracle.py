@@ -132,8 +132,11 @@ def generate(M, J_list: Sequence[np.ndarray], dq, bias, devs: List[Dict], null_k
     u_tasks = []
     for dv in devs:
         dof = np.asarray(dv["ctrlr_dof"], dtype=bool)
+        # calc_error reads the LIVE device.ctrlr_dof_xyz / ctrlr_dof_abg (osc.py:108,113), the row mask below is the
+        # device.ctrlr_dof frozen in Device.__init__ (device.py:36): they differ once a caller re-masks a live device
+        # (examples/ps_move_example.py:137-150); "calc_xyz" / "calc_abg" carry the live ones when they do
         u_task = calc_error(dv["ee_xyz"], dv["ee_quat"], dv["tgt_xyz"], dv["tgt_quat"],
-                            dof[:3], dof[3:])
+                            dv.get("calc_xyz", dof[:3]), dv.get("calc_abg", dof[3:]))
         stiffness = np.array(list(dv["k"]) + [1] * 3)
         damping = np.array(list(dv["d"]) + [1] * 3)
         kp, kv, ko = dv["kp"], dv["kv"], dv["ko"]
@@ -179,7 +182,8 @@ def generate_batch(layout: Dict, gains: Dict, M, J, dq, bias, ee_pose, tgt_pose,
     """Loop ``generate`` over a batch stored in the C-ABI layout.
 
     layout : dict(n, dev_rows[ndev], ctrlr_dof[ndev][6], joint_ids[ndev] (lists of positions),
-                  j_idx0[ndev] (first dx row used by branch B), use_g, admittance, nullspace)
+                  j_idx0[ndev] (first dx row used by branch B), use_g, admittance, nullspace
+                  [, calc_xyz[ndev], calc_abg[ndev]: the live masks calc_error reads, default from ctrlr_dof])
     gains  : dict(kp, kv, ko [ndev]; k, d [ndev,3]; max_vel [ndev,2]; has_max_vel [ndev];
                   null_kv) — each either broadcast or with a leading batch axis.
     M[B,n,n] J[B,k,n] dq[B,n] bias[B,n] ee_pose[B,ndev,7] tgt_pose[B,ndev,7] wrench[B,ndev,6]
@@ -210,6 +214,8 @@ def generate_batch(layout: Dict, gains: Dict, M, J, dq, bias, ee_pose, tgt_pose,
                 tgt_vel=np.zeros(6) if tgt_vel is None else tgt_vel[b, d],
                 wrench=np.zeros(6) if wrench is None else wrench[b, d],
                 ctrlr_dof=dof, joint_ids_all=layout["joint_ids"][d],
+                calc_xyz=(layout["calc_xyz"][d] if "calc_xyz" in layout else dof[:3]),
+                calc_abg=(layout["calc_abg"][d] if "calc_abg" in layout else dof[3:]),
                 J_idx=np.arange(layout["j_idx0"][d], layout["j_idx0"][d] + r),
                 max_vel=(g("max_vel", b, d) if layout.get("has_max_vel", [True] * ndev)[d] else None),
                 kp=float(g("kp", b, d)), kv=float(g("kv", b, d)), ko=float(g("ko", b, d)),

@@ -75,6 +75,27 @@ def app_from_e2e(g, b):
     return app, robot, osc, targets
 
 
+def live_mutation_phases(g, b):
+    """e2e_live_mutations fixture: build the build's own app on instance b, then yield (phase, app, robot, osc, targets)
+    with each phase's mutations applied to the LIVE devices first (ctrlr_dof_abg re-set as examples/ps_move_example.py:137-150
+    does, max_vel[0] as examples/insertion_task.py:294 does) -- one OSC object for all phases."""
+    import irl_control_amd as ic
+    meta = g["meta"]
+    g0 = dict(g, tgt_xyz=g["tgt_xyz"][:, 0], tgt_quat=g["tgt_quat"][:, 0])
+    app, robot, osc, _ = app_from_e2e(g0, b)
+    for p, ph in enumerate(meta["phases"]):
+        for dn, mask in ph.get("abg", {}).items():
+            robot.get_device(dn).ctrlr_dof_abg = list(mask)
+        for dn, v in ph.get("max_vel0", {}).items():
+            robot.get_device(dn).max_vel[0] = v
+        targets = {}
+        for i, dn in enumerate(meta["target_order"]):
+            t = ic.Target()
+            t.set_all_quat(g["tgt_xyz"][b, p, i], g["tgt_quat"][b, p, i])
+            targets[dn] = t
+        yield p, app, robot, osc, targets
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
     g = {k: z[k] for k in z.files if k != "layout_json"}

@@ -228,6 +228,24 @@ def test_osc_generate_end_to_end_vs_reference(name):
             app.sim.data.ctrl[i] = f
 
 
+def test_live_device_mutations_match_reference_phase_by_phase():
+    """ps_move_example.py:137-150 / insertion_task.py:294 on the HIP path: one OSC object, the devices' ctrlr_dof_abg and
+    max_vel[0] changed between generate() calls exactly as the reference run that minted the fixture changed them; the
+    layout is re-keyed (angle block of calc_error off, six rows kept), GPU contexts are reused when a masking recurs."""
+    from conftest import live_mutation_phases
+    g = load_e2e("e2e_live_mutations")
+    meta = g["meta"]
+    for b in range(g["qM"].shape[0]):
+        osc_obj = None
+        for p, app, robot, osc, targets in live_mutation_phases(g, b):
+            osc_obj = osc
+            idxs, forces = osc.generate(targets)
+            assert [list(map(int, i)) for i in idxs] == meta["force_idxs"]
+            flat, ref = np.concatenate(forces), g["forces_flat"][b, p]
+            assert np.max(np.abs(flat - ref)) / np.max(np.abs(ref)) <= TOL64, (b, p)
+        assert len(osc_obj._ctx) == 4 and len(osc_obj._layouts) == 4
+
+
 def test_linearity_in_bias_and_empty_batch():
     """Size-independent properties at the full 65 536-instance size: u is affine in bias with unit
     slope (osc.py:191), and sharding the batch does not change any instance's result."""
@@ -439,7 +457,7 @@ def test_row16_give_up_counters_do_not_go_stale_across_uneven_trains():
             osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
     for rep in range(3):
         osc.step_resident(12, first_slot=0)                      # 8 @ bank 0, 4 @ bank 1
-        osc.step_resident(8, first_slot=1 + rep)                 # 8 @ bank 0 again: step 7 runs slot (1 + rep + 7) % 3
+        osc.step_resident(8, first_slot=(1 + rep) % nslots)      # 8 @ bank 0 again: step 7 runs slot (1 + rep + 7) % 3
         u_train, f_train = osc.download(B)
         osc.step(slot=(1 + rep + 7) % nslots)
         u_one, f_one = osc.download(B)
@@ -728,6 +746,48 @@ def test_row16_ragged_batches_and_sharding_bit_exact(B):
     assert np.array_equal(ut, full[off:]) and np.array_equal(ft, ffull[off:])
 
 
+def _bench_line(extra_args, env_extra, launcher):
+    """Run bench.py in a child process, small and quick; -> (parsed JSON line, number of JSON lines on stdout)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["bench.py", "--steps", "16", "--warmup", "8", "--preroll", "0", "--batch", "2048", "--no-cpu-baseline",
+            "--no-secondary", "--no-from-q"] + extra_args
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(env_extra)
+    cmd = [sys.executable] + (launcher or []) + args
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return json.loads(lines[-1]), len(lines)
+
+
+def test_bench_two_ranks_self_launched_and_under_a_launcher():
+    """SURVEY 8e on the one GPU a test box has: `python bench.py --gpus 2` with no launcher environment starts its two
+    workers itself; under `python -m torch.distributed.run` it behaves as before.  Both ranks share device 0
+    (IRLOSC_BENCH_DEVICE), so RCCL refuses the duplicate device and every rank switches to the file reduction TOGETHER.
+    One JSON line, n_gpus = 2, two checksums, and rank 0's checksum is the one the 1-rank run gives (rank r's data
+    depend on r only: sharding changes no bit)."""
+    one, n1 = _bench_line(["--gpus", "1"], {}, None)
+    assert n1 == 1 and one["n_gpus"] == 1 and len(one["rank_checksums"]) == 1
+    own, n2 = _bench_line(["--gpus", "2"], {"IRLOSC_BENCH_DEVICE": "0"}, None)
+    assert n2 == 1 and own["n_gpus"] == 2 and len(own["rank_checksums"]) == 2
+    assert own["rank_checksums"][0] == one["rank_checksums"][0] and own["rank_checksums"][1] != own["rank_checksums"][0]
+    assert own["value"] > 0 and own["config"]["instances_per_gpu"] == 2048
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    tr, n3 = _bench_line(["--gpus", "2"], {"IRLOSC_BENCH_DEVICE": "0"},
+                         ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port)])
+    assert n3 == 1 and tr["n_gpus"] == 2 and tr["rank_checksums"] == own["rank_checksums"]
+    for line in (own, tr):
+        assert "RCCL" in line["config"]["sharding"] or "files" in line["config"]["sharding"]
+
+
 @pytest.mark.parametrize("lost", [1, 2, 3, 5])
 def test_row16_rank_deficient_jacobians(lost):
     """Exactly singular task Jacobians (duplicated rows: `lost` zero eigenvalues of J M^-1 J^T): the plain
@@ -1001,6 +1061,23 @@ def test_insertion_action_sequence_matches_reference_tick_by_tick():
     assert np.allclose(rec["max_vel"], g["max_vel"], rtol=1e-9, atol=0)
     err = np.abs(rec["ctrl"] - g["ctrl"]).max(axis=1) / np.abs(g["ctrl"]).max(axis=1)
     assert err.max() <= TOL64, float(err.max())
+
+
+def test_insertion_sequence_with_grip_actions_matches_reference_tick_by_tick():
+    """The WHOLE insertion action list, GRIP entries included (insertion_task.py:190-205).  The reference times a GRIP with a
+    wall-clock thread; the golden was minted with that thread replaced by a tick budget of gripper_duration / tick_seconds
+    ticks around the reference's own loop body (oracle/make_golden.py), which is what ActionSequenceRunner.grip runs."""
+    g, meta = _load_loop_golden("loop_insertion_full")
+    assert meta["with_grip"] and meta["n_actions"] == 12
+    mod = _load_example("insertion_task_headless")
+    rec = mod.run(seed=meta["seed"], active_arm=meta["active_arm"], objects=meta["objects"], rate=meta["rate"], verbose=False,
+                  with_grip=True, tick_seconds=meta["tick_seconds"])
+    assert rec["ticks"] == meta["ticks"] == len(g["ctrl"]) and rec["n_actions"] == meta["n_actions"]
+    assert np.allclose(rec["max_vel"], g["max_vel"], rtol=1e-9, atol=0)
+    err = np.abs(rec["ctrl"] - g["ctrl"]).max(axis=1) / np.abs(g["ctrl"]).max(axis=1)
+    assert err.max() <= TOL64, float(err.max())
+    grip = np.abs(g["ctrl"][:, 7] - (-0.08)) < 1e-15           # the first GRIP's gripper force is on the right gripper's actuator
+    assert grip.sum() >= 25
 
 
 def test_tick_latency_b1_is_bounded():

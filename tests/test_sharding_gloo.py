@@ -128,4 +128,54 @@ def test_filecomm_fallback_three_ranks(tmp_path, monkeypatch):
             assert res[r][it] == (10.0 * 6 + 3 * it, 0.5 + 2 + it)
         assert res[r][5] == [0xdeadbeef00000000 + k for k in range(world)]
     import os
-    assert len([f for f in os.listdir(tmp_path) if "_file_op" in f]) <= world     # only the last operation's files stay
+    import stat
+    from irl_control_amd import sharding
+    d = sharding.rendezvous_dir("t1")                      # TMPDIR is tmp_path here: the launch's private directory
+    assert os.path.dirname(d) == str(tmp_path) and stat.S_IMODE(os.lstat(d).st_mode) == 0o700
+    left = [f for f in os.listdir(d) if "_file_op" in f]
+    assert 0 < len(left) <= world                          # only the last operation's files stay
+
+
+def test_rendezvous_dir_refuses_a_planted_path(tmp_path, monkeypatch):
+    """A shared /tmp: somebody else's directory, a world-writable one, or a symlink under the expected name is refused."""
+    import os
+    from irl_control_amd import sharding
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    planted = tmp_path / f"irlosc_{os.getuid()}_bad"
+    planted.mkdir(mode=0o777)
+    os.chmod(planted, 0o777)
+    with pytest.raises(PermissionError):
+        sharding.rendezvous_dir("bad")
+    target = tmp_path / "elsewhere"
+    target.mkdir()
+    os.symlink(target, tmp_path / f"irlosc_{os.getuid()}_link")
+    with pytest.raises(PermissionError):
+        sharding.rendezvous_dir("link")
+    assert os.path.isdir(sharding.rendezvous_dir("fine"))
+
+
+
+def _make_comm_worker(rank, world, tag, q):
+    from irl_control_amd import sharding
+    comm, note = sharding.make_comm(rank, world, 0, tag=tag, init_timeout_s=60.0)
+    total, worst = comm.reduce(rank + 1.0, 0.25 * (rank + 1))
+    comm.close()
+    q.put((rank, type(comm).__name__, note, total, worst))
+
+
+def test_make_comm_agrees_on_the_file_transport_when_rccl_is_unavailable(tmp_path, monkeypatch):
+    """No GPU here, so RCCL cannot come up on any rank: every rank must land on FileComm (the choice is collective: a
+    job with mixed transports would hang) and the reduction must work through it."""
+    import multiprocessing as mp
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_make_comm_worker, args=(r, 2, "mc", q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert [r[1] for r in res] == ["FileComm", "FileComm"]
+    assert all("files in TMPDIR" in r[2] and "rank(s) [0, 1]" in r[2] for r in res)
+    assert all(r[3] == 3.0 and r[4] == 0.5 for r in res)
