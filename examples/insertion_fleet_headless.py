@@ -36,7 +36,7 @@ def random_objects(rng, lay, model, q0, cfg_objects):
         qg = q0.copy()
         qg[:, 1:7] += rng.uniform(-spread, spread, (B, 6))
         probe.upload_q(qg, np.zeros_like(qg)); probe.frontend()
-        poses[name] = probe.download_records()["ee_pose"][:, ia].copy()
+        poses[name] = probe.download_records(keys=("ee_pose",))["ee_pose"][:, ia].copy()
     probe.close()
     out = []
     for b in range(B):
@@ -80,7 +80,8 @@ def run(robots=32, max_ticks=12000, seed=0, dt=1e-3, wp_only=True, verbose=True,
     q, qd, objects = q[sel], qd[sel], [objects[i] for i in sel]
     osc = BatchedOSC(lay, len(sel), dtype=np.float64)
     osc.set_model(model)
-    runner = FleetActionSequenceRunner(osc, gains, objects, seq, active_arm="right", passive_hold_orientation=True)
+    runner = FleetActionSequenceRunner(osc, gains, objects, seq, active_arm="right", passive_hold_orientation=True,
+                                       integrator_records=("M", "bias"))      # what the toy physics below reads
     traj = []
     while not runner.done().all() and runner.ticks < max_ticks:
         u, rec = runner.tick(q, qd)
@@ -88,7 +89,7 @@ def run(robots=32, max_ticks=12000, seed=0, dt=1e-3, wp_only=True, verbose=True,
         qd = qd + dt * qacc
         q = q + dt * qd
         osc.upload_q(q, qd); osc.frontend()
-        runner.after_step(osc.download_records()["ee_pose"].astype(np.float64))
+        runner.after_step(osc.download_records(keys=("ee_pose",))["ee_pose"].astype(np.float64))
         traj.append(u.copy())
     osc.close()
     if verbose:

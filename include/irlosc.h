@@ -30,8 +30,11 @@
  *   flags[B]        uint32 status bits per instance (IRLOSC_FLAG_*)
  *
  * Contracts the kernels rely on (not checked on the device):
- *   - M is symmetric: the throughput kernels read row j of M as its column j (the generic kernel uses M as given);
- *     irl_control_amd.BatchedOSC.upload(check_symmetric=True) / OSC.generate check it on the host;
+ *   - M is symmetric: the throughput kernels read row j of M as its column j (the generic kernel uses M as given, like
+ *     osc.py:49,151).  Records that come from the HOST are probed on the device: irlosc_upload and irlosc_tick return
+ *     IRLOSC_ERR_ARG when an instance has max |M - M^T| > 1e-6 max |M| and the context runs a throughput kernel.  Records
+ *     assembled on the device (irlosc_upload_raw / irlosc_assemble_device / irlosc_frontend) are symmetric by
+ *     construction; for irlosc_step_device it stays the caller's contract;
  *   - device pointers handed to irlosc_step_device / irlosc_assemble_device are 16-byte aligned;
  *   - a context is driven from ONE stream at a time: its train tables, worklists and pending stage-2 work are ordered
  *     by stream order only, so a caller stream passed to the *_device entry points must not run concurrently with the
@@ -122,7 +125,8 @@ const char* irlosc_frontend_name(const irlosc_ctx* ctx); /* name of the kernel i
  * every instance (kept in constant/SGPR space), nb == max_batch gives per-instance gains. */
 int irlosc_set_gains(irlosc_ctx* ctx, const double* gains, const double* null_kv, int32_t nb);
 
-/* Host -> device copy of one batch of robot state into resident slot `slot`.  wrench may be NULL. */
+/* Host -> device copy of one batch of robot state into resident slot `slot`.  wrench may be NULL.  On the throughput paths
+ * an asymmetric M is refused (IRLOSC_ERR_ARG, the slot then holds nothing): see the contracts block above. */
 int irlosc_upload(irlosc_ctx* ctx, int32_t slot, int32_t B, const void* M, const void* J,
                   const void* dq, const void* bias, const void* ee_pose, const void* wrench);
 /* Host -> device copy of the targets for slot `slot`.  tgt_vel may be NULL (all zero). */
@@ -235,7 +239,9 @@ int irlosc_set_model(irlosc_ctx* ctx, const irlosc_model* model);
 /* Joint positions and velocities of one batch into resident slot `slot`: qpos[B][n], qvel[B][n], always double. */
 int irlosc_upload_q(irlosc_ctx* ctx, int32_t slot, int32_t B, const double* qpos, const double* qvel);
 /* Run the front end on the slot's (qpos, qvel): fills its M, J, dq, bias, ee_pose records (asynchronous, context's
- * stream); irlosc_set_targets + irlosc_step then work as after irlosc_upload. */
+ * stream); irlosc_set_targets + irlosc_step then work as after irlosc_upload.  Afterwards the slot holds the records of
+ * exactly B robots (an earlier, larger upload no longer vouches for the instances beyond B); the wrench of the slot stays what
+ * the last irlosc_upload / irlosc_upload_raw wrote (undefined for instances beyond THAT call's B). */
 int irlosc_frontend(irlosc_ctx* ctx, int32_t slot, int32_t B);
 /* Copy records of slot `slot` back to the host (any pointer may be NULL): what irlosc_upload put there, or what the front
  * end / irlosc_upload_raw assembled on the GPU.  Same layouts and element type as irlosc_upload. */

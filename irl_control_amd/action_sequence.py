@@ -186,8 +186,11 @@ class FleetActionSequenceRunner:
     (tests/test_gpu_parity.py::test_fleet_action_sequence_lockstep_equals_solo_runs)."""
 
     def __init__(self, osc, base_gains: Dict, objects: List[Dict], sequence: List[Dict], active_arm: str = "right",
-                 tick_seconds: float = 0.001, passive_hold_orientation: bool = False):
+                 tick_seconds: float = 0.001, passive_hold_orientation: bool = False, integrator_records=()):
         self.osc, self.lay = osc, osc.layout
+        # records tick() hands back besides the EE poses it needs itself: a host-side integrator names what IT reads (e.g.
+        # ("M", "bias")); by default only the 168 B of EE poses per robot cross PCIe per tick, not the 8.5 KB of records
+        self.records = ("ee_pose",) + tuple(k for k in integrator_records if k != "ee_pose")
         # the reference sends the passive arm to DEFAULT_EE_QUAT at every waypoint (insertion_task.py:213), which suits the
         # start pose of its scene; with arbitrary start poses holding the current orientation keeps that arm where it is
         self.passive_hold_orientation = passive_hold_orientation
@@ -240,11 +243,11 @@ class FleetActionSequenceRunner:
         return self.action >= len(self.seq)
 
     def tick(self, q, qd):
-        """One control tick for the fleet: returns (u[B,n], records) for the integrator."""
+        """One control tick for the fleet: returns (u[B,n], records) for the integrator (records: `integrator_records`)."""
         osc = self.osc
         osc.upload_q(q, qd)
         osc.frontend()
-        rec = osc.download_records()
+        rec = osc.download_records(keys=self.records)
         ee = rec["ee_pose"].astype(np.float64)
         if self.tgt is None:
             self.tgt = ee.copy()

@@ -87,6 +87,8 @@ class BatchedOSC:
         self._gains_sent = (g.copy(), nk.copy(), nb)
 
     def upload(self, M, J, dq, bias, ee_pose, wrench=None, slot: int = 0, check_symmetric: bool = False):
+        """Records of B robots into resident slot `slot`.  On the throughput kernels the library itself refuses an asymmetric M
+        (device-side probe, IrloscError); check_symmetric=True additionally checks on the host before anything is copied."""
         L = self.layout
         B = int(np.shape(M)[0])
         M = self._arr(M, (B, L.n, L.n), "M")
@@ -183,12 +185,13 @@ class BatchedOSC:
         """(qpos, qvel) of the slot -> its M, J, dq, bias, ee_pose records (on the GPU)."""
         self._chk(self.lib.irlosc_frontend(self._h, slot, self._B[slot]))
 
-    def download_records(self, slot: int = 0):
-        """-> dict(M, J, dq, bias, ee_pose) of the slot as it sits in HBM (uploaded, or assembled by the front end)."""
+    def download_records(self, slot: int = 0, keys=("M", "J", "dq", "bias", "ee_pose")):
+        """-> dict of the slot's records as they sit in HBM (uploaded, or assembled by the front end); `keys` picks which
+        ones cross PCIe (a per-tick caller that only needs the EE poses asks for ("ee_pose",): 168 B instead of 8.5 KB per robot)."""
         L, B = self.layout, self._B[slot]
-        out = dict(M=np.empty((B, L.n, L.n), self.dtype), J=np.empty((B, L.k, L.n), self.dtype), dq=np.empty((B, L.n), self.dtype),
-                   bias=np.empty((B, L.n), self.dtype), ee_pose=np.empty((B, L.ndev, 7), self.dtype))
-        self._chk(self.lib.irlosc_download_records(self._h, slot, B, *[_lib.ptr(out[k]) for k in ("M", "J", "dq", "bias", "ee_pose")]))
+        shapes = dict(M=(B, L.n, L.n), J=(B, L.k, L.n), dq=(B, L.n), bias=(B, L.n), ee_pose=(B, L.ndev, 7))
+        out = {k: np.empty(shapes[k], self.dtype) for k in keys}
+        self._chk(self.lib.irlosc_download_records(self._h, slot, B, *[_lib.ptr(out.get(k)) for k in ("M", "J", "dq", "bias", "ee_pose")]))
         return out
 
     def step_from_q(self, qpos, qvel, tgt_pose, tgt_vel=None, return_flags: bool = False):

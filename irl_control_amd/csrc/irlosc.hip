@@ -78,6 +78,7 @@ struct irlosc_ctx {
     // irlosc_tick: one pinned host block and one device block per direction, grown on demand
     void* tick_hin = nullptr; void* tick_din = nullptr; size_t tick_in_bytes = 0;
     void* tick_hout = nullptr; void* tick_dout = nullptr; size_t tick_out_bytes = 0;
+    int32_t* dsym = nullptr;  // symmetry probe of the throughput paths: {count, first instance}
     void* dgains = nullptr;   // [nb][ndev][12] in dtype
     void* dnullkv = nullptr;  // [nb]
     int gains_nb = 0;
@@ -182,6 +183,7 @@ static void free_all(irlosc_ctx* c) {
     if (c->dzeros) (void)hipFree(c->dzeros);
     for (int k = 0; k < R16_TRAIN; ++k) if (c->dr16_list[k]) (void)hipFree(c->dr16_list[k]);
     if (c->dr16_count) (void)hipFree(c->dr16_count);
+    if (c->dsym) (void)hipFree(c->dsym);
     if (c->dgains) (void)hipFree(c->dgains);
     if (c->dnullkv) (void)hipFree(c->dnullkv);
     if (c->ddbg) (void)hipFree(c->ddbg);
@@ -250,6 +252,7 @@ static int create_impl(irlosc_ctx* c) {
     }
     c->du = c->du_set[0];
     c->dflags = c->dflags_set[0];
+    HIPCHK(nullptr, hipMalloc((void**)&c->dsym, 2 * sizeof(int32_t)));
     HIPCHK(nullptr, hipMalloc(&c->dgains, B * nd * IRLOSC_GAIN_WORDS * e));
     HIPCHK(nullptr, hipMalloc(&c->dnullkv, B * e));
     if (c->kernel != IRLOSC_KERNEL_GENERIC && getenv("IRLOSC_PHASE_TIMING"))     // debug aid: cycles per kernel phase
@@ -355,6 +358,30 @@ static int check_slot(irlosc_ctx* c, int slot, int B) {
     return IRLOSC_OK;
 }
 
+// The throughput kernels read row j of M as its column j (include/irlosc.h, contracts): an asymmetric M would give a wrong
+// answer without any flag, so records that come from the HOST are probed on the device before they are accepted (the
+// generic kernel uses M as given, like osc.py:49,151, and takes anything).  Enqueues the probe; symmetry_verdict reads it.
+static int symmetry_probe(irlosc_ctx* c, const void* dM, int B, hipStream_t st) {
+    if (c->kernel == IRLOSC_KERNEL_GENERIC) return IRLOSC_OK;
+    static const int32_t init[2] = {0, 0x7fffffff};
+    HIPCHK(c, hipMemcpyAsync(c->dsym, init, sizeof init, hipMemcpyHostToDevice, st));
+    const int rc = c->cfg.dtype == IRLOSC_F64 ? launch_symmetry_probe<double>((const double*)dM, c->cfg.n, B, c->dsym, st)
+                                              : launch_symmetry_probe<float>((const float*)dM, c->cfg.n, B, c->dsym, st);
+    HIPCHK(c, (hipError_t)rc);
+    return IRLOSC_OK;
+}
+static int symmetry_verdict(irlosc_ctx* c, hipStream_t st) {       // the stream must have been synchronised after the probe
+    if (c->kernel == IRLOSC_KERNEL_GENERIC) return IRLOSC_OK;
+    int32_t res[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(res, c->dsym, sizeof res, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (res[0] > 0)
+        return fail(c, IRLOSC_ERR_ARG, "M of instance %d is not symmetric (%d instance(s) with max |M - M^T| > 1e-6 max |M|): the %s "
+                    "kernel reads rows of M as columns; use IRLOSC_KERNEL_GENERIC for a non-symmetric M", res[1], res[0],
+                    c->kernel_name.c_str());
+    return IRLOSC_OK;
+}
+
 extern "C" int irlosc_upload(irlosc_ctx* c, int32_t slot, int32_t B, const void* M, const void* J, const void* dq,
                              const void* bias, const void* ee_pose, const void* wrench) {
     if (!c) return IRLOSC_ERR_ARG;
@@ -372,7 +399,10 @@ extern "C" int irlosc_upload(irlosc_ctx* c, int32_t slot, int32_t B, const void*
     HIPCHK(c, hipMemcpyAsync(c->dee[slot], ee_pose, b * nd * 7 * e, hipMemcpyHostToDevice, c->stream));
     if (wrench) HIPCHK(c, hipMemcpyAsync(c->dwrench[slot], wrench, b * nd * 6 * e, hipMemcpyHostToDevice, c->stream));
     c->has_wrench[slot] = wrench != nullptr;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->uploaded[slot] = 0;                              // nothing usable in the slot until the records are accepted
+    int rcs = symmetry_probe(c, c->dM[slot], B, c->stream);
+    if (!rcs) rcs = symmetry_verdict(c, c->stream);
+    if (rcs) return rcs;
     c->uploaded[slot] = B;
     return IRLOSC_OK;
 }
@@ -1117,13 +1147,16 @@ extern "C" int irlosc_tick(irlosc_ctx* c, int32_t B, const void* M, const void* 
     unsigned char* din = (unsigned char*)c->tick_din;
     for (int i = 0; i < 8; ++i) if (sz[i]) memcpy(hin + off[i], src[i], sz[i]);
     HIPCHK(c, hipMemcpyAsync(din, hin, total, hipMemcpyHostToDevice, c->stream));
+    int rcs = symmetry_probe(c, din + off[0], B, c->stream);
+    if (rcs) return rcs;
     unsigned char* dout = (unsigned char*)c->tick_dout;
     uint32_t* dfl = (uint32_t*)(dout + ((ub + 255) & ~(size_t)255));
     int rc = launch(c, B, din + off[0], din + off[1], din + off[2], sz[3] ? din + off[3] : nullptr, din + off[4], din + off[5],
                     sz[7] ? din + off[7] : nullptr, sz[6] ? din + off[6] : nullptr, dout, dfl, c->stream);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->tick_hout, dout, out_total, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rcs = symmetry_verdict(c, c->stream);               // synchronises the stream; nothing is handed out for an asymmetric M
+    if (rcs) return rcs;
     memcpy(u_host, c->tick_hout, ub);
     if (flags_host) memcpy(flags_host, (unsigned char*)c->tick_hout + ((ub + 255) & ~(size_t)255), b * sizeof(uint32_t));
     return IRLOSC_OK;

@@ -40,5 +40,8 @@ struct RawDesc;
 template <typename T> struct RawPtrs;
 template <typename T>
 int launch_assemble(const RawDesc& d, const RawPtrs<T>& r, int B, hipStream_t st);
+// out[0] += instances whose M is not symmetric, out[1] = min(out[1], first such instance)
+template <typename T>
+int launch_symmetry_probe(const T* M, int n, int B, int32_t* out, hipStream_t st);
 
 }  // namespace irlosc

@@ -27,7 +27,15 @@ class MujocoApp():
         with open(cfg_path, 'r') as f:
             self.config = yaml.safe_load(f)
         if sim is None:
+            if scene_file is None:
+                raise ValueError("MujocoApp needs either sim= (an MjSim-like object) or scene_file=")
             scene = scene_file if os.path.isabs(scene_file) else os.path.join(_PKG_DIR, "scenes", scene_file)
+            if not os.path.exists(scene):
+                # the reference resolves a relative scene against its own scenes/ directory (mujoco_app.py:14-16); this package
+                # ships no MJCF scenes or meshes (out of scope), so a relative name cannot be found here
+                raise FileNotFoundError(
+                    f"scene file {scene!r} not found: irl_control_amd ships no scenes/ directory -- pass an absolute path to an MJCF "
+                    f"file (e.g. <irl_control checkout>/irl_control/scenes/{os.path.basename(scene_file)}) or inject sim=")
             try:
                 import mujoco  # noqa: F401
                 from .mujoco_backend import MujocoSim

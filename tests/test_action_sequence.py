@@ -80,7 +80,9 @@ class _StubBatched:
 
     def upload_q(self, q, qd): pass
     def frontend(self): pass
-    def download_records(self): return dict(ee_pose=self.ee.copy())
+    def download_records(self, keys=("ee_pose",)):
+        assert tuple(keys) == ("ee_pose",)          # the runner itself needs nothing else across PCIe
+        return dict(ee_pose=self.ee.copy())
     def set_gains(self, *a): self.gains = a
     def set_targets(self, t): self.targets = np.array(t)
     def step(self): return np.zeros((self.B, self.layout.n))

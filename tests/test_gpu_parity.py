@@ -1036,6 +1036,36 @@ def test_step_refuses_more_instances_than_the_slot_holds():
     osc.close()
 
 
+@pytest.mark.parametrize("dtype,kernel", [(np.float64, _lib.KERNEL_AUTO), (np.float32, _lib.KERNEL_ROW16), (np.float32, _lib.KERNEL_AUTO)])
+def test_library_refuses_an_asymmetric_M_on_the_throughput_paths(dtype, kernel):
+    """The throughput kernels read row j of M as column j; the reference uses M as given (osc.py:49,151).  Records that
+    come from the host are probed ON THE DEVICE (irlosc_upload, irlosc_tick): an asymmetric M is IRLOSC_ERR_ARG naming the
+    instance, the slot then holds nothing, and the generic kernel still takes such an M as it is."""
+    B = 300
+    lay, gains, g = synth.make_batch("k13", B, seed=4, dtype=dtype)
+    osc = BatchedOSC(lay, B, dtype=dtype, kernel=kernel)
+    assert "generic" not in osc.kernel_name
+    osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+    osc.upload(g["M"], g["J"], g["dq"], g["bias"], g["ee_pose"])                     # symmetric: accepted
+    Masym = g["M"].copy()
+    Masym[257, 3, 7] *= 1.01
+    Masym[123, 20, 2] += 0.5
+    with pytest.raises(_lib.IrloscError, match=r"M of instance 123 is not symmetric \(2 instance"):
+        osc.upload(Masym, g["J"], g["dq"], g["bias"], g["ee_pose"])
+    osc.set_targets(g["tgt_pose"])
+    with pytest.raises(_lib.IrloscError, match="must precede a step"):                 # the refused upload left the slot empty
+        osc.step()
+    with pytest.raises(_lib.IrloscError, match="M of instance 123 is not symmetric"):
+        osc.tick(Masym, g["J"], g["dq"], g["bias"], g["ee_pose"], g["tgt_pose"])
+    u = osc.tick(g["M"], g["J"], g["dq"], g["bias"], g["ee_pose"], g["tgt_pose"])      # and the context is still usable
+    assert np.all(np.isfinite(u))
+    osc.close()
+    gen = BatchedOSC(lay, B, dtype=dtype, kernel=_lib.KERNEL_GENERIC)
+    gen.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+    gen.upload(Masym, g["J"], g["dq"], g["bias"], g["ee_pose"])                        # M as given, like the reference
+    gen.close()
+
+
 def test_force_test_loop_matches_reference_tick_by_tick():
     """examples/force_test.py:57-127 headless (osc1 gains, admittance, left arm along a line of waypoints at 1 cm,
     F/T force read back after every step): forces of all 240 ticks, the waypoint indices and the logged sensor force."""

@@ -171,3 +171,14 @@ def test_live_device_mutations_oracle_and_layout_keying():
             worst = max(worst, np.max(np.abs(flat - ref)) / np.max(np.abs(ref)))
         assert len(layouts) == 4          # both on / right off / both off / left off: re-keyed, and reused when masks recur
     assert worst <= 1e-9, worst
+
+
+def test_mujoco_app_says_why_a_relative_scene_cannot_be_found():
+    """The reference joins a relative scene_file with its own scenes/ directory (mujoco_app.py:14-16); this package ships no
+    scenes, so the error must say so instead of surfacing as a loader failure deep inside a simulator binding."""
+    import pytest
+    import irl_control_amd as ic
+    with pytest.raises(FileNotFoundError, match="ships no scenes/ directory"):
+        ic.MujocoApp("default_xyz_abg.yaml", "gain_test_scene.xml")
+    with pytest.raises(ValueError, match="sim=.*or scene_file="):
+        ic.MujocoApp("default_xyz_abg.yaml", None)
