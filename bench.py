@@ -300,18 +300,17 @@ def measure_from_q(BatchedOSC, synth, args, B, local_rank, state0=None, ref_u=No
         flops = FLOPS_FRONT_END + FLOPS_OSC_STEP.get(args.layout, FLOPS_OSC_STEP["k13"])
         achieved = flops * B / (ms_step * 1e-3) / 1e12
         res = dict(value=B * steps / el, unit="steps/s", ms_per_step=el / steps * 1e3, ms_per_step_events=ms_step,
-                   ms_osc_step_alone=ms_osc, ms_front_end=ms_step - ms_osc, kernel=osc.frontend_name + " + " + osc.kernel_name,
+                   ms_osc_step_on_records_alone=ms_osc, kernel=osc.from_q_name,
                    input_bytes_per_step_per_instance=2 * lay.n * 8 + 7 * lay.ndev * esz,
                    roofline=dict(bound="fp64_valu", achieved=achieved, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
                                  frac=achieved / FP64_VALU_PEAK_TFLOPS, flops_per_step_per_instance=flops,
                                  note="useful fp64 flops (FMA = 2) of front end + OSC step, DESIGN.md section 5; HBM sees "
                                       "568 B in and 200 B out per robot, so the HBM roof is not the bound of this path"),
-                   note="per step: rigid-body front end (FK, EE Jacobians, CRBA, RNEA) from resident (qpos, qvel), then the OSC "
-                        "step; nothing crosses PCIe")
+                   note="per step: rigid-body front end (FK, EE Jacobians, CRBA, RNEA) from resident (qpos, qvel) and the OSC step on "
+                        "what it leaves behind (fused path: a compact exchange buffer of the structural non-zeros, 2.5 KB per robot, "
+                        "instead of 8.5 KB of dense records); nothing crosses PCIe")
         if ref_u is not None:                          # front end + step on slot 0 against the chained oracles
-            osc.frontend(slot=0)
-            osc.step(slot=0)
-            u, _ = osc.download(B)
+            u = osc.step_q(slot=0)
             res["parity_sample"] = _parity_plain(u, ref_u, 1e-5,
                                                  "GPU front end + OSC step vs oracle/rigid_body.py -> oracle/osc_oracle.py chained "
                                                  "on the same (qpos, qvel, targets) of the first robots of slot 0")

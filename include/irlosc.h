@@ -247,8 +247,19 @@ int irlosc_frontend(irlosc_ctx* ctx, int32_t slot, int32_t B);
  * end / irlosc_upload_raw assembled on the GPU.  Same layouts and element type as irlosc_upload. */
 int irlosc_download_records(irlosc_ctx* ctx, int32_t slot, int32_t B, void* M, void* J, void* dq, void* bias,
                             void* ee_pose);
-/* Benchmark form of the whole path from joint coordinates: `iters` x (front end + step) on resident (qpos, qvel),
- * slot = (first_slot + i) % n_slots; HIP-event time of the region on the library's stream. */
+/* One control step from joint coordinates: irlosc_upload_q + irlosc_set_targets, then this (results as after irlosc_step).
+ * With the compiled Dual-UR5 tree shape and the fp64 row16 kernel this is the FUSED path: the lane-per-robot walk leaves only
+ * the structural non-zeros of M and J, the bias forces and the EE poses in a compact exchange buffer (2.4 KB per robot,
+ * written once, coalesced) and the OSC kernel gathers its operands from there -- the dense records of the slot are neither
+ * written nor read (robots the in-kernel eigen stage hands to the generic kernel get theirs from the wave-per-robot front end;
+ * their entries of the slot's records are overwritten).  Other models / kernels: irlosc_frontend + irlosc_step.
+ * set_model allocates one exchange buffer per step of a train for it: 8 x ceil(max_batch / 64) x 318 x 512 bytes. */
+int irlosc_step_from_q(irlosc_ctx* ctx, int32_t slot, int32_t B, void* u_host, uint32_t* flags_host);
+/* What irlosc_step_from_q / irlosc_step_resident_from_q launch ("" before irlosc_set_model). */
+const char* irlosc_from_q_name(const irlosc_ctx* ctx);
+/* Benchmark form of the whole path from joint coordinates: `iters` steps like irlosc_step_from_q on resident (qpos, qvel),
+ * chained into trains on the fused path, slot = (first_slot + i) % n_slots; HIP-event time of the region on the library's
+ * stream. */
 int irlosc_step_resident_from_q(irlosc_ctx* ctx, int32_t first_slot, int32_t B, int32_t iters, float* ms_total,
                                 float* ms_step_avg);
 

@@ -194,12 +194,25 @@ class BatchedOSC:
         self._chk(self.lib.irlosc_download_records(self._h, slot, B, *[_lib.ptr(out.get(k)) for k in ("M", "J", "dq", "bias", "ee_pose")]))
         return out
 
+    @property
+    def from_q_name(self) -> str:
+        """What step_from_q / step_resident_from_q launch: the fused pair (compact exchange buffer, no dense M / J) when the
+        model has the compiled Dual-UR5 shape and the context runs the fp64 row16 kernel, else front end + step."""
+        return self.lib.irlosc_from_q_name(self._h).decode()
+
+    def step_q(self, slot: int = 0, return_flags: bool = False):
+        """One step from the slot's resident (qpos, qvel) and targets (irlosc_step_from_q)."""
+        B = self._B[slot]
+        u = np.empty((B, self.layout.n), dtype=self.dtype)
+        fl = np.empty(B, dtype=np.uint32)
+        self._chk(self.lib.irlosc_step_from_q(self._h, slot, B, _lib.ptr(u), _lib.ptr(fl)))
+        return (u, fl) if return_flags else u
+
     def step_from_q(self, qpos, qvel, tgt_pose, tgt_vel=None, return_flags: bool = False):
-        """One tick from joint coordinates: upload (qpos, qvel), front end, step, download."""
+        """One tick from joint coordinates: upload (qpos, qvel) and the targets, one step from them, download."""
         self.upload_q(qpos, qvel)
-        self.frontend()
         self.set_targets(tgt_pose, tgt_vel)
-        return self.step(return_flags=return_flags)
+        return self.step_q(return_flags=return_flags)
 
     def step_resident_from_q(self, iters: int, first_slot: int = 0, B: Optional[int] = None):
         """-> (ms_total, ms_per_step): `iters` x (front end + step) on resident joint coordinates, HIP-event timed."""

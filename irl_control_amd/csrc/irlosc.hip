@@ -23,6 +23,7 @@
 #include "launchers.hpp"
 
 using namespace irlosc;
+static_assert(FE_TRAIN == R16_TRAIN, "the walk and the OSC kernel chain the same number of steps per launch");
 
 static thread_local std::string g_create_error;
 
@@ -73,6 +74,13 @@ struct irlosc_ctx {
     size_t fe_smem = 0;
     int fe_lane = 0;                  // 1: the model has the compiled Dual-UR5 shape -> lane-per-instance front end
     double* fe_side = nullptr;        // side buffer of the lane kernel: [wave][entry][64]
+    // fused path (irlosc_step_from_q / irlosc_step_resident_from_q on the row16 kernel): entry tables of the compact exchange
+    // buffer and one buffer per step of a train
+    FeCompactTables* dtables = nullptr;
+    size_t fe_xentries = 0;
+    double* fe_xside[R16_TRAIN] = {};
+    int fused = 0;
+    int fused_xcd_map = 1;
     std::vector<double*> dqpos, dqvel;
     std::vector<int> has_q;
     // irlosc_tick: one pinned host block and one device block per direction, grown on demand
@@ -174,6 +182,8 @@ static void free_all(irlosc_ctx* c) {
     if (c->draw) (void)hipFree(c->draw);
     if (c->dmodel) (void)hipFree(c->dmodel);
     if (c->fe_side) (void)hipFree(c->fe_side);
+    if (c->dtables) (void)hipFree(c->dtables);
+    for (int k = 0; k < R16_TRAIN; ++k) if (c->fe_xside[k]) (void)hipFree(c->fe_xside[k]);
     for (double* p : c->dqpos) if (p) (void)hipFree(p);
     for (double* p : c->dqvel) if (p) (void)hipFree(p);
     if (c->tick_hin) (void)hipHostFree(c->tick_hin);
@@ -655,7 +665,7 @@ static int row16_train(irlosc_ctx* c, const KParams<T>* ps, int n, hipStream_t s
     c->r16_parity ^= 1;
     for (int i = 0; i < n; ++i) {
         tr.p[i] = ps[i];
-        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[i], bank + i};
+        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[i], bank + i, nullptr, nullptr, nullptr, 0};
     }
     if (c->tev_begin) HIPCHK(c, hipEventRecord(c->tev_begin, st));
     int rc = launch_row16<T>(tr, n, st);
@@ -999,6 +1009,25 @@ extern "C" int irlosc_set_model(irlosc_ctx* c, const irlosc_model* m) {
         const size_t waves = ((size_t)c->cfg.max_batch + 63) / 64;
         HIPCHK(c, hipMalloc((void**)&c->fe_side, waves * frontend_lane_dual_ur5_side_doubles_per_wave() * sizeof(double)));
     }
+    {   // The fused path needs the compiled tree shape (lane kernel) and the fp64 row16 kernel; IRLOSC_FUSED=0 forces the
+        // two-kernel path through dense records (A/B measurements).
+        const char* e = getenv("IRLOSC_FUSED");
+        c->fused = c->fe_lane && c->kernel == IRLOSC_KERNEL_ROW16 && !(e && !strcmp(e, "0"));
+        const char* m = getenv("IRLOSC_FROMQ_MAP");        // "0": identity block map (A/B measurements)
+        c->fused_xcd_map = !(m && !strcmp(m, "0"));
+    }
+    if (c->fused) {
+        FeCompactTables t;
+        memset(&t, 0, sizeof t);
+        frontend_lane_dual_ur5_tables(h, &t);
+        c->fe_xentries = t.n_entries;
+        if (!c->dtables) HIPCHK(c, hipMalloc((void**)&c->dtables, sizeof t));
+        HIPCHK(c, hipMemcpyAsync(c->dtables, &t, sizeof t, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));      // t lives on this stack frame
+        const size_t waves = ((size_t)c->cfg.max_batch + 63) / 64;
+        for (int k2 = 0; k2 < R16_TRAIN; ++k2)
+            if (!c->fe_xside[k2]) HIPCHK(c, hipMalloc((void**)&c->fe_xside[k2], waves * c->fe_xentries * 64 * sizeof(double)));
+    }
     HIPCHK(c, hipMemcpyAsync(c->dmodel, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->dqpos.empty()) {
@@ -1077,6 +1106,104 @@ extern "C" int irlosc_download_records(irlosc_ctx* c, int32_t slot, int32_t B, v
     return IRLOSC_OK;
 }
 
+// A step from joint coordinates over B robots needs B robots of (qpos, qvel) AND of targets in the slot.
+static int check_slot_q(irlosc_ctx* c, int slot, int B) {
+    if (!c->dmodel) return fail(c, IRLOSC_ERR_STATE, "irlosc_set_model has not been called");
+    if (!c->has_q[slot] || !c->targeted[slot])
+        return fail(c, IRLOSC_ERR_STATE, "slot %d: irlosc_upload_q and irlosc_set_targets must precede a step from joint coordinates", slot);
+    if (B > std::max(0, c->has_q[slot]) || B > std::max(0, c->targeted[slot]))
+        return fail(c, IRLOSC_ERR_STATE, "slot %d holds joint coordinates of %d and targets for %d instances, step asked for %d", slot,
+                    std::max(0, c->has_q[slot]), std::max(0, c->targeted[slot]), B);
+    return IRLOSC_OK;
+}
+
+// Fused path: one train of n steps from joint coordinates (step i: slot slots[i], outputs of set i).  Two launches -- the
+// lane-per-robot walk leaves the structural non-zeros of M / J, the bias forces and the EE poses in the compact exchange
+// buffer of each step; the row16 kernel (FROMQ) gathers its operands from there -- and the give-up pass: the few robots the
+// eigen stage hands over get their dense records from the wave-per-robot front end (worklist form) and go through the
+// generic kernel like on the record path.  Dense M / J exist in HBM for those robots only.
+template <typename T>
+static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, hipStream_t st) {
+    if (n < 1 || n > R16_TRAIN) return fail(c, IRLOSC_ERR_STATE, "train of %d steps", n);
+    FeLaneTrain ft;
+    memset(&ft, 0, sizeof ft);
+    Row16Train<T> tr;
+    memset(&tr, 0, sizeof tr);
+    FeGenericArgs<T> ga;
+    memset(&ga, 0, sizeof ga);
+    int32_t* bank = c->dr16_count + c->r16_parity * R16_TRAIN;
+    int32_t* other = c->dr16_count + (c->r16_parity ^ 1) * R16_TRAIN;
+    c->r16_parity ^= 1;
+    ft.B = ga.B = B;
+    for (int i = 0; i < n; ++i) {
+        const int sl = slots[i];
+        ft.qpos[i] = ga.qpos[i] = c->dqpos[sl];
+        ft.qvel[i] = ga.qvel[i] = c->dqvel[sl];
+        ft.side[i] = c->fe_xside[i];
+        fill_params<T>(c, tr.p[i], B, c->dM[sl], c->dJ[sl], c->ddq[sl], c->dbias[sl], c->dee[sl], c->dtgt[sl],
+                       c->has_tvel[sl] ? c->dtvel[sl] : nullptr, c->has_wrench[sl] ? c->dwrench[sl] : nullptr, c->du_set[i], c->dflags_set[i]);
+        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[i], bank + i, c->fe_xside[i], c->dqvel[sl], c->dtables, c->fused_xcd_map};
+        ga.out[i] = FeOut<T>{(T*)c->dM[sl], (T*)c->dJ[sl], (T*)c->ddq[sl], (T*)c->dbias[sl], (T*)c->dee[sl]};
+        ga.list[i] = c->dr16_list[i];
+        ga.count[i] = bank + i;
+    }
+    if (c->tev_begin) HIPCHK(c, hipEventRecord(c->tev_begin, st));
+    HIPCHK(c, (hipError_t)launch_frontend_lane_compact_dual_ur5(c->dmodel, ft, n, st));
+    HIPCHK(c, (hipError_t)launch_row16_fromq<T>(tr, n, st));
+    HIPCHK(c, (hipError_t)launch_frontend_generic_lists<T>(c->dmodel, ga, n, c->fe_smem, st));
+    HIPCHK(c, (hipError_t)launch_row16_worklist<T>(tr, n, other, st));
+    if (c->tev_end) HIPCHK(c, hipEventRecord(c->tev_end, st));
+    return IRLOSC_OK;
+}
+
+static int fused_resident(irlosc_ctx* c, int first_slot, int B, int iters) {
+    int done = 0;
+    while (done < iters) {
+        const int n = std::min((int)R16_TRAIN, iters - done);
+        int slots[R16_TRAIN];
+        for (int i = 0; i < n; ++i) {
+            slots[i] = (first_slot + done + i) % c->cfg.n_slots;
+            int rc = check_slot_q(c, slots[i], B);
+            if (rc) return rc;
+        }
+        int rc = c->cfg.dtype == IRLOSC_F64 ? fused_train<double>(c, slots, n, B, c->stream) : fused_train<float>(c, slots, n, B, c->stream);
+        if (rc) return rc;
+        c->cur = n - 1;
+        done += n;
+    }
+    c->du = c->du_set[c->cur];
+    c->dflags = c->dflags_set[c->cur];
+    return IRLOSC_OK;
+}
+
+extern "C" const char* irlosc_from_q_name(const irlosc_ctx* c) {
+    static thread_local std::string nm;
+    if (!c || !c->dmodel) return "";
+    if (c->fused) nm = std::string("osc_frontend_lane_compact_dual_ur5 + ") + c->kernel_name + "_fromq (fused: compact exchange buffer, no dense M / J)";
+    else nm = std::string(irlosc_frontend_name(c)) + " + " + c->kernel_name + " (through dense records)";
+    return nm.c_str();
+}
+
+extern "C" int irlosc_step_from_q(irlosc_ctx* c, int32_t slot, int32_t B, void* u_host, uint32_t* flags_host) {
+    if (!c) return IRLOSC_ERR_ARG;
+    int rc = check_slot(c, slot, B);
+    if (rc) return rc;
+    if (c->gains_nb == 0) return fail(c, IRLOSC_ERR_STATE, "irlosc_set_gains has not been called");
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    if (B > 0) {
+        if (c->fused) {
+            rc = fused_resident(c, slot, B, 1);
+        } else {
+            rc = check_slot_q(c, slot, B);
+            if (!rc) rc = frontend_launch(c, slot, B);
+            if (!rc) rc = launch_slot(c, slot, B);
+        }
+        if (rc) return rc;
+    }
+    if (u_host || flags_host) return irlosc_download(c, B, u_host, flags_host);
+    return IRLOSC_OK;
+}
+
 extern "C" int irlosc_step_resident_from_q(irlosc_ctx* c, int32_t first_slot, int32_t B, int32_t iters, float* ms_total,
                                            float* ms_step_avg) {
     if (!c) return IRLOSC_ERR_ARG;
@@ -1086,12 +1213,18 @@ extern "C" int irlosc_step_resident_from_q(irlosc_ctx* c, int32_t first_slot, in
     if (c->gains_nb == 0) return fail(c, IRLOSC_ERR_STATE, "irlosc_set_gains has not been called");
     HIPCHK(c, hipSetDevice(c->cfg.hip_device));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    for (int i = 0; i < iters; ++i) {
-        const int slot = (first_slot + i) % c->cfg.n_slots;
-        rc = frontend_launch(c, slot, B);
+    if (c->fused && B > 0) {
+        rc = fused_resident(c, first_slot, B, iters);
         if (rc) return rc;
-        rc = launch_slot(c, slot, B);
-        if (rc) return rc;
+    } else {
+        for (int i = 0; i < iters; ++i) {
+            const int slot = (first_slot + i) % c->cfg.n_slots;
+            rc = check_slot_q(c, slot, B);
+            if (!rc) rc = frontend_launch(c, slot, B);
+            if (rc) return rc;
+            rc = launch_slot(c, slot, B);
+            if (rc) return rc;
+        }
     }
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));

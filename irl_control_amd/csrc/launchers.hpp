@@ -21,6 +21,8 @@ template <typename TIN> struct Row16Train;
 template <typename TIN>
 int launch_row16(const Row16Train<TIN>& tr, int nsteps, hipStream_t st);
 template <typename TIN>
+int launch_row16_fromq(const Row16Train<TIN>& tr, int nsteps, hipStream_t st);
+template <typename TIN>
 int launch_row16_worklist(const Row16Train<TIN>& tr, int nsteps, int32_t* reset, hipStream_t st);
 
 // tu_frontend.hip / tu_frontend_lane.hip -- rigid-body front end (osc_frontend.hpp, osc_frontend_lane.hpp); TOUT = record type
@@ -32,6 +34,14 @@ int launch_frontend_generic(const FeModel* dmodel, const double* qpos, const dou
 template <typename TOUT>
 int launch_frontend_lane_dual_ur5(const FeModel* dmodel, const double* qpos, const double* qvel, const FeOut<TOUT>& out, int B,
                                   double* side, hipStream_t st);
+template <typename TOUT> struct FeGenericArgs;
+template <typename TOUT>
+int launch_frontend_generic_lists(const FeModel* dmodel, const FeGenericArgs<TOUT>& a, int nsteps, size_t smem, hipStream_t st);
+// compact form for the fused path: a train of up to FE_TRAIN steps, nothing but the exchange buffer is written
+struct FeLaneTrain;
+struct FeCompactTables;
+int launch_frontend_lane_compact_dual_ur5(const FeModel* dmodel, const FeLaneTrain& tr, int nsteps, hipStream_t st);
+void frontend_lane_dual_ur5_tables(const FeModel& h, FeCompactTables* t);
 size_t frontend_lane_dual_ur5_side_doubles_per_wave();
 bool frontend_lane_dual_ur5_matches(const FeModel& h);
 

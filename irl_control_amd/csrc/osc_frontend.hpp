@@ -96,9 +96,51 @@ __device__ __forceinline__ void inertia_apply(double m, V3 c, const double* Ic, 
 template <typename TOUT>
 struct FeOut { TOUT* M; TOUT* J; TOUT* dq; TOUT* bias; TOUT* ee; };
 
+// Steps chained into one launch of the compact lane kernel (blockIdx.y = step); equals R16_TRAIN of the consumer.
+constexpr int FE_TRAIN = 8;
+
+// Entry indices of the COMPACT EXCHANGE BUFFER the lane-per-robot walk leaves for the fp64 OSC kernel (osc_row16.hpp,
+// FROMQ): per walk wave a block [entry][64 robots] of doubles holding only the structural non-zeros -- M[i][j] for i at
+// or above j, the Jacobian columns and the pose of the end-effector bodies, the bias forces -- plus one entry of zeros that
+// every structural zero points at.  Built on the host from the compiled tree shape (tu_frontend_lane_f64.hip).
+struct FeCompactTables {
+    uint16_t mtab[32][32];                    // [column j][row i]: entry of M[i][j] = M[j][i]
+    uint16_t jtab[IRLOSC_MAX_K][32];          // [task row r][joint i]: entry of J[r][i]
+    uint16_t eetab[IRLOSC_MAX_DEV][8];        // [device d][0..6]: x y z qw qx qy qz of its end effector
+    uint16_t btab[32];                        // [joint i]: bias force
+    uint16_t zero, n_entries;
+};
+
+// Parameters of one launch of the compact lane kernel (osc_frontend_lane.hpp): step i reads (qpos[i], qvel[i]) of B robots and
+// fills the exchange buffer side[i].
+struct FeLaneTrain {
+    const double* qpos[FE_TRAIN];
+    const double* qvel[FE_TRAIN];
+    double* side[FE_TRAIN];
+    int32_t B;
+};
+
+// Arguments of the wave-per-robot kernel, one set per step of a launch (blockIdx.y = step; a plain launch has one step).
+// With `list` a step works through a device-side worklist (list[0 .. *count)) instead of all B robots: the give-up pass
+// of the fused path (dense records of a few robots, for the generic OSC kernel).
 template <typename TOUT>
-__global__ __launch_bounds__(64) void osc_frontend_kernel(const FeModel* __restrict__ model_, const double* __restrict__ qpos,
-                                                          const double* __restrict__ qvel, const FeOut<TOUT> out, const int B) {
+struct FeGenericArgs {
+    const double* qpos[FE_TRAIN];
+    const double* qvel[FE_TRAIN];
+    FeOut<TOUT> out[FE_TRAIN];
+    const int32_t* list[FE_TRAIN];
+    const int32_t* count[FE_TRAIN];
+    int32_t B;
+};
+
+template <typename TOUT>
+__global__ __launch_bounds__(64) void osc_frontend_kernel(const FeModel* __restrict__ model_, const FeGenericArgs<TOUT> args) {
+    const double* __restrict__ qpos = args.qpos[blockIdx.y];
+    const double* __restrict__ qvel = args.qvel[blockIdx.y];
+    const FeOut<TOUT> out = args.out[blockIdx.y];
+    const int32_t* __restrict__ list = args.list[blockIdx.y];
+    const int32_t* __restrict__ count = args.count[blockIdx.y];
+    const int B = args.B;
     typedef const __attribute__((address_space(4))) FeModel* cmodel_t;
     const cmodel_t md = (cmodel_t)model_;
     // LDS sized by the model (frontend_smem_bytes): it bounds the waves per CU of this latency-bound kernel
@@ -126,7 +168,9 @@ __global__ __launch_bounds__(64) void osc_frontend_kernel(const FeModel* __restr
     const int j = lane;
     const bool isj = j < nj;
     const int bj = isj ? md->body_of_joint[j] : 0;
-    for (int inst = blockIdx.x; inst < B; inst += gridDim.x) {
+    const int n_items = list ? min(*count, B) : B;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int inst = list ? list[item] : item;
         if (isj) {
             s_q[j] = qpos[(size_t)inst * nj + j];
             s_qd[j] = qvel[(size_t)inst * nj + j];

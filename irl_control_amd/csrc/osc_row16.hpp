@@ -35,6 +35,7 @@
 #include <utility>
 
 #include "osc_common.hpp"
+#include "osc_frontend.hpp"      // FeCompactTables: the exchange buffer of the fused path (FROMQ)
 
 namespace irlosc {
 namespace r16 {
@@ -421,6 +422,12 @@ struct Row16Extra {
     const void* zeros;         // >= 32 * 32 * 8 bytes of zeros
     int32_t* worklist;         // [B]
     int32_t* workcount;        // counter of this step (zero on entry)
+    // FROMQ (the fused path from joint coordinates): M, J, bias and the end-effector poses are not records in HBM but
+    // entries of the compact exchange buffer the lane-per-robot walk left behind (osc_frontend_lane.hpp), dq is qvel
+    const double* side;        // [walk wave][entry][64 robots]
+    const double* qvel;        // [B][n]
+    const FeCompactTables* tables;
+    int32_t xcd_map;           // 1: the XCD-aware block -> robots map of the FROMQ kernel (0: identity, A/B measurements)
 };
 
 // One launch = a TRAIN of up to R16_TRAIN steps (blockIdx.y = step): consecutive steps of irlosc_step_resident are
@@ -435,11 +442,18 @@ struct Row16Train {
 };
 
 // TIN = storage type of the records (double, or float for the mixed path); arithmetic is double throughout.
-template <int K, int NDEV, typename TIN, int N>
+// FROMQ: the fused path from joint coordinates.  Same kernel, but the operands the rigid-body front end computes come out
+// of the compact exchange buffer (x.side, entry tables x.tables) instead of dense records: row j of M is 25 gathered
+// entries of which the structural zeros all point at one entry of zeros, J likewise, bias and EE pose are entries, dq is
+// qvel.  A walk wave's block [entry][64 robots] is consumed by 16 blocks of this kernel (4 robots each); the
+// blockIdx -> robots map keeps those 16 on ONE XCD (blockIdx.x % 8), so that the 128-byte lines they share are fetched
+// into one L2 only.  Targets, gains, wrench, outputs stay records of type TIN.
+template <int K, int NDEV, typename TIN, int N, bool FROMQ = false>
 __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> tr) {
     using namespace r16;
     const KParams<TIN>& p = tr.p[blockIdx.y];
     const Row16Extra& x = tr.x[blockIdx.y];
+    using TM = std::conditional_t<FROMQ, double, TIN>;      // type the M / J / dq / bias operands arrive in
     static_assert(N > 16 && N <= 32 && K >= 1 && K <= 16 && NDEV >= 1 && NDEV <= 4, "shape");
     constexpr int N1 = N - 16;                 // real rows in slot 1
     constexpr int PF = 8;                      // rows of M in flight ahead of the column being eliminated
@@ -449,14 +463,38 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
     __shared__ double Kvl[4][4];
     __shared__ int Brl[4][4];
 
+    __shared__ uint16_t Mt[FROMQ ? N * 32 : 2];      // FROMQ: entry of M[j][i] at [j * 32 + i], of J[r][i] at [r * 32 + i]
+    __shared__ uint16_t Jt[FROMQ ? K * 32 : 2];
     const int lane = threadIdx.x, q = lane >> 4, l = lane & 15;
-    const int b = blockIdx.x * 4 + q;
+    int blk = blockIdx.x;
+    if constexpr (FROMQ) {      // block x + 8 (s + 16 t) -> walk wave 8 t + x, robots 4 s .. 4 s + 3 of it
+        if (x.xcd_map) {
+            const int r = blk & 127;
+            blk = ((blk >> 7) * 8 + (r & 7)) * 16 + (r >> 3);
+        }
+    }
+    const int b = blk * 4 + q;
     const bool live = b < p.B;
     const int bc = live ? b : p.B - 1;
     const bool v1 = l < N1;
     const TIN* __restrict__ zeros = reinterpret_cast<const TIN*>(x.zeros);
-    const TIN* __restrict__ m0p = p.M + (size_t)bc * (N * N) + l;
-    const TIN* __restrict__ m1p = v1 ? p.M + (size_t)bc * (N * N) + 16 + l : zeros;
+    const TIN* __restrict__ m0p = FROMQ ? zeros : p.M + (size_t)bc * (N * N) + l;
+    const TIN* __restrict__ m1p = (!FROMQ && v1) ? p.M + (size_t)bc * (N * N) + 16 + l : zeros;
+    // FROMQ: this robot's column of its walk wave's exchange block; entry e sits e * 512 bytes further on
+    const char* sb = nullptr;
+    if constexpr (FROMQ) {
+        const FeCompactTables* __restrict__ tb = x.tables;
+        for (int e = lane; e < N * 32; e += 64) Mt[e] = tb->mtab[e >> 5][e & 31];
+        for (int e = lane; e < K * 32; e += 64) Jt[e] = tb->jtab[e >> 5][e & 31];
+        sb = reinterpret_cast<const char*>(x.side + ((size_t)(bc >> 6) * tb->n_entries * 64 + (bc & 63)));
+    }
+    auto side_ld = [&](const unsigned entry) -> double { return *reinterpret_cast<const double*>(sb + ((size_t)entry << 9)); };
+    // (Two thirds of M's and J's entries are structural zeros, all naming the one entry of zeros.  Masking those lanes out of
+    // the loads was tried: 1 586 instead of 1 476 us per train of 8 -- the exec-mask bookkeeping costs more issue slots than
+    // the lines it saves; the loads stay unconditional.)
+    unsigned zb = 0;
+    if constexpr (FROMQ) zb = x.tables->zero;
+    auto side_ldz = [&](const unsigned entry) -> double { return side_ld(entry); };
     double* Jq = Jl + q * ((K + 1) * N);
     uint32_t flags = 0;
     // IRLOSC_PHASE_TIMING=1 debug runs: cycle stamps per phase and the wall clock of the wave (p.dbg != nullptr)
@@ -466,18 +504,35 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
     IRLOSC_TS(0);
 
     // ---- prologue: first rows of M in flight, J (coalesced) into LDS, dq ------------------------------------------
-    TIN pm0[N], pm1[N];
-    static_for<0, PF>([&](auto jc) { constexpr int j = decltype(jc)::value; pm0[j] = m0p[j * N]; pm1[j] = m1p[j * N]; });
-    const TIN* __restrict__ Jb = p.J + (size_t)bc * (K * N);
-    const TIN* __restrict__ Jb1 = v1 ? Jb + 16 + l : zeros;
-    TIN jl0[K], jl1[K];
-#pragma unroll
-    for (int r = 0; r < K; ++r) { jl0[r] = Jb[r * N + l]; jl1[r] = Jb1[r * N]; }
-    const TIN dq0_in = p.dq[(size_t)bc * N + l];
-    const TIN dq1_in = (v1 ? p.dq + (size_t)bc * N + 16 + l : zeros)[0];
+    TM pm0[N], pm1[N];
+    TM jl0[K], jl1[K];
+    TM dq0_in, dq1_in, bias0_in, bias1_in;
     const bool use_g = (p.cfgflags & IRLOSC_USE_G) != 0;
-    const TIN bias0_in = (use_g ? p.bias + (size_t)bc * N + l : zeros)[0];
-    const TIN bias1_in = (use_g && v1 ? p.bias + (size_t)bc * N + 16 + l : zeros)[0];
+    unsigned mo0 = 0, mo1 = 0;      // FROMQ: entries of the next row of M to be requested (table reads run one column ahead)
+    if constexpr (FROMQ) {
+        lds_sync();                 // the entry tables are in LDS
+        static_for<0, PF>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            pm0[j] = side_ldz(Mt[j * 32 + l]); pm1[j] = side_ldz(Mt[j * 32 + 16 + l]);
+        });
+        mo0 = Mt[PF * 32 + l]; mo1 = Mt[PF * 32 + 16 + l];
+#pragma unroll
+        for (int r = 0; r < K; ++r) { jl0[r] = side_ldz(Jt[r * 32 + l]); jl1[r] = side_ldz(Jt[r * 32 + 16 + l]); }
+        dq0_in = x.qvel[(size_t)bc * N + l];
+        dq1_in = v1 ? x.qvel[(size_t)bc * N + 16 + l] : 0.0;
+        bias0_in = side_ldz(use_g ? x.tables->btab[l] : zb);
+        bias1_in = side_ldz(use_g ? x.tables->btab[16 + l] : zb);
+    } else {
+        static_for<0, PF>([&](auto jc) { constexpr int j = decltype(jc)::value; pm0[j] = m0p[j * N]; pm1[j] = m1p[j * N]; });
+        const TIN* __restrict__ Jb = p.J + (size_t)bc * (K * N);
+        const TIN* __restrict__ Jb1 = v1 ? Jb + 16 + l : zeros;
+#pragma unroll
+        for (int r = 0; r < K; ++r) { jl0[r] = Jb[r * N + l]; jl1[r] = Jb1[r * N]; }
+        dq0_in = p.dq[(size_t)bc * N + l];
+        dq1_in = (v1 ? p.dq + (size_t)bc * N + 16 + l : zeros)[0];
+        bias0_in = (use_g ? p.bias + (size_t)bc * N + l : zeros)[0];
+        bias1_in = (use_g && v1 ? p.bias + (size_t)bc * N + 16 + l : zeros)[0];
+    }
     Wl[q][l] = 0.0;
     lds_sync();
 
@@ -492,12 +547,19 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
     const DevMeta dm = p.dev[dd];
     bool own_brB = false;
     {
-        const TIN* __restrict__ eep = p.ee + ((size_t)bc * NDEV + dd) * 7;
         const TIN* __restrict__ tgp = p.tgt + ((size_t)bc * NDEV + dd) * 7;
         const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * NDEV * IRLOSC_GAIN_WORDS : 0) + dd * IRLOSC_GAIN_WORDS;
         double ee[7], tg[7], g[IRLOSC_GAIN_WORDS];
+        if constexpr (FROMQ) {
 #pragma unroll
-        for (int i = 0; i < 7; ++i) { ee[i] = (double)eep[i]; tg[i] = (double)tgp[i]; }
+            for (int i = 0; i < 7; ++i) ee[i] = side_ld(x.tables->eetab[dd][i]);
+        } else {
+            const TIN* __restrict__ eep = p.ee + ((size_t)bc * NDEV + dd) * 7;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) ee[i] = (double)eep[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) tg[i] = (double)tgp[i];
 #pragma unroll
         for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) g[i] = (double)gp[i];
         double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -578,7 +640,14 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
     static_for<0, N>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int sj = j >> 4, gj = j & 15;
-        if constexpr (j + PF < N) { pm0[j + PF] = m0p[(j + PF) * N]; pm1[j + PF] = m1p[(j + PF) * N]; }
+        if constexpr (j + PF < N) {
+            if constexpr (FROMQ) {
+                pm0[j + PF] = side_ldz(mo0); pm1[j + PF] = side_ldz(mo1);
+                if constexpr (j + PF + 1 < N) { mo0 = Mt[(j + PF + 1) * 32 + l]; mo1 = Mt[(j + PF + 1) * 32 + 16 + l]; }
+            } else {
+                pm0[j + PF] = m0p[(j + PF) * N]; pm1[j + PF] = m1p[(j + PF) * N];
+            }
+        }
         double m0 = (double)pm0[j], m1 = (double)pm1[j];
         double tj = tnext;
         if constexpr (j + 1 < N) tnext = trow[j + 1];

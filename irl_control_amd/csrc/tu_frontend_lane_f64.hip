@@ -15,6 +15,13 @@ int launch_frontend_lane_dual_ur5(const FeModel* dmodel, const double* qpos, con
 }
 template int launch_frontend_lane_dual_ur5<double>(const FeModel*, const double*, const double*, const FeOut<double>&, int, double*, hipStream_t);
 
+int launch_frontend_lane_compact_dual_ur5(const FeModel* dmodel, const FeLaneTrain& tr, int nsteps, hipStream_t st) {
+    if (tr.B <= 0 || nsteps <= 0) return 0;
+    hipLaunchKernelGGL((osc_frontend_lane_compact_kernel<TopoDualUr5>), dim3((tr.B + 63) / 64, nsteps), dim3(64), 0, st, dmodel, tr);
+    return (int)hipGetLastError();
+}
+void frontend_lane_dual_ur5_tables(const FeModel& h, FeCompactTables* t) { frontend_lane_tables<TopoDualUr5>(h, t); }
+
 size_t frontend_lane_dual_ur5_side_doubles_per_wave() { return (size_t)FeTopo<TopoDualUr5>::n_side() * 64; }
 bool frontend_lane_dual_ur5_matches(const FeModel& h) { return frontend_lane_matches<TopoDualUr5>(h); }
 

@@ -18,6 +18,21 @@ int launch_row16(const Row16Train<TIN>& tr, int nsteps, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// The same train on the fused path: operands from the compact exchange buffers (tr.x[i].side / qvel / tables).  The grid
+// covers whole groups of 8 walk waves (128 blocks) so that the XCD-aware block map of the kernel stays a bijection.
+template <typename TIN>
+int launch_row16_fromq(const Row16Train<TIN>& tr, int nsteps, hipStream_t st) {
+    const KParams<TIN>& p = tr.p[0];
+    if (p.B <= 0 || nsteps <= 0) return 0;
+    const int waves = (p.B + 63) / 64;
+    const dim3 grid(((waves + 7) / 8) * 128, nsteps);
+    if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25, true>), grid, dim3(64), 0, st, tr);
+    else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<12, 2, TIN, 25, true>), grid, dim3(64), 0, st, tr);
+    else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<7, 3, TIN, 25, true>), grid, dim3(64), 0, st, tr);
+    else return (int)hipErrorNotSupported;
+    return (int)hipGetLastError();
+}
+
 
 // The generic kernel (Jacobi, fp64 arithmetic) over the give-up lists of a train; zeroes the counters `reset` points at.
 template <typename TIN>
@@ -29,6 +44,7 @@ int launch_row16_worklist(const Row16Train<TIN>& tr, int nsteps, int32_t* reset,
 }
 
 template int launch_row16<double>(const Row16Train<double>&, int, hipStream_t);
+template int launch_row16_fromq<double>(const Row16Train<double>&, int, hipStream_t);
 template int launch_row16_worklist<double>(const Row16Train<double>&, int, int32_t*, hipStream_t);
 
 }  // namespace irlosc

@@ -918,6 +918,111 @@ def test_frontend_records_and_step_from_q(cfg):
     assert rel_err(u_q, ref)[dom].max() <= TOL64
 
 
+def _from_q_setup(cfg, B, dtype, seed, n_slots=1, singular_every=0):
+    from irl_control_amd.rigid_body import RigidBodyModel
+    lay = synth.make_layout(cfg)
+    _, gains, g = synth.make_batch(cfg, B, seed=seed, dtype=dtype)
+    model = RigidBodyModel.load("dual_ur5")
+    rng = np.random.default_rng(seed + 1000)
+    osc = BatchedOSC(lay, B, dtype=dtype, n_slots=n_slots, kernel=_lib.KERNEL_ROW16)
+    osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+    osc.set_model(model)
+    states = []
+    for sl in range(n_slots):
+        qpos, qvel = model.random_state(rng, B)
+        if singular_every:                   # stretched / folded arms: every angle of the two arms a multiple of pi / 2
+            idx = np.arange(sl, B, singular_every)
+            qpos[idx, 1:7] = (np.pi / 2) * rng.integers(-2, 3, size=(len(idx), 6))
+            qpos[idx, 13:19] = (np.pi / 2) * rng.integers(-2, 3, size=(len(idx), 6))
+        osc.upload_q(qpos, qvel, slot=sl)
+        osc.set_targets(g["tgt_pose"], g.get("tgt_vel"), slot=sl)
+        states.append((qpos, qvel))
+    return lay, gains, g, model, osc, states
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("cfg", ["k13", "k7", "k12_admit"])
+def test_fused_from_q_equals_the_path_through_dense_records(cfg, dtype, monkeypatch):
+    """SURVEY 8 f1, fused form: lane-per-robot walk -> compact exchange buffer -> row16 kernel gathering its operands
+    (no dense M / J in HBM) against the same two kernels' arithmetic through dense records (irlosc_frontend +
+    irlosc_step).  In float64 the operands are the same numbers, so the torques agree to rounding; with float32 records
+    the dense path ROUNDS M / J / bias to float32 on the way while the fused path hands them over in float64, so there the
+    comparison is at the float32-records tolerance.  Flags equal.  Singular arm configurations (all arm angles multiples
+    of pi / 2) are mixed in: the eigen stage and the give-up hand-over run on both paths."""
+    B = 2048 + 37
+    lay, gains, g, model, osc, states = _from_q_setup(cfg, B, dtype, seed=5, singular_every=9)
+    assert "fused" in osc.from_q_name and "compact" in osc.from_q_name
+    u_f, fl_f = osc.step_q(return_flags=True)
+    osc.frontend()
+    u_d, fl_d = osc.step(return_flags=True)
+    osc.close()
+    assert np.all(np.isfinite(u_f))
+    if cfg != "k7":            # (three translational rows per arm stay well conditioned: no eigen stage there)
+        assert (fl_f & _lib.FLAG_EIGEN_PATH).mean() > 0.02
+    d = np.abs(u_f.astype(np.float64) - u_d).max(axis=1) / np.abs(u_d).max(axis=1)
+    if dtype == np.float64:
+        assert np.array_equal(fl_f, fl_d)
+        assert d.max() <= 1e-9, float(d.max())
+    else:
+        same = ((fl_f ^ fl_d) & (_lib.FLAG_PINV_BRANCH | _lib.FLAG_TRUNCATED)) == 0
+        assert same.mean() > 0.97
+        assert np.median(d) <= 1e-5 and np.quantile(d[same], 0.99) <= 1e-2, (float(np.median(d)), float(np.quantile(d[same], 0.99)))
+    monkeypatch.setenv("IRLOSC_FUSED", "0")            # and the library's own switch gives the two-kernel path
+    lay, gains, g, model, osc2, _ = _from_q_setup(cfg, B, dtype, seed=5, singular_every=9)
+    assert "through dense records" in osc2.from_q_name
+    u_2, fl_2 = osc2.step_q(return_flags=True)
+    osc2.close()
+    assert np.array_equal(u_2, u_d) and np.array_equal(fl_2, fl_d)
+
+
+def test_fused_from_q_against_the_chained_oracles():
+    """The fused path end to end against oracle/rigid_body.py -> oracle/osc_oracle.py on the same (qpos, qvel, targets):
+    north_star's 1e-5 in the parity domain."""
+    from irl_control_amd.rigid_body import DUAL_UR5_EE
+    from oracle import rigid_body as rb
+    B = 96
+    lay, gains, g, model, osc, states = _from_q_setup("k13", B, np.float64, seed=23, singular_every=0)
+    u, fl = osc.step_q(return_flags=True)
+    osc.close()
+    qpos, qvel = states[0]
+    om = rb.Model()
+    recs = [rb.records(om, lay.as_oracle_dict(), DUAL_UR5_EE, qpos[b], qvel[b]) for b in range(B)]
+    R = {k: np.array([r[k] for r in recs]) for k in ("M", "J", "dq", "bias", "ee_pose")}
+    ref = osc_oracle.generate_batch(lay.as_oracle_dict(), gains, R["M"], R["J"], R["dq"], R["bias"], R["ee_pose"], g["tgt_pose"])
+    dom = np.array([in_parity_domain(*osc_oracle.task_inertia(R["J"][b], R["M"][b])[2:]) for b in range(B)])
+    assert dom.sum() >= B // 2 and rel_err(u, ref)[dom].max() <= TOL64
+
+
+@pytest.mark.parametrize("B", [1, 3, 63, 64, 65, 130, 515])
+def test_fused_from_q_ragged_batches_bit_exact(B):
+    """A walk wave carries 64 robots, a row16 block 4, and the block -> robots map groups 128 blocks per 8 walk waves: batch
+    sizes around all three.  Robot b comes out bit-identical whatever the batch around it."""
+    lay, gains, g, model, osc, states = _from_q_setup("k13", 640, np.float64, seed=31, singular_every=5)
+    full, ffull = osc.step_q(return_flags=True)
+    qpos, qvel = states[0]
+    osc.upload_q(qpos[:B], qvel[:B])
+    osc.set_targets(g["tgt_pose"][:B])
+    part, fpart = osc.step_q(return_flags=True)
+    osc.close()
+    assert np.array_equal(part, full[:B]) and np.array_equal(fpart, ffull[:B])
+
+
+@pytest.mark.parametrize("iters", [1, 7, 8, 12, 19])
+def test_fused_resident_trains_equal_single_steps(iters):
+    """irlosc_step_resident_from_q chains up to 8 steps per launch pair (walk train, OSC train, one give-up pass), each
+    step with its own exchange buffer and output set: the outputs left behind are bit for bit those of a single fused
+    step on the last slot visited -- also right after an uneven train (the counters of the give-up lists)."""
+    nslots, B = 3, 700
+    lay, gains, g, model, osc, states = _from_q_setup("k13", B, np.float64, seed=41, n_slots=nslots, singular_every=6)
+    for rep in range(2):
+        first = (1 + rep) % nslots
+        osc.step_resident_from_q(iters, first_slot=first)
+        u_t, f_t = osc.download(B)
+        u_1, f_1 = osc.step_q(slot=(first + iters - 1) % nslots, return_flags=True)
+        assert np.array_equal(u_t, u_1) and np.array_equal(f_t, f_1), rep
+    osc.close()
+
+
 @pytest.mark.parametrize("fe", ["lane", "generic"])
 @pytest.mark.parametrize("B", [1, 70, 128])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
