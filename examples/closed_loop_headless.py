@@ -45,7 +45,13 @@ def run(robots=16, ticks=1500, seed=0, dt=1e-3, damping=0.0, verbose=True):
     err0 = None
     hist = []
     for t in range(ticks):
-        u = osc.step_from_q(q, qd, tgt)
+        # the front end plays the simulator here: its records (M, bias, EE poses) are read back for the host-side physics, so
+        # it runs as a kernel of its own and the controller steps on the records (osc.step_from_q would take the fused path,
+        # which leaves no dense records behind)
+        osc.upload_q(q, qd)
+        osc.frontend()
+        osc.set_targets(tgt)
+        u = osc.step()
         rec = osc.download_records()
         pos_err = np.linalg.norm(rec["ee_pose"][:, :2, :3] - tgt[:, :2, :3], axis=2)      # the two arms
         if err0 is None:

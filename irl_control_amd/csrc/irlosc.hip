@@ -67,7 +67,12 @@ struct irlosc_ctx {
     // two counters used alternately (the worklist pass of a step zeroes the counter of the next one)
     void* dzeros = nullptr;
     int32_t* dr16_list[R16_TRAIN] = {};    // give-up list of each step of a train
-    int32_t* dr16_count = nullptr;         // [2 banks][R16_TRAIN]: trains alternate banks, a train's give-up pass zeroes the other one
+    int32_t* dr16_count = nullptr;         // [2 banks][2 * R16_TRAIN] (give-up counters, then eigen-list counters): trains alternate
+                                           // banks, a train's give-up pass zeroes the other one
+    // eigen pass of the row16 path: hand-over records of the flagged instances of each step of a train
+    double* dr16_eigA[R16_TRAIN] = {};     // [B][K][16]
+    double* dr16_eigw[R16_TRAIN] = {};     // [B][16]
+    int32_t* dr16_eiglist[R16_TRAIN] = {}; // [B]
     int r16_parity = 0;
     // rigid-body front end (irlosc_set_model): device copy of the tables, resident joint coordinates per slot
     FeModel* dmodel = nullptr;
@@ -81,6 +86,7 @@ struct irlosc_ctx {
     double* fe_xside[R16_TRAIN] = {};
     int fused = 0;
     int fused_xcd_map = 1;
+    int fused_train = R16_TRAIN;
     std::vector<double*> dqpos, dqvel;
     std::vector<int> has_q;
     // irlosc_tick: one pinned host block and one device block per direction, grown on demand
@@ -191,7 +197,12 @@ static void free_all(irlosc_ctx* c) {
     if (c->tick_hout) (void)hipHostFree(c->tick_hout);
     if (c->tick_dout) (void)hipFree(c->tick_dout);
     if (c->dzeros) (void)hipFree(c->dzeros);
-    for (int k = 0; k < R16_TRAIN; ++k) if (c->dr16_list[k]) (void)hipFree(c->dr16_list[k]);
+    for (int k = 0; k < R16_TRAIN; ++k) {
+        if (c->dr16_list[k]) (void)hipFree(c->dr16_list[k]);
+        if (c->dr16_eigA[k]) (void)hipFree(c->dr16_eigA[k]);
+        if (c->dr16_eigw[k]) (void)hipFree(c->dr16_eigw[k]);
+        if (c->dr16_eiglist[k]) (void)hipFree(c->dr16_eiglist[k]);
+    }
     if (c->dr16_count) (void)hipFree(c->dr16_count);
     if (c->dsym) (void)hipFree(c->dsym);
     if (c->dgains) (void)hipFree(c->dgains);
@@ -256,9 +267,14 @@ static int create_impl(irlosc_ctx* c) {
         constexpr size_t ZB = 64 * 1024;
         HIPCHK(nullptr, hipMalloc(&c->dzeros, ZB));
         HIPCHK(nullptr, hipMemsetAsync(c->dzeros, 0, ZB, c->stream));
-        for (int k2 = 0; k2 < R16_TRAIN; ++k2) HIPCHK(nullptr, hipMalloc((void**)&c->dr16_list[k2], B * sizeof(int32_t)));
-        HIPCHK(nullptr, hipMalloc((void**)&c->dr16_count, 2 * R16_TRAIN * sizeof(int32_t)));
-        HIPCHK(nullptr, hipMemsetAsync(c->dr16_count, 0, 2 * R16_TRAIN * sizeof(int32_t), c->stream));
+        for (int k2 = 0; k2 < R16_TRAIN; ++k2) {
+            HIPCHK(nullptr, hipMalloc((void**)&c->dr16_list[k2], B * sizeof(int32_t)));
+            HIPCHK(nullptr, hipMalloc((void**)&c->dr16_eigA[k2], B * k * 16 * sizeof(double)));
+            HIPCHK(nullptr, hipMalloc((void**)&c->dr16_eigw[k2], B * 16 * sizeof(double)));
+            HIPCHK(nullptr, hipMalloc((void**)&c->dr16_eiglist[k2], B * sizeof(int32_t)));
+        }
+        HIPCHK(nullptr, hipMalloc((void**)&c->dr16_count, 4 * R16_TRAIN * sizeof(int32_t)));
+        HIPCHK(nullptr, hipMemsetAsync(c->dr16_count, 0, 4 * R16_TRAIN * sizeof(int32_t), c->stream));
     }
     c->du = c->du_set[0];
     c->dflags = c->dflags_set[0];
@@ -660,16 +676,18 @@ static int row16_train(irlosc_ctx* c, const KParams<T>* ps, int n, hipStream_t s
     if (n < 1 || n > R16_TRAIN) return fail(c, IRLOSC_ERR_STATE, "train of %d steps", n);
     Row16Train<T> tr;
     memset(&tr, 0, sizeof tr);
-    int32_t* bank = c->dr16_count + c->r16_parity * R16_TRAIN;
-    int32_t* other = c->dr16_count + (c->r16_parity ^ 1) * R16_TRAIN;
+    int32_t* bank = c->dr16_count + c->r16_parity * 2 * R16_TRAIN;
+    int32_t* other = c->dr16_count + (c->r16_parity ^ 1) * 2 * R16_TRAIN;
     c->r16_parity ^= 1;
     for (int i = 0; i < n; ++i) {
         tr.p[i] = ps[i];
-        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[i], bank + i, nullptr, nullptr, nullptr, 0};
+        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[i], bank + i, c->dr16_eigA[i], c->dr16_eigw[i], c->dr16_eiglist[i],
+                             bank + R16_TRAIN + i, nullptr, nullptr, nullptr, 0};
     }
     if (c->tev_begin) HIPCHK(c, hipEventRecord(c->tev_begin, st));
     int rc = launch_row16<T>(tr, n, st);
     if (rc) return fail(c, IRLOSC_ERR_HIP, "row16 kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIPCHK(c, (hipError_t)launch_row16_eigen<T>(tr, n, false, st));
     HIPCHK(c, (hipError_t)launch_row16_worklist<T>(tr, n, other, st));
     if (c->tev_end) HIPCHK(c, hipEventRecord(c->tev_end, st));
     return IRLOSC_OK;
@@ -1015,6 +1033,8 @@ extern "C" int irlosc_set_model(irlosc_ctx* c, const irlosc_model* m) {
         c->fused = c->fe_lane && c->kernel == IRLOSC_KERNEL_ROW16 && !(e && !strcmp(e, "0"));
         const char* m = getenv("IRLOSC_FROMQ_MAP");        // "0": identity block map (A/B measurements)
         c->fused_xcd_map = !(m && !strcmp(m, "0"));
+        const char* t = getenv("IRLOSC_FUSED_TRAIN");      // steps per launch pair of the fused path (A/B measurements)
+        if (t && atoi(t) >= 1 && atoi(t) <= R16_TRAIN) c->fused_train = atoi(t);
     }
     if (c->fused) {
         FeCompactTables t;
@@ -1131,8 +1151,8 @@ static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, hipStream_
     memset(&tr, 0, sizeof tr);
     FeGenericArgs<T> ga;
     memset(&ga, 0, sizeof ga);
-    int32_t* bank = c->dr16_count + c->r16_parity * R16_TRAIN;
-    int32_t* other = c->dr16_count + (c->r16_parity ^ 1) * R16_TRAIN;
+    int32_t* bank = c->dr16_count + c->r16_parity * 2 * R16_TRAIN;
+    int32_t* other = c->dr16_count + (c->r16_parity ^ 1) * 2 * R16_TRAIN;
     c->r16_parity ^= 1;
     ft.B = ga.B = B;
     for (int i = 0; i < n; ++i) {
@@ -1142,7 +1162,8 @@ static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, hipStream_
         ft.side[i] = c->fe_xside[i];
         fill_params<T>(c, tr.p[i], B, c->dM[sl], c->dJ[sl], c->ddq[sl], c->dbias[sl], c->dee[sl], c->dtgt[sl],
                        c->has_tvel[sl] ? c->dtvel[sl] : nullptr, c->has_wrench[sl] ? c->dwrench[sl] : nullptr, c->du_set[i], c->dflags_set[i]);
-        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[i], bank + i, c->fe_xside[i], c->dqvel[sl], c->dtables, c->fused_xcd_map};
+        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[i], bank + i, c->dr16_eigA[i], c->dr16_eigw[i], c->dr16_eiglist[i],
+                             bank + R16_TRAIN + i, c->fe_xside[i], c->dqvel[sl], c->dtables, c->fused_xcd_map};
         ga.out[i] = FeOut<T>{(T*)c->dM[sl], (T*)c->dJ[sl], (T*)c->ddq[sl], (T*)c->dbias[sl], (T*)c->dee[sl]};
         ga.list[i] = c->dr16_list[i];
         ga.count[i] = bank + i;
@@ -1150,6 +1171,7 @@ static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, hipStream_
     if (c->tev_begin) HIPCHK(c, hipEventRecord(c->tev_begin, st));
     HIPCHK(c, (hipError_t)launch_frontend_lane_compact_dual_ur5(c->dmodel, ft, n, st));
     HIPCHK(c, (hipError_t)launch_row16_fromq<T>(tr, n, st));
+    HIPCHK(c, (hipError_t)launch_row16_eigen<T>(tr, n, true, st));
     HIPCHK(c, (hipError_t)launch_frontend_generic_lists<T>(c->dmodel, ga, n, c->fe_smem, st));
     HIPCHK(c, (hipError_t)launch_row16_worklist<T>(tr, n, other, st));
     if (c->tev_end) HIPCHK(c, hipEventRecord(c->tev_end, st));
@@ -1159,7 +1181,7 @@ static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, hipStream_
 static int fused_resident(irlosc_ctx* c, int first_slot, int B, int iters) {
     int done = 0;
     while (done < iters) {
-        const int n = std::min((int)R16_TRAIN, iters - done);
+        const int n = std::min(c->fused_train, iters - done);
         int slots[R16_TRAIN];
         for (int i = 0; i < n; ++i) {
             slots[i] = (first_slot + done + i) % c->cfg.n_slots;
