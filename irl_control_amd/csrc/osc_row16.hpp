@@ -36,6 +36,7 @@
 
 #include "osc_common.hpp"
 #include "osc_frontend.hpp"      // FeCompactTables: the exchange buffer of the fused path (FROMQ)
+#include "osc_row16_asm.hpp"     // generated: the main loop's broadcast-FMA chains as asm blocks
 
 namespace irlosc {
 namespace r16 {
@@ -668,17 +669,9 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
         fmac_bc_nop<gj>(mdq0, dqs, m0);
         fmac_bc<gj>(mdq1, dqs, m1);
         fmac_bc<gj>(dx, dqs, tj);
-        static_for<0, j>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            if constexpr (j < 16) {
-                fmac_bc_n<gj>(m0, L0[c], L0[c]);
-                fmac_bc_n<gj>(m1, L0[c], L1[c]);
-                fmac_bc_n<gj>(tj, L0[c], T[c]);
-            } else {
-                fmac_bc_n<gj>(m1, L1[c], L1[c]);
-                fmac_bc_n<gj>(tj, L1[c], T[c]);
-            }
-        });
+        // the column terms, one asm statement per chunk of them (osc_row16_asm.hpp: no compiler padding inside)
+        if constexpr (j > 0 && j < 16) fmac3_chain<gj, 0, j>(m0, m1, tj, L0, L1, T);
+        else if constexpr (j >= 16) fmac2_chain<gj, 0, j>(m1, tj, L1, T);
         double d = bc_nop<gj>(sj ? m1 : m0);
         flags |= !(d > 0.0) ? IRLOSC_FLAG_M_NOT_PD : 0u;      // also catches NaN
         d = fmax(d, 1e-300);
@@ -968,14 +961,14 @@ __global__ __launch_bounds__(64, 2) void osc_row16_eigen_kernel(const Row16Train
 // The generic kernel over a worklist: instance ids list[0..*count); zeroes *reset for the step after.
 // T = arithmetic type, S = storage type of the records (S = float, T = double on the mixed path).
 template <typename T, typename S>
-__global__ __launch_bounds__(64) void osc_generic_worklist_kernel(const Row16Train<S> tr, int32_t* __restrict__ reset) {   // reset: 2 * R16_TRAIN counters (give-up, then eigen)
+__global__ __launch_bounds__(64) void osc_generic_worklist_kernel(const Row16Train<S> tr, int32_t* __restrict__ reset) {   // reset: optional, 2 * R16_TRAIN counters to zero
     extern __shared__ __align__(16) unsigned char smem_raw_w[];
     T* smem = reinterpret_cast<T*>(smem_raw_w);
     const KParams<S>& p = tr.p[blockIdx.y];
     const int32_t* __restrict__ list = tr.x[blockIdx.y].worklist;
     const int n = *tr.x[blockIdx.y].workcount;
-    // The other bank = the next train's counters, ALL of them: a shorter train (step_resident with iters % R16_TRAIN != 0)
-    // would otherwise leave the counters beyond its own length at whatever an earlier, longer train counted.
+    // (The counters of a train are zeroed by the host with a memset in front of its main kernel -- ALL 2 * R16_TRAIN of its
+    // half, whatever the train's length: a shorter train must not inherit what a longer one counted.)
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2 * R16_TRAIN && reset) reset[threadIdx.x] = 0;
     for (int it = blockIdx.x; it < n; it += gridDim.x) generic_instance<T>(p, list[it], smem);
 }

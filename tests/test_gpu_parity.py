@@ -1071,6 +1071,43 @@ def test_frontend_records_themselves(fe, B, dtype, monkeypatch):
             row += 1
 
 
+def test_second_tree_through_the_generic_front_end():
+    """"Any tree of hinges" on something that is not the Dual-UR5: the single arm of scenes/ur5.xml (models/ur5.json: a chain
+    of six on a world-fixed base, one device, k = 6).  It has no compiled shape, so irlosc_set_model picks the wave-per-robot
+    front end and the OSC step runs on the generic kernel: records against the rigid-body oracle element by element, torques
+    of step_from_q against the OSC oracle on those records."""
+    from irl_control_amd.rigid_body import RigidBodyModel
+    from oracle import rigid_body as rb
+    import os
+    B = 70
+    model = RigidBodyModel.load("ur5")
+    om = rb.Model(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "irl_control_amd", "models", "ur5.json"))
+    lay = OSCLayout(n=6, dev_names=["arm"], ctrlr_dof=[[True] * 6], joint_ids=[list(range(6))], j_idx0=[0])
+    rng = np.random.default_rng(77)
+    qpos, qvel = rng.uniform(-np.pi, np.pi, (B, 6)), rng.normal(0.0, 0.5, (B, 6))
+    recs = [rb.records(om, lay.as_oracle_dict(), {"arm": "EE"}, qpos[b], qvel[b]) for b in range(B)]
+    R = {k: np.array([r[k] for r in recs]) for k in ("M", "J", "dq", "bias", "ee_pose")}
+    gains = dict(kp=[200.0], kv=[50.0], ko=[200.0], k=[[1.0, 2.0, 3.0]], d=[[0.5, 1.0, 1.0]], max_vel=[[1.0, 5.0]], null_kv=10.0)
+    tgt = R["ee_pose"].copy()
+    tgt[:, :, :3] += rng.normal(0.0, 0.2, size=tgt[:, :, :3].shape)
+    for dtype, tol in ((np.float64, 1e-10), (np.float32, 2e-6)):
+        osc = BatchedOSC(lay, B, dtype=dtype)
+        assert "generic" in osc.kernel_name
+        osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+        osc.set_model(model, ee_bodies=["EE"])
+        assert "_generic_" in osc.frontend_name and "through dense records" in osc.from_q_name
+        u = osc.step_from_q(qpos, qvel, tgt)
+        got = osc.download_records()
+        osc.close()
+        for k in ("M", "J", "dq", "bias", "ee_pose"):
+            scale = np.abs(R[k]).reshape(B, -1).max(axis=1).reshape((B,) + (1,) * (R[k].ndim - 1)) + 1e-300
+            assert (np.abs(np.asarray(got[k], dtype=np.float64) - R[k]) / scale).max() <= tol, k
+        if dtype == np.float64:
+            ref = osc_oracle.generate_batch(lay.as_oracle_dict(), gains, R["M"], R["J"], R["dq"], R["bias"], R["ee_pose"], tgt)
+            dom = np.array([in_parity_domain(*osc_oracle.task_inertia(R["J"][b], R["M"][b])[2:]) for b in range(B)])
+            assert dom.sum() >= B // 2 and rel_err(u.astype(np.float64), ref)[dom].max() <= TOL64
+
+
 def test_frontend_is_deterministic_and_independent_of_batch_mates():
     """The lane-per-robot front end stages its output through LDS without s_waitcnt between a wave's own writes and
     reads (in-order LDS) and parks its entries in a side buffer shared by all launches of a context: the same robots

@@ -7,9 +7,20 @@ import pytest
 from oracle import rigid_body as rb
 
 
-@pytest.fixture(scope="module")
-def model():
-    return rb.Model()
+import os
+
+MODELS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "irl_control_amd", "models")
+# two trees through the same code: the Dual-UR5 (scenes/dual_ur5.xml: branching, 25 hinges) and the single arm of
+# scenes/ur5.xml (a chain of 6 whose first body hangs on a world-fixed base)
+PROBES = {"dual_ur5": ("ur_EE_ur5right", "ur_EE_ur5left", "ur_stand_dummy", "left_inner_finger_ur5left"),
+          "ur5": ("EE", "link3", "link6")}
+
+
+@pytest.fixture(scope="module", params=["dual_ur5", "ur5"])
+def model(request):
+    m = rb.Model(os.path.join(MODELS, request.param + ".json"))
+    m.name = request.param
+    return m
 
 
 def _state(model, seed):
@@ -23,8 +34,13 @@ def _state(model, seed):
 
 
 def test_tree_matches_the_reference_scene(model):
-    # joint / actuator numbering of SURVEY.md Appendix A (scenes/dual_ur5.xml)
     names = model.raw["joint_names"]
+    if model.name == "ur5":                                   # scenes/ur5.xml:85-147: joint0..5 down one chain, motors on all six
+        assert names == [f"joint{i}" for i in range(6)] and model.raw["actuator_joints"] == names
+        assert list(np.nonzero(model.anc[model.body_id("EE")])[0]) == [0, 1, 2, 3, 4, 5]
+        assert not model.anc[model.body_id("base_link")].any()
+        return
+    # joint / actuator numbering of SURVEY.md Appendix A (scenes/dual_ur5.xml)
     assert model.nj == 25 and names[0] == "ur_stand_joint" and names[1] == "joint0_ur5right" and names[13] == "joint0_ur5left"
     assert names[10] == "right_outer_knuckle_joint_ur5right" and names[22] == "right_outer_knuckle_joint_ur5left"
     acts = [names.index(a) for a in model.raw["actuator_joints"]]
@@ -40,7 +56,7 @@ def test_jacobians_equal_finite_differences_of_the_kinematics(model, seed):
     q, _ = _state(model, seed)
     kin = rb.kinematics(model, q)
     h = 1e-6
-    for name in ("ur_EE_ur5right", "ur_EE_ur5left", "ur_stand_dummy", "left_inner_finger_ur5left"):
+    for name in PROBES[model.name]:
         b = model.body_id(name)
         jp, jr = rb.body_jacobian(model, kin, b)
         for j in range(model.nj):
@@ -60,8 +76,10 @@ def test_mass_matrix_equals_the_kinetic_energy_form(model, seed):
     assert np.allclose(M, M.T, atol=1e-14)
     assert np.allclose(M, M2, rtol=1e-12, atol=1e-13)
     assert np.linalg.eigvalsh(M).min() > 0
-    # sparsity of the Dual-UR5 tree: the two arms only couple through the stand joint
-    assert np.all(M[1:13, 13:25] == 0.0) and np.all(M[0, 1:] != 0.0)
+    if model.name == "dual_ur5":      # sparsity of the Dual-UR5 tree: the two arms only couple through the stand joint
+        assert np.all(M[1:13, 13:25] == 0.0) and np.all(M[0, 1:] != 0.0)
+    else:                             # a chain: every hinge is above or below every other one, no structural zero block
+        assert np.count_nonzero(M) > 30
 
 
 @pytest.mark.parametrize("seed", [0, 4])
@@ -82,10 +100,42 @@ def test_bias_forces_satisfy_lagranges_equations(model, seed):
     # gravity alone: zero velocity
     _, g, _ = rb.dynamics(model, q, np.zeros(n))
     assert np.allclose(g, dPE, rtol=1e-7, atol=1e-7 * np.abs(g).max())
-    assert abs(g[0]) < 1e-9          # the stand joint is vertical: gravity exerts no torque about it
+    assert abs(g[0]) < 1e-9          # the first joint of both trees is vertical: gravity exerts no torque about it
+
+
+def test_mesh_derived_inertia_of_the_base_links():
+    """scenes/dual_ur5.xml:63,164: base_link_ur5right / left carry no <inertial>; MuJoCo integrates their mesh geom (link0.stl,
+    density 1000).  tools/parse_mjcf.py did that integration in the build container; here the numbers it left in the model
+    table are checked for plausibility against the mesh's bounding cylinder (r = 73.5 mm, h = 21.3 mm: 0.361 kg when solid)
+    and for their effect: the yaw inertia of the stand joint grows by m (0.15^2 + ...) per link."""
+    m = rb.Model(os.path.join(MODELS, "dual_ur5.json"))
+    for name in ("base_link_ur5right", "base_link_ur5left"):
+        b = m.bodies[m.body_id(name)]
+        assert 0.25 < b["mass"] < 0.361 and b["inertia_from"].startswith("mesh geoms")
+        assert abs(b["ipos"][0]) < 1e-3 and abs(b["ipos"][1]) < 1e-3 and 0.005 < b["ipos"][2] < 0.0213
+        i1, i2, i3 = sorted(b["inertia"])
+        assert i1 > 0 and i1 + i2 >= i3 * (1 - 1e-9)                                       # a physical inertia tensor
+        assert abs(i3 - 0.5 * b["mass"] * 0.0735 ** 2) / i3 < 0.2                          # about the axis: ~ m r^2 / 2
+        ex = b["mesh_inertia_exact"]
+        assert 0.85 < ex["mass"] / b["mass"] < 1.0                                         # signed volumes: a little less
+    q = np.zeros(m.nj)
+    M_with = rb.mass_matrix_energy_form(m, q)[0, 0]
+    bare = rb.Model(os.path.join(MODELS, "dual_ur5.json"))
+    gain = 0.0
+    for n in ("base_link_ur5right", "base_link_ur5left"):
+        b = bare.bodies[bare.body_id(n)]
+        gain += b["mass"] * 0.15 ** 2                       # the links sit 0.15 m off the yaw axis (dual_ur5.xml:63,164)
+        b["mass"], b["inertia"] = 0.0, [0.0, 0.0, 0.0]
+    M_without = rb.mass_matrix_energy_form(bare, q)[0, 0]
+    assert gain < M_with - M_without < gain + 0.01 and (M_with - M_without) / M_with < 0.01
 
 
 def test_records_have_the_abi_layout(model):
+    if model.name != "dual_ur5":
+        lay = dict(dev_names=["arm"], ctrlr_dof=[[True] * 6])
+        r = rb.records(model, lay, dict(arm="EE"), *_state(model, 5))
+        assert r["M"].shape == (6, 6) and r["J"].shape == (6, 6) and r["ee_pose"].shape == (1, 7)
+        return
     q, qd = _state(model, 5)
     lay = dict(dev_names=["ur5right", "ur5left", "base"], ctrlr_dof=[[True] * 6, [True] * 6, [False] * 5 + [True]])
     ee = dict(base="ur_stand_dummy", ur5right="ur_EE_ur5right", ur5left="ur_EE_ur5left")
