@@ -66,20 +66,8 @@ struct irlosc_ctx {
     // fp64 row16 path: zero page for the padding lanes, worklist of the instances handed to the generic kernel, and
     // two counters used alternately (the worklist pass of a step zeroes the counter of the next one)
     void* dzeros = nullptr;
-    // Everything a train of the row16 path writes exists TWICE (halves 0 / 1, R16_TRAIN steps each): consecutive trains of
-    // irlosc_step_resident alternate halves, so that the eigen pass + give-up pass of train t (second stream) can run while
-    // the main kernel of train t + 1 (the context's stream) is already working -- the eigen stage is chains of dependent
-    // broadcast-FMAs that issue at a fraction of the main loop's rate and want a main-loop wave as SIMD-mate.
-    static constexpr int R16_SETS = 2 * R16_TRAIN;
-    int32_t* dr16_list[R16_SETS] = {};     // give-up list of each step
-    int32_t* dr16_count = nullptr;         // [2 halves][2 * R16_TRAIN]: give-up counters, then eigen-list counters
-    double* dr16_eigA[R16_SETS] = {};      // hand-over records of the flagged instances: [B][K][16]
-    double* dr16_eigw[R16_SETS] = {};      // [B][16]
-    int32_t* dr16_eiglist[R16_SETS] = {};  // [B]
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_main[2] = {}, ev_done[2] = {};
-    bool done_pending[2] = {false, false}; // ev_done[h] recorded on stream2 and not yet waited for by the context's stream
-    int overlap = 1;                       // IRLOSC_OVERLAP=0: everything in order on one stream (A/B measurements)
+    int32_t* dr16_list[R16_TRAIN] = {};    // give-up list of each step of a train
+    int32_t* dr16_count = nullptr;         // [R16_TRAIN] give-up counters, zeroed in front of every train
     // rigid-body front end (irlosc_set_model): device copy of the tables, resident joint coordinates per slot
     FeModel* dmodel = nullptr;
     size_t fe_smem = 0;
@@ -89,7 +77,7 @@ struct irlosc_ctx {
     // buffer and one buffer per step of a train
     FeCompactTables* dtables = nullptr;
     size_t fe_xentries = 0;
-    double* fe_xside[2 * R16_TRAIN] = {};
+    double* fe_xside[R16_TRAIN] = {};
     int fused = 0;
     int fused_xcd_map = 1;
     int fused_train = R16_TRAIN;
@@ -195,7 +183,7 @@ static void free_all(irlosc_ctx* c) {
     if (c->dmodel) (void)hipFree(c->dmodel);
     if (c->fe_side) (void)hipFree(c->fe_side);
     if (c->dtables) (void)hipFree(c->dtables);
-    for (int k = 0; k < 2 * R16_TRAIN; ++k) if (c->fe_xside[k]) (void)hipFree(c->fe_xside[k]);
+    for (int k = 0; k < R16_TRAIN; ++k) if (c->fe_xside[k]) (void)hipFree(c->fe_xside[k]);
     for (double* p : c->dqpos) if (p) (void)hipFree(p);
     for (double* p : c->dqvel) if (p) (void)hipFree(p);
     if (c->tick_hin) (void)hipHostFree(c->tick_hin);
@@ -203,12 +191,7 @@ static void free_all(irlosc_ctx* c) {
     if (c->tick_hout) (void)hipHostFree(c->tick_hout);
     if (c->tick_dout) (void)hipFree(c->tick_dout);
     if (c->dzeros) (void)hipFree(c->dzeros);
-    for (int k = 0; k < irlosc_ctx::R16_SETS; ++k) {
-        if (c->dr16_list[k]) (void)hipFree(c->dr16_list[k]);
-        if (c->dr16_eigA[k]) (void)hipFree(c->dr16_eigA[k]);
-        if (c->dr16_eigw[k]) (void)hipFree(c->dr16_eigw[k]);
-        if (c->dr16_eiglist[k]) (void)hipFree(c->dr16_eiglist[k]);
-    }
+    for (int k = 0; k < R16_TRAIN; ++k) if (c->dr16_list[k]) (void)hipFree(c->dr16_list[k]);
     if (c->dr16_count) (void)hipFree(c->dr16_count);
     if (c->dsym) (void)hipFree(c->dsym);
     if (c->dgains) (void)hipFree(c->dgains);
@@ -217,11 +200,6 @@ static void free_all(irlosc_ctx* c) {
     for (hipEvent_t ev : c->tev_pool) (void)hipEventDestroy(ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    for (int h = 0; h < 2; ++h) {
-        if (c->ev_main[h]) (void)hipEventDestroy(c->ev_main[h]);
-        if (c->ev_done[h]) (void)hipEventDestroy(c->ev_done[h]);
-    }
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
 }
 
@@ -258,7 +236,7 @@ static int create_impl(irlosc_ctx* c) {
     }
     if (c->kernel == IRLOSC_KERNEL_ROW16) {
         c->train = R16_TRAIN;
-        c->nsets = irlosc_ctx::R16_SETS;
+        c->nsets = R16_TRAIN;               // a train completes (give-up pass included) before the next one starts
     }
     for (int k2 = 0; k2 < c->nsets; ++k2) {
         HIPCHK(nullptr, hipMalloc(&c->du_set[k2], B * n * e));
@@ -278,23 +256,9 @@ static int create_impl(irlosc_ctx* c) {
         constexpr size_t ZB = 64 * 1024;
         HIPCHK(nullptr, hipMalloc(&c->dzeros, ZB));
         HIPCHK(nullptr, hipMemsetAsync(c->dzeros, 0, ZB, c->stream));
-        HIPCHK(nullptr, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-        for (int h = 0; h < 2; ++h) {
-            HIPCHK(nullptr, hipEventCreateWithFlags(&c->ev_main[h], hipEventDisableTiming));
-            HIPCHK(nullptr, hipEventCreateWithFlags(&c->ev_done[h], hipEventDisableTiming));
-        }
-        {
-            const char* e = getenv("IRLOSC_OVERLAP");
-            c->overlap = !(e && !strcmp(e, "0"));
-        }
-        for (int k2 = 0; k2 < irlosc_ctx::R16_SETS; ++k2) {
-            HIPCHK(nullptr, hipMalloc((void**)&c->dr16_list[k2], B * sizeof(int32_t)));
-            HIPCHK(nullptr, hipMalloc((void**)&c->dr16_eigA[k2], B * k * 16 * sizeof(double)));
-            HIPCHK(nullptr, hipMalloc((void**)&c->dr16_eigw[k2], B * 16 * sizeof(double)));
-            HIPCHK(nullptr, hipMalloc((void**)&c->dr16_eiglist[k2], B * sizeof(int32_t)));
-        }
-        HIPCHK(nullptr, hipMalloc((void**)&c->dr16_count, 4 * R16_TRAIN * sizeof(int32_t)));
-        HIPCHK(nullptr, hipMemsetAsync(c->dr16_count, 0, 4 * R16_TRAIN * sizeof(int32_t), c->stream));
+        for (int k2 = 0; k2 < R16_TRAIN; ++k2) HIPCHK(nullptr, hipMalloc((void**)&c->dr16_list[k2], B * sizeof(int32_t)));
+        HIPCHK(nullptr, hipMalloc((void**)&c->dr16_count, R16_TRAIN * sizeof(int32_t)));
+        HIPCHK(nullptr, hipMemsetAsync(c->dr16_count, 0, R16_TRAIN * sizeof(int32_t), c->stream));
     }
     c->du = c->du_set[0];
     c->dflags = c->dflags_set[0];
@@ -366,7 +330,6 @@ extern "C" void irlosc_destroy(irlosc_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.hip_device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     free_all(c);
     delete c;
 }
@@ -690,57 +653,24 @@ static int flush_pending(irlosc_ctx* c, hipStream_t st) {
 }
 
 // fp64-arithmetic path: one launch for a train of n steps (ps[i] complete with its own outputs), whatever the storage
-// type T of the records.  All instances run on the row16 kernel; the few it gives up on (net of eigen-candidates full,
-// degenerate A) are recomputed by the generic kernel (Jacobi, fp64 arithmetic) from the lists it leaves behind.
-// Passes that finish a train of the row16 path after its main kernel, on stream `st2`: the eigen pass (flagged instances,
-// four to a wave), on the fused path the dense records of the few robots the eigen stage gives up on, then the generic
-// kernel over the give-up lists.
+// type T of the records.  All instances run on the row16 kernel, the truncated pseudo-inverse included; the few it gives
+// up on (net of eigen-candidates full, degenerate A) are recomputed by the generic kernel (Jacobi, fp64 arithmetic) from
+// the lists it leaves behind.
 template <typename T>
-static int row16_after(irlosc_ctx* c, const Row16Train<T>& tr, const FeGenericArgs<T>* ga, int n, hipStream_t st2) {
-    HIPCHK(c, (hipError_t)launch_row16_eigen<T>(tr, n, ga != nullptr, st2));
-    if (ga) HIPCHK(c, (hipError_t)launch_frontend_generic_lists<T>(c->dmodel, *ga, n, c->fe_smem, st2));
-    HIPCHK(c, (hipError_t)launch_row16_worklist<T>(tr, n, nullptr, st2));
-    return IRLOSC_OK;
-}
-
-// The context's stream catches up with the second one: everything of the half's previous train is complete afterwards.
-static int wait_half(irlosc_ctx* c, int half, hipStream_t st) {
-    if (c->done_pending[half]) {
-        HIPCHK(c, hipStreamWaitEvent(st, c->ev_done[half], 0));
-        c->done_pending[half] = false;
-    }
-    return IRLOSC_OK;
-}
-
-// fp64-arithmetic path: one train of n steps (ps[i] complete with its own outputs), whatever the storage type T of the
-// records, on the buffers of `half`.  Main kernel on `st`; the passes after it on `st` too, or -- `overlap` -- on the second
-// stream behind an event, so that the caller may launch the next train (other half) right away.
-template <typename T>
-static int row16_train(irlosc_ctx* c, const KParams<T>* ps, int n, hipStream_t st, int half = 0, bool overlap = false) {
+static int row16_train(irlosc_ctx* c, const KParams<T>* ps, int n, hipStream_t st) {
     if (n < 1 || n > R16_TRAIN) return fail(c, IRLOSC_ERR_STATE, "train of %d steps", n);
-    int rc = wait_half(c, half, st);
-    if (rc) return rc;
     Row16Train<T> tr;
     memset(&tr, 0, sizeof tr);
-    int32_t* bank = c->dr16_count + half * 2 * R16_TRAIN;
-    HIPCHK(c, hipMemsetAsync(bank, 0, 2 * R16_TRAIN * sizeof(int32_t), st));
+    HIPCHK(c, hipMemsetAsync(c->dr16_count, 0, R16_TRAIN * sizeof(int32_t), st));
     for (int i = 0; i < n; ++i) {
-        const int k2 = half * R16_TRAIN + i;
         tr.p[i] = ps[i];
-        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[k2], bank + i, c->dr16_eigA[k2], c->dr16_eigw[k2], c->dr16_eiglist[k2],
-                             bank + R16_TRAIN + i, nullptr, nullptr, nullptr, 0};
+        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[i], c->dr16_count + i, nullptr, nullptr, nullptr, 0};
     }
     if (c->tev_begin) HIPCHK(c, hipEventRecord(c->tev_begin, st));
-    rc = launch_row16<T>(tr, n, st);
+    int rc = launch_row16<T>(tr, n, st);
     if (rc) return fail(c, IRLOSC_ERR_HIP, "row16 kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    HIPCHK(c, (hipError_t)launch_row16_worklist<T>(tr, n, nullptr, st));
     if (c->tev_end) HIPCHK(c, hipEventRecord(c->tev_end, st));
-    if (!overlap) return row16_after<T>(c, tr, nullptr, n, st);
-    HIPCHK(c, hipEventRecord(c->ev_main[half], st));
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_main[half], 0));
-    rc = row16_after<T>(c, tr, nullptr, n, c->stream2);
-    if (rc) return rc;
-    HIPCHK(c, hipEventRecord(c->ev_done[half], c->stream2));
-    c->done_pending[half] = true;
     return IRLOSC_OK;
 }
 
@@ -891,10 +821,8 @@ static int resident_trains(irlosc_ctx* c, int first_slot, int B, int iters, cons
 template <typename T>
 static int row16_resident(irlosc_ctx* c, int first_slot, int B, int iters, const std::vector<hipEvent_t>* evs, int skip) {
     int done = 0, launch_no = 0;
-    const bool overlap = c->overlap != 0;
     while (done < iters) {
         const int n = std::min((int)R16_TRAIN, iters - done);
-        const int half = launch_no & 1;
         KParams<T> ps[R16_TRAIN];
         for (int i = 0; i < n; ++i) {
             const int slot = (first_slot + done + i) % c->cfg.n_slots;
@@ -902,22 +830,18 @@ static int row16_resident(irlosc_ctx* c, int first_slot, int B, int iters, const
             if (rcf) return rcf;
             fill_params<T>(c, ps[i], B, c->dM[slot], c->dJ[slot], c->ddq[slot], c->dbias[slot], c->dee[slot], c->dtgt[slot],
                            c->has_tvel[slot] ? c->dtvel[slot] : nullptr, c->has_wrench[slot] ? c->dwrench[slot] : nullptr,
-                           c->du_set[half * R16_TRAIN + i], c->dflags_set[half * R16_TRAIN + i]);
+                           c->du_set[i], c->dflags_set[i]);
         }
         if (evs && launch_no >= skip && 2 * (launch_no - skip) + 1 < (int)evs->size()) {
             c->tev_begin = (*evs)[2 * (launch_no - skip)];
             c->tev_end = (*evs)[2 * (launch_no - skip) + 1];
         }
-        int rc = row16_train<T>(c, ps, n, c->stream, half, overlap);
+        int rc = row16_train<T>(c, ps, n, c->stream);
         c->tev_begin = c->tev_end = nullptr;
         if (rc) return rc;
-        c->cur = half * R16_TRAIN + n - 1;
+        c->cur = n - 1;
         done += n;
         ++launch_no;
-    }
-    for (int h = 0; h < 2; ++h) {
-        int rc = wait_half(c, h, c->stream);
-        if (rc) return rc;
     }
     c->du = c->du_set[c->cur];
     c->dflags = c->dflags_set[c->cur];
@@ -1102,7 +1026,7 @@ extern "C" int irlosc_set_model(irlosc_ctx* c, const irlosc_model* m) {
         HIPCHK(c, hipMemcpyAsync(c->dtables, &t, sizeof t, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));      // t lives on this stack frame
         const size_t waves = ((size_t)c->cfg.max_batch + 63) / 64;
-        for (int k2 = 0; k2 < 2 * R16_TRAIN; ++k2)
+        for (int k2 = 0; k2 < R16_TRAIN; ++k2)
             if (!c->fe_xside[k2]) HIPCHK(c, hipMalloc((void**)&c->fe_xside[k2], waves * c->fe_xentries * 64 * sizeof(double)));
     }
     HIPCHK(c, hipMemcpyAsync(c->dmodel, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
@@ -1200,68 +1124,51 @@ static int check_slot_q(irlosc_ctx* c, int slot, int B) {
 // eigen stage hands over get their dense records from the wave-per-robot front end (worklist form) and go through the
 // generic kernel like on the record path.  Dense M / J exist in HBM for those robots only.
 template <typename T>
-static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, hipStream_t st, int half, bool overlap) {
+static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, hipStream_t st) {
     if (n < 1 || n > R16_TRAIN) return fail(c, IRLOSC_ERR_STATE, "train of %d steps", n);
-    int rc = wait_half(c, half, st);
-    if (rc) return rc;
     FeLaneTrain ft;
     memset(&ft, 0, sizeof ft);
     Row16Train<T> tr;
     memset(&tr, 0, sizeof tr);
     FeGenericArgs<T> ga;
     memset(&ga, 0, sizeof ga);
-    int32_t* bank = c->dr16_count + half * 2 * R16_TRAIN;
-    HIPCHK(c, hipMemsetAsync(bank, 0, 2 * R16_TRAIN * sizeof(int32_t), st));
+    HIPCHK(c, hipMemsetAsync(c->dr16_count, 0, R16_TRAIN * sizeof(int32_t), st));
     ft.B = ga.B = B;
     for (int i = 0; i < n; ++i) {
-        const int sl = slots[i], k2 = half * R16_TRAIN + i;
+        const int sl = slots[i];
         ft.qpos[i] = ga.qpos[i] = c->dqpos[sl];
         ft.qvel[i] = ga.qvel[i] = c->dqvel[sl];
-        ft.side[i] = c->fe_xside[k2];
+        ft.side[i] = c->fe_xside[i];
         fill_params<T>(c, tr.p[i], B, c->dM[sl], c->dJ[sl], c->ddq[sl], c->dbias[sl], c->dee[sl], c->dtgt[sl],
-                       c->has_tvel[sl] ? c->dtvel[sl] : nullptr, c->has_wrench[sl] ? c->dwrench[sl] : nullptr, c->du_set[k2], c->dflags_set[k2]);
-        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[k2], bank + i, c->dr16_eigA[k2], c->dr16_eigw[k2], c->dr16_eiglist[k2],
-                             bank + R16_TRAIN + i, c->fe_xside[k2], c->dqvel[sl], c->dtables, c->fused_xcd_map};
+                       c->has_tvel[sl] ? c->dtvel[sl] : nullptr, c->has_wrench[sl] ? c->dwrench[sl] : nullptr, c->du_set[i], c->dflags_set[i]);
+        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[i], c->dr16_count + i, c->fe_xside[i], c->dqvel[sl], c->dtables, c->fused_xcd_map};
         ga.out[i] = FeOut<T>{(T*)c->dM[sl], (T*)c->dJ[sl], (T*)c->ddq[sl], (T*)c->dbias[sl], (T*)c->dee[sl]};
-        ga.list[i] = c->dr16_list[k2];
-        ga.count[i] = bank + i;
+        ga.list[i] = c->dr16_list[i];
+        ga.count[i] = c->dr16_count + i;
     }
     if (c->tev_begin) HIPCHK(c, hipEventRecord(c->tev_begin, st));
     HIPCHK(c, (hipError_t)launch_frontend_lane_compact_dual_ur5(c->dmodel, ft, n, st));
     HIPCHK(c, (hipError_t)launch_row16_fromq<T>(tr, n, st));
+    HIPCHK(c, (hipError_t)launch_frontend_generic_lists<T>(c->dmodel, ga, n, c->fe_smem, st));
+    HIPCHK(c, (hipError_t)launch_row16_worklist<T>(tr, n, nullptr, st));
     if (c->tev_end) HIPCHK(c, hipEventRecord(c->tev_end, st));
-    if (!overlap) return row16_after<T>(c, tr, &ga, n, st);
-    HIPCHK(c, hipEventRecord(c->ev_main[half], st));
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_main[half], 0));
-    rc = row16_after<T>(c, tr, &ga, n, c->stream2);
-    if (rc) return rc;
-    HIPCHK(c, hipEventRecord(c->ev_done[half], c->stream2));
-    c->done_pending[half] = true;
     return IRLOSC_OK;
 }
 
 static int fused_resident(irlosc_ctx* c, int first_slot, int B, int iters) {
-    int done = 0, launch_no = 0;
-    const bool overlap = c->overlap != 0;
+    int done = 0;
     while (done < iters) {
         const int n = std::min(c->fused_train, iters - done);
-        const int half = launch_no & 1;
         int slots[R16_TRAIN];
         for (int i = 0; i < n; ++i) {
             slots[i] = (first_slot + done + i) % c->cfg.n_slots;
             int rc = check_slot_q(c, slots[i], B);
             if (rc) return rc;
         }
-        int rc = c->cfg.dtype == IRLOSC_F64 ? fused_train<double>(c, slots, n, B, c->stream, half, overlap)
-                                            : fused_train<float>(c, slots, n, B, c->stream, half, overlap);
+        int rc = c->cfg.dtype == IRLOSC_F64 ? fused_train<double>(c, slots, n, B, c->stream) : fused_train<float>(c, slots, n, B, c->stream);
         if (rc) return rc;
-        c->cur = half * R16_TRAIN + n - 1;
+        c->cur = n - 1;
         done += n;
-        ++launch_no;
-    }
-    for (int h = 0; h < 2; ++h) {
-        int rc = wait_half(c, h, c->stream);
-        if (rc) return rc;
     }
     c->du = c->du_set[c->cur];
     c->dflags = c->dflags_set[c->cur];

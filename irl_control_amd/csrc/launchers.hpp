@@ -23,8 +23,6 @@ int launch_row16(const Row16Train<TIN>& tr, int nsteps, hipStream_t st);
 template <typename TIN>
 int launch_row16_fromq(const Row16Train<TIN>& tr, int nsteps, hipStream_t st);
 template <typename TIN>
-int launch_row16_eigen(const Row16Train<TIN>& tr, int nsteps, bool fromq, hipStream_t st);
-template <typename TIN>
 int launch_row16_worklist(const Row16Train<TIN>& tr, int nsteps, int32_t* reset, hipStream_t st);
 
 // tu_frontend.hip / tu_frontend_lane.hip -- rigid-body front end (osc_frontend.hpp, osc_frontend_lane.hpp); TOUT = record type

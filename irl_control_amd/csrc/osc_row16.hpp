@@ -423,12 +423,6 @@ struct Row16Extra {
     const void* zeros;         // >= 32 * 32 * 8 bytes of zeros
     int32_t* worklist;         // [B]
     int32_t* workcount;        // counter of this step (zero on entry)
-    // Eigen pass: the instances whose k x k solve is not certifiably the reference's inverse branch are handed to
-    // osc_row16_eigen_kernel, four of them per wave (see there): their A = J M^-1 J^T and task vector w, and their ids
-    double* eig_A;             // [B][K][16]: column c (= row c) of A in lane c
-    double* eig_w;             // [B][16]
-    int32_t* eig_list;         // [B]
-    int32_t* eig_count;        // counter of this step (zero on entry)
     // FROMQ (the fused path from joint coordinates): M, J, bias and the end-effector poses are not records in HBM but
     // entries of the compact exchange buffer the lane-per-robot walk left behind (osc_frontend_lane.hpp), dq is qvel
     const double* side;        // [walk wave][entry][64 robots]
@@ -469,7 +463,6 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
     __shared__ double Dxl[4][16];              // dx for the target-velocity branch
     __shared__ double Kvl[4][4];
     __shared__ int Brl[4][4];
-    __shared__ int Eil[4];                     // hand-over slot of a flagged instance in the eigen list
 
     __shared__ uint32_t Mt[FROMQ ? N * 32 : 1];      // FROMQ: byte offset of the entry of M[j][i] at [j * 32 + i], of J[r][i] at [r * 32 + i]
     __shared__ uint32_t Jt[FROMQ ? K * 32 : 1];
@@ -775,24 +768,19 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
         fmac_bc_n_nop<i>(t, t, G[i]);
     });
     IRLOSC_TS(5);
-    // Instances that are not certifiably on the reference's inverse branch need the truncated pseudo-inverse (osc.py:55),
-    // an iteration of ~5 600 instructions that 11 % of the instances of the benchmark batch want -- but 37 % of the WAVES
-    // if it ran here (one flagged instance makes its three wave-mates wait).  So they are handed over instead: A, w and the
-    // id go to the step's eigen list, this wave finishes the instance with t = 0 (u without the task term), and
-    // osc_row16_eigen_kernel completes it, four flagged instances to a wave.
+    // Instances that are not certifiably on the reference's inverse branch: truncated pseudo-inverse (osc.py:55).
+    // Wave-uniform branch: the whole wave runs it (DPP sources must be active lanes), the others keep their t.
+    // (Handing the flagged instances to a pass of their own, four to a wave, was built and measured in round 3: the main
+    // kernel drops from 1 212 to 1 045 us per train of 8 and the pass costs 140 us -- zero-sum.  eigen16 is chains of
+    // dependent broadcast-FMAs that issue at a fraction of the main loop's rate; here they hide behind the wave-mate's
+    // main loop, in a pass of their own two such chains share a SIMD.  profiles/r03c_eigen_handover_experiment_*.)
+    bool giveup = false;
     if (__any(!plain)) {
-        const bool hand = !plain && live;
-        if (hand && l == 0) Eil[q] = atomicAdd(x.eig_count, 1);
-        lds_sync();
-        if (hand) {
-            const int sidx = Eil[q];
-            double* __restrict__ ha = x.eig_A + (size_t)sidx * (K * 16) + l;
-#pragma unroll
-            for (int r = 0; r < K; ++r) ha[r * 16] = Ac[r];
-            x.eig_w[(size_t)sidx * 16 + l] = w;
-            if (l == 0) x.eig_list[sidx] = b;
-        }
-        t = plain ? t : 0.0;
+        double t2 = 0.0;
+        uint32_t f2 = 0;
+        eigen16<K>(Ac, F, G, invd_own, pdA, nA2, trA, w, l, !plain, t2, f2, giveup);
+        t = plain ? t : t2;
+        flags |= plain ? 0u : f2;
     }
 
     IRLOSC_TS(6);
@@ -823,8 +811,8 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
     u1 += (double)bias1_in;
     u0 -= kvn * mdq0;
     u1 -= kvn * mdq1;
-    u0 -= jt0;                       // the task term last: for a handed-over instance it is exactly zero here and the
-    u1 -= jt1;                       // eigen pass subtracts it from the stored value -- the same operation on the same numbers
+    u0 -= jt0;                       // the task term last
+    u1 -= jt1;
     const bool bad = !t_finite(u0) || (v1 && !t_finite(u1));
     flags |= bad ? IRLOSC_FLAG_NONFINITE : 0u;
     // flags of the instance = OR over its 16 lanes
@@ -836,7 +824,10 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
     if (live) {
         p.u[(size_t)b * N + l] = (TIN)u0;
         if (v1) p.u[(size_t)b * N + 16 + l] = (TIN)u1;
-        if (l == 0) p.flags[b] = flags;
+        if (l == 0) {
+            p.flags[b] = flags;
+            if (giveup) x.worklist[atomicAdd(x.workcount, 1)] = b;
+        }
     }
     IRLOSC_TS(7);
     if (p.dbg && lane == 0) {
@@ -848,128 +839,18 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
 #undef IRLOSC_TS
 }
 
-// Eigen pass of a train (blockIdx.y = step): the instances osc_row16_kernel handed over, FOUR TO A WAVE, grid-strided over
-// the step's list.  Per instance: A and w back from the hand-over record (column c of A in lane c), the L~ D L~^T
-// factorisation and trace(A^-1) again (~500 instructions: cheaper than carrying F, G and the rest through HBM), eigen16,
-// then u -= J^T t on the torques the main kernel stored without the task term, the TRUNCATED / NONFINITE flags, and the
-// give-up list for the generic kernel.  Every quantity of eigen16 is frozen at the instance's own convergence, so which
-// instances share a wave changes no bit.
-template <int K, int NDEV, typename TIN, int N, bool FROMQ = false>
-__global__ __launch_bounds__(64, 2) void osc_row16_eigen_kernel(const Row16Train<TIN> tr) {
-    using namespace r16;
-    const KParams<TIN>& p = tr.p[blockIdx.y];
-    const Row16Extra& x = tr.x[blockIdx.y];
-    constexpr int N1 = N - 16;
-    const int lane = threadIdx.x, q = lane >> 4, l = lane & 15;
-    const bool v1 = l < N1;
-    __shared__ double Pk[(2 * K + 2) * 64];     // [value][lane]: each lane parks and fetches its own words only
-    const int count = min(*x.eig_count, p.B);
-    for (int it0 = blockIdx.x * 4; it0 < count; it0 += gridDim.x * 4) {
-        const int it = it0 + q;
-        const bool live = it < count;
-        const int itc = live ? it : count - 1;
-        const int b = x.eig_list[itc];
-        // A (column c in lane c), w
-        double Ac[K], A[K];
-        const double* __restrict__ ha = x.eig_A + (size_t)itc * (K * 16) + l;
-#pragma unroll
-        for (int r = 0; r < K; ++r) { Ac[r] = ha[r * 16]; A[r] = Ac[r]; }
-        const double w = x.eig_w[(size_t)itc * 16 + l];
-        // J rows of the own joints and the stored torques, for u -= J^T t: requested now, parked in LDS until eigen16 is
-        // through (held in registers they push eigen16 into scratch: 52 + 4 VGPRs on top of its ~200)
-        {
-            double jr0[K], jr1[K];
-            if constexpr (FROMQ) {
-                const FeCompactTables* __restrict__ tb = x.tables;
-                const double* __restrict__ sb = x.side + ((size_t)(b >> 6) * tb->n_entries * 64 + (b & 63));
-#pragma unroll
-                for (int r = 0; r < K; ++r) {
-                    jr0[r] = sb[(size_t)tb->jtab[r][l] * 64];
-                    jr1[r] = sb[(size_t)tb->jtab[r][16 + l] * 64];
-                }
-            } else {
-                const TIN* __restrict__ Jb = p.J + (size_t)b * (K * N);
-#pragma unroll
-                for (int r = 0; r < K; ++r) { jr0[r] = (double)Jb[r * N + l]; jr1[r] = v1 ? (double)Jb[r * N + 16 + l] : 0.0; }
-            }
-            const double u0 = (double)p.u[(size_t)b * N + l];
-            const double u1 = v1 ? (double)p.u[(size_t)b * N + 16 + l] : 0.0;
-#pragma unroll
-            for (int r = 0; r < K; ++r) { Pk[(2 * r) * 64 + lane] = jr0[r]; Pk[(2 * r + 1) * 64 + lane] = jr1[r]; }
-            Pk[(2 * K) * 64 + lane] = u0;
-            Pk[(2 * K + 1) * 64 + lane] = u1;
-        }
-        // the factorisation and the trace certificate exactly as in the main kernel
-        double nA2 = 0.0;
-#pragma unroll
-        for (int r = 0; r < K; ++r) nA2 = fma(A[r], A[r], nA2);
-        nA2 = row_sum(nA2);
-        double F[K], G[K];
-        double invd_own = 0.0, detA = 1.0;
-        bool pdA = true;
-        ldl16<K>(A, l, 0.0, F, G, invd_own, pdA, detA);
-        double X[K];
-#pragma unroll
-        for (int m = 0; m < K; ++m) X[m] = (l == m) ? 1.0 : 0.0;
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<0, K - 1>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            static_for<0, j + 1>([&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                if constexpr (j < 3 || m == 0) fmac_bc_n_nop<j>(X[m], X[m], F[j]);
-                else fmac_bc_n<j>(X[m], X[m], F[j]);
-            });
-        });
-        __builtin_amdgcn_sched_barrier(0);
-        double trA = 0.0;
-#pragma unroll
-        for (int m = 0; m < K; ++m) trA = fma(X[m], X[m], trA);
-        trA = row_sum(trA * invd_own);
-        double t = 0.0;
-        uint32_t f2 = 0;
-        bool giveup = false;
-        eigen16<K>(Ac, F, G, invd_own, pdA, nA2, trA, w, l, true, t, f2, giveup);
-        double jt0 = 0.0, jt1 = 0.0;
-        double jr0[K], jr1[K];
-#pragma unroll
-        for (int r = 0; r < K; ++r) { jr0[r] = Pk[(2 * r) * 64 + lane]; jr1[r] = Pk[(2 * r + 1) * 64 + lane]; }
-        double u0 = Pk[(2 * K) * 64 + lane], u1 = Pk[(2 * K + 1) * 64 + lane];
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<0, K>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            if constexpr (r == 0) fmac_bc_nop<r>(jt0, t, jr0[r]);
-            else fmac_bc<r>(jt0, t, jr0[r]);
-            fmac_bc<r>(jt1, t, jr1[r]);
-        });
-        __builtin_amdgcn_sched_barrier(0);
-        u0 -= jt0;
-        u1 -= jt1;
-        const bool bad = !t_finite(u0) || (v1 && !t_finite(u1));
-        const unsigned long long mbad = __ballot(bad);
-        if ((mbad >> (q * 16)) & 0xffffull) f2 |= IRLOSC_FLAG_NONFINITE;
-        if (live) {
-            p.u[(size_t)b * N + l] = (TIN)u0;
-            if (v1) p.u[(size_t)b * N + 16 + l] = (TIN)u1;
-            if (l == 0) {
-                if (f2) p.flags[b] |= f2;
-                if (giveup) x.worklist[atomicAdd(x.workcount, 1)] = b;
-            }
-        }
-    }
-}
-
 // The generic kernel over a worklist: instance ids list[0..*count); zeroes *reset for the step after.
 // T = arithmetic type, S = storage type of the records (S = float, T = double on the mixed path).
 template <typename T, typename S>
-__global__ __launch_bounds__(64) void osc_generic_worklist_kernel(const Row16Train<S> tr, int32_t* __restrict__ reset) {   // reset: optional, 2 * R16_TRAIN counters to zero
+__global__ __launch_bounds__(64) void osc_generic_worklist_kernel(const Row16Train<S> tr, int32_t* __restrict__ reset) {   // reset: optional, R16_TRAIN counters to zero
     extern __shared__ __align__(16) unsigned char smem_raw_w[];
     T* smem = reinterpret_cast<T*>(smem_raw_w);
     const KParams<S>& p = tr.p[blockIdx.y];
     const int32_t* __restrict__ list = tr.x[blockIdx.y].worklist;
     const int n = *tr.x[blockIdx.y].workcount;
-    // (The counters of a train are zeroed by the host with a memset in front of its main kernel -- ALL 2 * R16_TRAIN of its
-    // half, whatever the train's length: a shorter train must not inherit what a longer one counted.)
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2 * R16_TRAIN && reset) reset[threadIdx.x] = 0;
+    // (The give-up counters of a train are zeroed by the host with a memset in front of its main kernel -- ALL R16_TRAIN of
+    // them, whatever the train's length: a shorter train must not inherit what a longer one counted.)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < R16_TRAIN && reset) reset[threadIdx.x] = 0;
     for (int it = blockIdx.x; it < n; it += gridDim.x) generic_instance<T>(p, list[it], smem);
 }
 

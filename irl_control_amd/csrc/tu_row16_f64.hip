@@ -34,26 +34,6 @@ int launch_row16_fromq(const Row16Train<TIN>& tr, int nsteps, hipStream_t st) {
 }
 
 
-// Eigen pass of a train: the flagged instances of each step, four to a wave, grid-strided over the device-side lists.
-template <typename TIN>
-int launch_row16_eigen(const Row16Train<TIN>& tr, int nsteps, bool fromq, hipStream_t st) {
-    const KParams<TIN>& p = tr.p[0];
-    if (p.B <= 0 || nsteps <= 0) return 0;
-    const int blocks = (p.B + 3) / 4 < 2048 ? (p.B + 3) / 4 : 2048;
-    const dim3 grid(blocks, nsteps);
-#define IRLOSC_EIGEN_LAUNCH(KK, ND)                                                                                      \
-    do {                                                                                                                 \
-        if (fromq) hipLaunchKernelGGL((osc_row16_eigen_kernel<KK, ND, TIN, 25, true>), grid, dim3(64), 0, st, tr);       \
-        else hipLaunchKernelGGL((osc_row16_eigen_kernel<KK, ND, TIN, 25, false>), grid, dim3(64), 0, st, tr);            \
-    } while (0)
-    if (p.k == 13 && p.ndev == 3) IRLOSC_EIGEN_LAUNCH(13, 3);
-    else if (p.k == 12 && p.ndev == 2) IRLOSC_EIGEN_LAUNCH(12, 2);
-    else if (p.k == 7 && p.ndev == 3) IRLOSC_EIGEN_LAUNCH(7, 3);
-    else return (int)hipErrorNotSupported;
-#undef IRLOSC_EIGEN_LAUNCH
-    return (int)hipGetLastError();
-}
-
 // The generic kernel (Jacobi, fp64 arithmetic) over the give-up lists of a train; zeroes the counters `reset` points at.
 template <typename TIN>
 int launch_row16_worklist(const Row16Train<TIN>& tr, int nsteps, int32_t* reset, hipStream_t st) {
@@ -65,7 +45,6 @@ int launch_row16_worklist(const Row16Train<TIN>& tr, int nsteps, int32_t* reset,
 
 template int launch_row16<double>(const Row16Train<double>&, int, hipStream_t);
 template int launch_row16_fromq<double>(const Row16Train<double>&, int, hipStream_t);
-template int launch_row16_eigen<double>(const Row16Train<double>&, int, bool, hipStream_t);
 template int launch_row16_worklist<double>(const Row16Train<double>&, int, int32_t*, hipStream_t);
 
 }  // namespace irlosc
