@@ -11,7 +11,7 @@ batches are rotated so that successive launches do not re-hit the 256 MiB Infini
 --dtype names the ARITHMETIC of the measured path:
   f64    float64 records, float64 arithmetic (osc_row16 kernel)  - the reference's precision, meets north_star's 1e-5
   mixed  float32 records, float64 arithmetic (osc_row16 kernel)  - BASELINE configs[2]'s fp32 storage at the 1e-5 bar
-  f32    float32 records, float32 arithmetic (osc_group kernel)  - fastest; error ~ eps32 * cond(J M^-1 J^T)
+  f32    float32 records, float32 arithmetic (osc_group kernel)  - fastest, does NOT meet 1e-5: error ~ eps32 * cond(J M^-1 J^T)
 The JSON line's "dtype" is the arithmetic type ("f64" for f64 and mixed); config.records names the storage.
 
 Instances shard across GPUs with no data-path collective (weak scaling: B per GPU is fixed; `--total-batch T`
@@ -44,8 +44,8 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 lanes x 2 flop (FMA) x 2.4 GHz: v_fma_f64 issues at the full VALU rate
 # Useful fp64 flops of one control step from joint coordinates (FMA = 2; DESIGN.md section 5 derives both figures):
-FLOPS_OSC_STEP = {"k13": 23.0e3, "k12_admit": 21.6e3, "k7": 14.6e3}    # Cholesky, substitution, J M^-1 J^T, k x k, torques
-FLOPS_FRONT_END = 21.5e3                                                # FK, EE Jacobians, CRBA, RNEA of the Dual-UR5 tree
+FLOPS_OSC_STEP = {"k13": 23.3e3, "k12_admit": 21.6e3, "k7": 14.2e3}    # Cholesky, substitution, J M^-1 J^T, k x k, torques
+FLOPS_FRONT_END = 20.1e3                                                # FK, EE Jacobians, CRBA, RNEA of the Dual-UR5 tree (counted in the ISA)
 MODES = {   # --dtype -> (record dtype, arithmetic label, kernel id)
     "f64": (np.float64, "f64", 0),
     "mixed": (np.float32, "f64", 3),
@@ -302,6 +302,7 @@ def measure_from_q(BatchedOSC, synth, args, B, local_rank, state0=None, ref_u=No
         res = dict(value=B * steps / el, unit="steps/s", ms_per_step=el / steps * 1e3, ms_per_step_events=ms_step,
                    ms_osc_step_on_records_alone=ms_osc, kernel=osc.from_q_name,
                    input_bytes_per_step_per_instance=2 * lay.n * 8 + 7 * lay.ndev * esz,
+                   hbm_traffic_bytes_per_step_per_instance=_fromq_traffic(osc.from_q_name, B),
                    roofline=dict(bound="fp64_valu", achieved=achieved, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
                                  frac=achieved / FP64_VALU_PEAK_TFLOPS, flops_per_step_per_instance=flops,
                                  note="useful fp64 flops (FMA = 2) of front end + OSC step, DESIGN.md section 5; HBM sees "
@@ -318,6 +319,17 @@ def measure_from_q(BatchedOSC, synth, args, B, local_rank, state0=None, ref_u=No
         return res
     except Exception as e:                              # never break the bench line
         return dict(error=str(e))
+
+
+def _fromq_traffic(name, B):
+    """HBM bytes per robot and step of the fused path from the committed PMC passes (profiles/hbm_traffic.json: walk + OSC
+    kernel, FETCH_SIZE x2 + WRITE_SIZE; an upper bound for the gathered 8-byte loads), or None."""
+    if "fused" not in name:
+        return None
+    a, b = measured_profile("osc_frontend_lane_compact_dual_ur5"), measured_profile("osc_row16_f64_n25_k13_fromq")
+    if not a or not b or a.get("instances") != B or b.get("instances") != B:
+        return None
+    return (a["traffic_bytes_per_launch"] + b["traffic_bytes_per_launch"]) / (a["steps_per_launch"] * a["instances"])
 
 
 def _parity_plain(u, ref, tol, note):

@@ -18,5 +18,6 @@ fdb=$(find gpurun_out/pmc_fetch_$tag -name "*.db" | head -1); wdb=$(find gpurun_
 if [ -n "$fdb" ] && [ -n "$wdb" ]; then
   python tools/pmc_dump.py "$fdb" osc_ > gpurun_out/pmc_fetch_size_$tag.txt; cat gpurun_out/pmc_fetch_size_$tag.txt
   python tools/pmc_dump.py "$wdb" osc_ > gpurun_out/pmc_write_size_$tag.txt; cat gpurun_out/pmc_write_size_$tag.txt
-  python tools/pmc_traffic.py "$fdb" "$wdb" "$kern" "$key" gpurun_out/hbm_traffic_$tag.json
+  python tools/pmc_traffic.py "$fdb" "$wdb" "$kern" "$key" gpurun_out/hbm_traffic_$tag.json "$db" ${INSTANCES:-65536} ${SPL:-8}
+  python tools/rocprof_gaps.py "$db" 200 > gpurun_out/kernel_gaps_$tag.txt; cat gpurun_out/kernel_gaps_$tag.txt
 fi
