@@ -104,10 +104,12 @@ constexpr int FE_TRAIN = 8;
 // or above j, the Jacobian columns and the pose of the end-effector bodies, the bias forces -- plus one entry of zeros that
 // every structural zero points at.  Built on the host from the compiled tree shape (tu_frontend_lane_f64.hip).
 struct FeCompactTables {
-    uint16_t mtab[32][32];                    // [column j][row i]: entry of M[i][j] = M[j][i]
-    uint16_t jtab[IRLOSC_MAX_K][32];          // [task row r][joint i]: entry of J[r][i]
-    uint16_t eetab[IRLOSC_MAX_DEV][8];        // [device d][0..6]: x y z qw qx qy qz of its end effector
-    uint16_t btab[32];                        // [joint i]: bias force
+    // BYTE offsets of the entries inside a walk wave's block (entry index x 512), 16-byte aligned arrays: the OSC kernel
+    // copies them into LDS with a handful of 16-byte loads per lane
+    alignas(16) uint32_t mt_off[32 * 32];              // [column j * 32 + row i]: M[i][j] = M[j][i]
+    alignas(16) uint32_t jt_off[IRLOSC_MAX_K * 32];    // [task row r * 32 + joint i]: J[r][i]
+    uint16_t eetab[IRLOSC_MAX_DEV][8];                 // entry indices: [device d][0..6] = x y z qw qx qy qz of its end effector
+    uint16_t btab[32];                                 // [joint i]: bias force
     uint16_t zero, n_entries;
 };
 

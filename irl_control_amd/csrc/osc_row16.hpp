@@ -36,6 +36,7 @@
 
 #include "osc_common.hpp"
 #include "osc_frontend.hpp"      // FeCompactTables: the exchange buffer of the fused path (FROMQ)
+#include "osc_frontend_lane.hpp" // FeTopo: compile-time queries on a tree shape (FROMQ with a compiled topology)
 #include "osc_row16_asm.hpp"     // generated: the main loop's broadcast-FMA chains as asm blocks
 
 namespace irlosc {
@@ -405,6 +406,21 @@ __device__ __forceinline__ void apply_gains6_fast(const double* __restrict__ g, 
     }
 }
 
+// Compile-time shape queries for the tree-structured factorisation (hinge numbering = MuJoCo's depth-first order)
+template <class TOPO>
+constexpr int tree_subtree_size(int j) {
+    int n = 0;
+    for (int c = 0; c < TOPO::NJ; ++c) n += FeTopo<TOPO>::above(j, c) ? 1 : 0;
+    return n;
+}
+template <class TOPO>
+constexpr bool tree_subtree_contiguous(int j) {
+    const int sz = tree_subtree_size<TOPO>(j);
+    for (int c = 0; c < TOPO::NJ; ++c)
+        if (FeTopo<TOPO>::above(j, c) != (c >= j && c < j + sz)) return false;
+    return true;
+}
+
 // LDS hand-over inside ONE wave (64-thread blocks): DS operations of a wave execute in order, so a compile-time
 // ordering point plus "all my DS operations are done" is a complete synchronisation.  __syncthreads() would also drain
 // every global load in flight (its fence covers all address spaces: s_waitcnt vmcnt(0)), i.e. the prefetched M stream.
@@ -449,9 +465,19 @@ struct Row16Train {
 // qvel.  A walk wave's block [entry][64 robots] is consumed by 16 blocks of this kernel (4 robots each); the
 // blockIdx -> robots map keeps those 16 on ONE XCD (blockIdx.x % 8), so that the 128-byte lines they share are fetched
 // into one L2 only.  Targets, gains, wrench, outputs stay records of type TIN.
-template <int K, int NDEV, typename TIN, int N, bool FROMQ = false>
+//
+// TOPO (FROMQ only): the compiled tree shape of the model.  The joint-space inertia of a TREE factors without fill-in when
+// the hinges are eliminated leaves first: M = L^T L with L[c][i] != 0 only for i at or above c.  In MuJoCo's depth-first
+// numbering that is the Cholesky recursion run from the LAST column to the first, and column j only needs the terms
+// c in subtree(j) \ {j} = j + 1 .. j + size(j) - 1, a contiguous run known at compile time: for the Dual-UR5 130 column terms
+// instead of the 300 of a dense 25 x 25 factorisation, and two instead of three chains for the columns below 16 (their
+// slot-1 rows are already eliminated) -- 283 broadcast-FMAs per wave instead of 745.  The entries of unrelated pairs come out
+// as exact zeros (0 - sum of products with exact zeros, scaled), so nothing has to be masked; Y = L^-T J^T rides along as
+// before and J M^-1 J^T = Y^T Y is the same identity.  Records of unknown origin (TOPO = void) keep the dense recursion.
+template <int K, int NDEV, typename TIN, int N, bool FROMQ = false, class TOPO = void>
 __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> tr) {
     using namespace r16;
+    constexpr bool TREE = FROMQ && !std::is_void_v<TOPO>;
     const KParams<TIN>& p = tr.p[blockIdx.y];
     const Row16Extra& x = tr.x[blockIdx.y];
     using TM = std::conditional_t<FROMQ, double, TIN>;      // type the M / J / dq / bias operands arrive in
@@ -464,8 +490,8 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
     __shared__ double Kvl[4][4];
     __shared__ int Brl[4][4];
 
-    __shared__ uint32_t Mt[FROMQ ? N * 32 : 1];      // FROMQ: byte offset of the entry of M[j][i] at [j * 32 + i], of J[r][i] at [r * 32 + i]
-    __shared__ uint32_t Jt[FROMQ ? K * 32 : 1];
+    __shared__ __align__(16) uint32_t Mt[FROMQ ? N * 32 : 4];      // FROMQ: byte offset of the entry of M[j][i] at [j * 32 + i],
+    __shared__ __align__(16) uint32_t Jt[FROMQ ? K * 32 : 4];      // of J[r][i] at [r * 32 + i]
     const int lane = threadIdx.x, q = lane >> 4, l = lane & 15;
     int blk = blockIdx.x;
     if constexpr (FROMQ) {      // block x + 8 (s + 16 t) -> walk wave 8 t + x, robots 4 s .. 4 s + 3 of it
@@ -486,9 +512,21 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
     const char* sbase = nullptr;
     unsigned lane_off = 0;
     if constexpr (FROMQ) {
+        // the entry tables into LDS: all 16-byte loads of the wave issued before the first one is waited for (copied word
+        // by word in a loop, every round trip to L2 was paid in turn: 8 us of a wave's 22 us of residency)
         const FeCompactTables* __restrict__ tb = x.tables;
-        for (int e = lane; e < N * 32; e += 64) Mt[e] = ((unsigned)tb->mtab[e >> 5][e & 31] << 9);
-        for (int e = lane; e < K * 32; e += 64) Jt[e] = ((unsigned)tb->jtab[e >> 5][e & 31] << 9);
+        constexpr int MQ = N * 8, JQ = K * 8;                    // 16-byte pieces of the two tables
+        const uint4* __restrict__ msrc = reinterpret_cast<const uint4*>(tb->mt_off);
+        const uint4* __restrict__ jsrc = reinterpret_cast<const uint4*>(tb->jt_off);
+        uint4 mv[(MQ + 63) / 64], jv[(JQ + 63) / 64];
+#pragma unroll
+        for (int i = 0; i < (MQ + 63) / 64; ++i) mv[i] = msrc[min(lane + 64 * i, MQ - 1)];
+#pragma unroll
+        for (int i = 0; i < (JQ + 63) / 64; ++i) jv[i] = jsrc[min(lane + 64 * i, JQ - 1)];
+#pragma unroll
+        for (int i = 0; i < (MQ + 63) / 64; ++i) if (lane + 64 * i < MQ) reinterpret_cast<uint4*>(Mt)[lane + 64 * i] = mv[i];
+#pragma unroll
+        for (int i = 0; i < (JQ + 63) / 64; ++i) if (lane + 64 * i < JQ) reinterpret_cast<uint4*>(Jt)[lane + 64 * i] = jv[i];
         const int wv = __builtin_amdgcn_readfirstlane(bc >> 6);
         sbase = reinterpret_cast<const char*>(x.side + (size_t)wv * tb->n_entries * 64);
         lane_off = (unsigned)(bc & 63) * 8u;
@@ -517,11 +555,12 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
     unsigned mo0 = 0, mo1 = 0;      // FROMQ: entries of the next row of M to be requested (table reads run one column ahead)
     if constexpr (FROMQ) {
         lds_sync();                 // the entry tables are in LDS
-        static_for<0, PF>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
+        static_for<0, PF>([&](auto jc) {      // TREE: the recursion runs from the last column down
+            constexpr int j = TREE ? N - 1 - decltype(jc)::value : decltype(jc)::value;
             pm0[j] = side_at(Mt[j * 32 + l]); pm1[j] = side_at(Mt[j * 32 + 16 + l]);
         });
-        mo0 = Mt[PF * 32 + l]; mo1 = Mt[PF * 32 + 16 + l];
+        constexpr int jn = TREE ? N - 1 - PF : PF;
+        mo0 = Mt[jn * 32 + l]; mo1 = Mt[jn * 32 + 16 + l];
 #pragma unroll
         for (int r = 0; r < K; ++r) { jl0[r] = side_at(Jt[r * 32 + l]); jl1[r] = side_at(Jt[r * 32 + 16 + l]); }
         dq0_in = x.qvel[(size_t)bc * N + l];
@@ -639,9 +678,47 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
 
     IRLOSC_TS(2);
     // ---- main loop: Cholesky of M, Y = L^-1 J^T (as T), M dq, J dq ------------------------------------------------
-    double L0[15], L1[24], T[N];
+    double T[N];
     double mdq0 = 0.0, mdq1 = 0.0, dx = 0.0;
     const double* trow = Jq + (l < K ? l : K) * N;
+    if constexpr (TREE) {
+        // M = L^T L, columns N - 1 .. 0; R0[c] = L[c][l], R1[c] = L[c][16 + l] (the lane's two COLUMNS of L)
+        using TI = FeTopo<TOPO>;
+        static_assert(TOPO::NJ == N, "tree shape and kernel shape");
+        double R0[N], R1[N];
+        double tnext = trow[N - 1];
+        static_for_down<0, N>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int sj = j >> 4, gj = j & 15;
+            constexpr int SZ = tree_subtree_size<TOPO>(j);          // hinges j .. j + SZ - 1 are the subtree of j
+            static_assert(tree_subtree_contiguous<TOPO>(j), "depth-first numbering: a subtree is a run of indices");
+            if constexpr (j - PF >= 0) {
+                pm0[j - PF] = side_at(mo0); pm1[j - PF] = side_at(mo1);
+                if constexpr (j - PF - 1 >= 0) { mo0 = Mt[(j - PF - 1) * 32 + l]; mo1 = Mt[(j - PF - 1) * 32 + 16 + l]; }
+            }
+            double m0 = (double)pm0[j], m1 = (double)pm1[j];
+            double tj = tnext;
+            if constexpr (j > 0) tnext = trow[j - 1];
+            const double dqs = sj ? dq1 : dq0;
+            __builtin_amdgcn_sched_barrier(0);
+            fmac_bc_nop<gj>(mdq0, dqs, m0);
+            fmac_bc<gj>(mdq1, dqs, m1);
+            fmac_bc<gj>(dx, dqs, tj);
+            if constexpr (SZ > 1) {
+                if constexpr (j >= 16) fmac3_chain<gj, j + 1, SZ - 1>(m1, m0, tj, R1, R0, T);      // row j is a slot-1 row
+                else fmac2_chain<gj, j + 1, SZ - 1>(m0, tj, R0, T);                              // slot-1 rows are done
+            }
+            double d = bc_nop<gj>(sj ? m1 : m0);
+            flags |= !(d > 0.0) ? IRLOSC_FLAG_M_NOT_PD : 0u;      // also catches NaN
+            d = fmax(d, 1e-300);
+            const double dinv = rsq_refined(d);
+            R0[j] = m0 * dinv;
+            if constexpr (j >= 16) R1[j] = m1 * dinv;
+            T[j] = tj * dinv;
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    } else {
+    double L0[15], L1[24];
     double tnext = trow[0];
     static_for<0, N>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -674,6 +751,7 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
         T[j] = tj * dinv;
         __builtin_amdgcn_sched_barrier(0);
     });
+    }
 
     IRLOSC_TS(3);
     // ---- A = Y^T Y: lane c ends up with A[r][c], r = 0..K-1 -------------------------------------------------------

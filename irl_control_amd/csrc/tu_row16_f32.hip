@@ -1,6 +1,7 @@
 // Translation unit of the fp64-arithmetic row16 path on float records: the three Dual-UR5 shapes and the give-up pass.
 #include "osc_generic.hpp"
 #include "osc_row16.hpp"
+#include "topo_dual_ur5.hpp"     // the fused path exists for the compiled tree shape (irlosc_set_model checks the model against it)
 #include "launchers.hpp"
 
 namespace irlosc {
@@ -18,7 +19,8 @@ int launch_row16(const Row16Train<TIN>& tr, int nsteps, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-// The same train on the fused path: operands from the compact exchange buffers (tr.x[i].side / qvel / tables).  The grid
+// The same train on the fused path: operands from the compact exchange buffers (tr.x[i].side / qvel / tables), the
+// factorisation in the tree-structured form of the compiled Dual-UR5 shape.  The grid
 // covers whole groups of 8 walk waves (128 blocks) so that the XCD-aware block map of the kernel stays a bijection.
 template <typename TIN>
 int launch_row16_fromq(const Row16Train<TIN>& tr, int nsteps, hipStream_t st) {
@@ -26,9 +28,9 @@ int launch_row16_fromq(const Row16Train<TIN>& tr, int nsteps, hipStream_t st) {
     if (p.B <= 0 || nsteps <= 0) return 0;
     const int waves = (p.B + 63) / 64;
     const dim3 grid(((waves + 7) / 8) * 128, nsteps);
-    if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25, true>), grid, dim3(64), 0, st, tr);
-    else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<12, 2, TIN, 25, true>), grid, dim3(64), 0, st, tr);
-    else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<7, 3, TIN, 25, true>), grid, dim3(64), 0, st, tr);
+    if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25, true, TopoDualUr5>), grid, dim3(64), 0, st, tr);
+    else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<12, 2, TIN, 25, true, TopoDualUr5>), grid, dim3(64), 0, st, tr);
+    else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<7, 3, TIN, 25, true, TopoDualUr5>), grid, dim3(64), 0, st, tr);
     else return (int)hipErrorNotSupported;
     return (int)hipGetLastError();
 }
