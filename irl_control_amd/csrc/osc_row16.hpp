@@ -547,6 +547,35 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
 #define IRLOSC_TS(i) ts[i] = p.dbg ? __builtin_readcyclecounter() : 0ull
     IRLOSC_TS(0);
 
+    // ---- the inputs of the task-space signal FIRST: s_waitcnt counts loads in issue order, so whoever is requested last
+    // waits for everything before it.  Requested ahead of the 8 rows of M and the 26 words of J per lane, the poses /
+    // targets / gains are there one latency after the kernel starts and the ~480 instructions of the task error run while
+    // the big loads are still arriving, instead of behind all of them.
+    const bool has_tv = p.tvel != nullptr;
+    const int dv = l >> 2, ang_id = l & 3;
+    const int dd = dv < NDEV ? dv : NDEV - 1;
+    TM ee_in[7];
+    TIN tg_in[7], g_in[IRLOSC_GAIN_WORDS], tv_in[6];
+    {
+        const TIN* __restrict__ tgp = p.tgt + ((size_t)bc * NDEV + dd) * 7;
+        const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * NDEV * IRLOSC_GAIN_WORDS : 0) + dd * IRLOSC_GAIN_WORDS;
+        if constexpr (FROMQ) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) ee_in[i] = side_ld(x.tables->eetab[dd][i]);
+        } else {
+            const TIN* __restrict__ eep = p.ee + ((size_t)bc * NDEV + dd) * 7;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) ee_in[i] = eep[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) tg_in[i] = tgp[i];
+#pragma unroll
+        for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) g_in[i] = gp[i];
+        const TIN* __restrict__ tvp = has_tv ? p.tvel + ((size_t)bc * NDEV + dd) * 6 : zeros;      // all six together: as a
+#pragma unroll                                                                                      // short-circuit chain each
+        for (int i = 0; i < 6; ++i) tv_in[i] = tvp[i];                                              // waited for the one before
+    }
+
     // ---- prologue: first rows of M in flight, J (coalesced) into LDS, dq ------------------------------------------
     TM pm0[N], pm1[N];
     TM jl0[K], jl1[K];
@@ -585,28 +614,16 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
     // Lane a of the quad evaluates ONE of the three Euler angles (the fp64 atan2 is the expensive part), the quad
     // broadcasts them, every lane of the quad finishes the gains, lane 0 parks the controlled rows in LDS.
     const double kvn = (p.cfgflags & IRLOSC_NULLSPACE) ? (double)p.null_kv[p.gains_per_instance ? bc : 0] : 0.0;
-    const bool has_tv = p.tvel != nullptr;
     const bool has_wr = (p.cfgflags & IRLOSC_ADMITTANCE) && p.wrench != nullptr;
-    const int dv = l >> 2, ang_id = l & 3;
-    const int dd = dv < NDEV ? dv : NDEV - 1;
     const DevMeta dm = p.dev[dd];
     bool own_brB = false;
     {
-        const TIN* __restrict__ tgp = p.tgt + ((size_t)bc * NDEV + dd) * 7;
         const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * NDEV * IRLOSC_GAIN_WORDS : 0) + dd * IRLOSC_GAIN_WORDS;
         double ee[7], tg[7], g[IRLOSC_GAIN_WORDS];
-        if constexpr (FROMQ) {
 #pragma unroll
-            for (int i = 0; i < 7; ++i) ee[i] = side_ld(x.tables->eetab[dd][i]);
-        } else {
-            const TIN* __restrict__ eep = p.ee + ((size_t)bc * NDEV + dd) * 7;
+        for (int i = 0; i < 7; ++i) { ee[i] = (double)ee_in[i]; tg[i] = (double)tg_in[i]; }
 #pragma unroll
-            for (int i = 0; i < 7; ++i) ee[i] = (double)eep[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 7; ++i) tg[i] = (double)tgp[i];
-#pragma unroll
-        for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) g[i] = (double)gp[i];
+        for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) g[i] = (double)g_in[i];
         double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if (dm.calc & 1u) { e[0] = ee[0] - tg[0]; e[1] = ee[1] - tg[1]; e[2] = ee[2] - tg[2]; }
         if (dm.calc & 2u) {
@@ -644,10 +661,8 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
         }
         apply_gains6_fast(g, e);
         bool all_nonzero = has_tv;
-        if (has_tv) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) all_nonzero = all_nonzero && ((double)p.tvel[((size_t)bc * NDEV + dd) * 6 + i] != 0.0);
-        }
+        for (int i = 0; i < 6; ++i) all_nonzero = all_nonzero & ((double)tv_in[i] != 0.0);
         own_brB = all_nonzero && dv < NDEV;          // np.all(target_vel) == 0 quirk, osc.py:173
         if (ang_id == 0 && dv < NDEV) {
             int cnt = 0;
