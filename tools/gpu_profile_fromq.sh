@@ -18,5 +18,5 @@ if [ -n "$fdb" ] && [ -n "$wdb" ]; then
   (python tools/pmc_dump.py "$fdb" osc_; python tools/pmc_dump.py "$wdb" osc_) > gpurun_out/fromq_pmc_fetch_write_$tag.txt
   cat gpurun_out/fromq_pmc_fetch_write_$tag.txt
   python tools/pmc_traffic.py "$fdb" "$wdb" osc_frontend_lane_compact "osc_frontend_lane_compact_dual_ur5" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8
-  python tools/pmc_traffic.py "$fdb" "$wdb" "osc_row16_kernel<13, 3, double, 25, true>" "osc_row16_f64_n25_k13_fromq" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8
+  python tools/pmc_traffic.py "$fdb" "$wdb" "25, true" "osc_row16_f64_n25_k13_fromq" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8
 fi
