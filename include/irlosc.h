@@ -16,6 +16,10 @@
  *   targets dict (utils.py:5-67; osc.py:156-159,172)            -> irlosc_set_targets
  *   OSC.generate numerical body (osc.py:41-118,144-200)         -> irlosc_step / irlosc_step_device
  *   forces gather u_all[actuator_trnids] (osc.py:203-210)       -> host side, from u[B,n]
+ *   the per-tick MuJoCo reads themselves: mj_fullM (robot.py:68-72),
+ *   jacp / jacr (device.py:115-133), qfrc_bias (osc.py:190-191),
+ *   EE xpos / xquat (device.py:97-99), from (qpos, qvel)        -> irlosc_set_model, irlosc_upload_q, then irlosc_frontend
+ *                                                                  (dense records) or irlosc_step_from_q (fused: no records)
  *
  * Record layouts (batch-major, row-major, element type = cfg.dtype: float or double):
  *   M[B][n][n]      joint-space inertia, symmetric positive definite (the group kernel reads row j as column j)
