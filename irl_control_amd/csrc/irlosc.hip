@@ -11,6 +11,7 @@
 #include <new>
 #include <string>
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 #include "../../include/irlosc.h"
@@ -369,25 +370,46 @@ static int check_slot(irlosc_ctx* c, int slot, int B) {
 }
 
 // The throughput kernels read row j of M as its column j (include/irlosc.h, contracts): an asymmetric M would give a wrong
-// answer without any flag, so records that come from the HOST are probed on the device before they are accepted (the
-// generic kernel uses M as given, like osc.py:49,151, and takes anything).  Enqueues the probe; symmetry_verdict reads it.
-static int symmetry_probe(irlosc_ctx* c, const void* dM, int B, hipStream_t st) {
-    if (c->kernel == IRLOSC_KERNEL_GENERIC) return IRLOSC_OK;
-    static const int32_t init[2] = {0, 0x7fffffff};
-    HIPCHK(c, hipMemcpyAsync(c->dsym, init, sizeof init, hipMemcpyHostToDevice, st));
-    const int rc = c->cfg.dtype == IRLOSC_F64 ? launch_symmetry_probe<double>((const double*)dM, c->cfg.n, B, c->dsym, st)
-                                              : launch_symmetry_probe<float>((const float*)dM, c->cfg.n, B, c->dsym, st);
+// answer without any flag, so records that come from the HOST are checked before they are accepted (the generic kernel uses
+// M as given, like osc.py:49,151, and takes anything).  Small batches on the host, on the caller's own array (B = 1: under a
+// microsecond, no kernel in the tick); large ones on the device, one pass over M behind the copy.
+static constexpr int SYM_HOST_MAX_B = 32;
+static bool sym_applies(const irlosc_ctx* c) { return c->kernel != IRLOSC_KERNEL_GENERIC; }
+
+template <typename T>
+static int symmetry_host_t(irlosc_ctx* c, const T* M, int B) {
+    const int n = c->cfg.n;
+    for (int b = 0; b < B; ++b) {
+        const T* Mb = M + (size_t)b * n * n;
+        double asym = 0.0, scale = 0.0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                const double v = (double)Mb[i * n + j];
+                asym = std::max(asym, std::fabs(v - (double)Mb[j * n + i]));
+                scale = std::max(scale, std::fabs(v));
+            }
+        if (!(asym <= 1e-6 * std::max(scale, 1e-300)))
+            return fail(c, IRLOSC_ERR_ARG, "M of instance %d is not symmetric (max |M - M^T| = %.3g): the %s kernel reads rows of M as "
+                        "columns; use IRLOSC_KERNEL_GENERIC for a non-symmetric M", b, asym, c->kernel_name.c_str());
+    }
+    return IRLOSC_OK;
+}
+static int symmetry_host(irlosc_ctx* c, const void* M, int B) {
+    return c->cfg.dtype == IRLOSC_F64 ? symmetry_host_t<double>(c, (const double*)M, B) : symmetry_host_t<float>(c, (const float*)M, B);
+}
+// Device probe: zeroes the two result words at `dres` and enqueues the pass; the caller brings them back with whatever copy
+// it makes anyway and hands them to symmetry_verdict.
+static int symmetry_probe(irlosc_ctx* c, const void* dM, int B, int32_t* dres, hipStream_t st) {
+    HIPCHK(c, hipMemsetAsync(dres, 0, 2 * sizeof(int32_t), st));
+    const int rc = c->cfg.dtype == IRLOSC_F64 ? launch_symmetry_probe<double>((const double*)dM, c->cfg.n, B, dres, st)
+                                              : launch_symmetry_probe<float>((const float*)dM, c->cfg.n, B, dres, st);
     HIPCHK(c, (hipError_t)rc);
     return IRLOSC_OK;
 }
-static int symmetry_verdict(irlosc_ctx* c, hipStream_t st) {       // the stream must have been synchronised after the probe
-    if (c->kernel == IRLOSC_KERNEL_GENERIC) return IRLOSC_OK;
-    int32_t res[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(res, c->dsym, sizeof res, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+static int symmetry_verdict(irlosc_ctx* c, const int32_t res[2]) {
     if (res[0] > 0)
         return fail(c, IRLOSC_ERR_ARG, "M of instance %d is not symmetric (%d instance(s) with max |M - M^T| > 1e-6 max |M|): the %s "
-                    "kernel reads rows of M as columns; use IRLOSC_KERNEL_GENERIC for a non-symmetric M", res[1], res[0],
+                    "kernel reads rows of M as columns; use IRLOSC_KERNEL_GENERIC for a non-symmetric M", 0x7fffffff - res[1], res[0],
                     c->kernel_name.c_str());
     return IRLOSC_OK;
 }
@@ -410,9 +432,21 @@ extern "C" int irlosc_upload(irlosc_ctx* c, int32_t slot, int32_t B, const void*
     if (wrench) HIPCHK(c, hipMemcpyAsync(c->dwrench[slot], wrench, b * nd * 6 * e, hipMemcpyHostToDevice, c->stream));
     c->has_wrench[slot] = wrench != nullptr;
     c->uploaded[slot] = 0;                              // nothing usable in the slot until the records are accepted
-    int rcs = symmetry_probe(c, c->dM[slot], B, c->stream);
-    if (!rcs) rcs = symmetry_verdict(c, c->stream);
-    if (rcs) return rcs;
+    if (sym_applies(c)) {
+        int rcs;
+        if (B <= SYM_HOST_MAX_B) {
+            rcs = symmetry_host(c, M, B);
+        } else {
+            int32_t res[2] = {0, 0};
+            rcs = symmetry_probe(c, c->dM[slot], B, c->dsym, c->stream);
+            if (rcs) return rcs;
+            HIPCHK(c, hipMemcpyAsync(res, c->dsym, sizeof res, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            rcs = symmetry_verdict(c, res);
+        }
+        if (rcs) return rcs;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->uploaded[slot] = B;
     return IRLOSC_OK;
 }
@@ -1266,7 +1300,14 @@ extern "C" int irlosc_tick(irlosc_ctx* c, int32_t B, const void* M, const void* 
         HIPCHK(c, hipMalloc(&c->tick_din, total));
         c->tick_in_bytes = total;
     }
-    const size_t ub = b * n * e, out_total = ((ub + 255) & ~(size_t)255) + b * sizeof(uint32_t);
+    // output block: u | flags | the two words of the symmetry probe (they ride back in the one copy the tick makes anyway)
+    const size_t ub = b * n * e, fl_off = (ub + 255) & ~(size_t)255, sym_off = (fl_off + b * sizeof(uint32_t) + 15) & ~(size_t)15;
+    const size_t out_total = sym_off + 2 * sizeof(int32_t);
+    const bool sym_dev = sym_applies(c) && B > SYM_HOST_MAX_B;
+    if (sym_applies(c) && !sym_dev) {
+        int rch = symmetry_host(c, M, B);
+        if (rch) return rch;
+    }
     if (out_total > c->tick_out_bytes) {
         if (c->tick_hout) HIPCHK(c, hipHostFree(c->tick_hout));
         if (c->tick_dout) HIPCHK(c, hipFree(c->tick_dout));
@@ -1279,18 +1320,23 @@ extern "C" int irlosc_tick(irlosc_ctx* c, int32_t B, const void* M, const void* 
     unsigned char* din = (unsigned char*)c->tick_din;
     for (int i = 0; i < 8; ++i) if (sz[i]) memcpy(hin + off[i], src[i], sz[i]);
     HIPCHK(c, hipMemcpyAsync(din, hin, total, hipMemcpyHostToDevice, c->stream));
-    int rcs = symmetry_probe(c, din + off[0], B, c->stream);
-    if (rcs) return rcs;
     unsigned char* dout = (unsigned char*)c->tick_dout;
-    uint32_t* dfl = (uint32_t*)(dout + ((ub + 255) & ~(size_t)255));
+    uint32_t* dfl = (uint32_t*)(dout + fl_off);
+    if (sym_dev) {
+        int rcs = symmetry_probe(c, din + off[0], B, (int32_t*)(dout + sym_off), c->stream);
+        if (rcs) return rcs;
+    }
     int rc = launch(c, B, din + off[0], din + off[1], din + off[2], sz[3] ? din + off[3] : nullptr, din + off[4], din + off[5],
                     sz[7] ? din + off[7] : nullptr, sz[6] ? din + off[6] : nullptr, dout, dfl, c->stream);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->tick_hout, dout, out_total, hipMemcpyDeviceToHost, c->stream));
-    rcs = symmetry_verdict(c, c->stream);               // synchronises the stream; nothing is handed out for an asymmetric M
-    if (rcs) return rcs;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (sym_dev) {                                      // nothing is handed out for an asymmetric M
+        int rcs = symmetry_verdict(c, (const int32_t*)((unsigned char*)c->tick_hout + sym_off));
+        if (rcs) return rcs;
+    }
     memcpy(u_host, c->tick_hout, ub);
-    if (flags_host) memcpy(flags_host, (unsigned char*)c->tick_hout + ((ub + 255) & ~(size_t)255), b * sizeof(uint32_t));
+    if (flags_host) memcpy(flags_host, (unsigned char*)c->tick_hout + fl_off, b * sizeof(uint32_t));
     return IRLOSC_OK;
 }
 

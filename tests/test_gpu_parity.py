@@ -1203,6 +1203,15 @@ def test_library_refuses_an_asymmetric_M_on_the_throughput_paths(dtype, kernel):
         osc.tick(Masym, g["J"], g["dq"], g["bias"], g["ee_pose"], g["tgt_pose"])
     u = osc.tick(g["M"], g["J"], g["dq"], g["bias"], g["ee_pose"], g["tgt_pose"])      # and the context is still usable
     assert np.all(np.isfinite(u))
+    sl = slice(120, 126)                              # small batches are checked on the host, on the caller's array (no kernel)
+    with pytest.raises(_lib.IrloscError, match=r"M of instance 3 is not symmetric \(max"):
+        osc.tick(Masym[sl], g["J"][sl], g["dq"][sl], g["bias"][sl], g["ee_pose"][sl], g["tgt_pose"][sl])
+    with pytest.raises(_lib.IrloscError, match="M of instance 3 is not symmetric"):
+        osc.upload(Masym[sl], g["J"][sl], g["dq"][sl], g["bias"][sl], g["ee_pose"][sl])
+    u6 = osc.tick(g["M"][sl], g["J"][sl], g["dq"][sl], g["bias"][sl], g["ee_pose"][sl], g["tgt_pose"][sl])
+    if "row16" in osc.kernel_name:                     # (a fp32 group batch under 16 instances runs on the generic kernel)
+        assert np.array_equal(u6, u[sl])
+    assert np.all(np.isfinite(u6))
     osc.close()
     gen = BatchedOSC(lay, B, dtype=dtype, kernel=_lib.KERNEL_GENERIC)
     gen.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
