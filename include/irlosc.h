@@ -133,6 +133,16 @@ int irlosc_set_gains(irlosc_ctx* ctx, const double* gains, const double* null_kv
  * an asymmetric M is refused (IRLOSC_ERR_ARG, the slot then holds nothing): see the contracts block above. */
 int irlosc_upload(irlosc_ctx* ctx, int32_t slot, int32_t B, const void* M, const void* J,
                   const void* dq, const void* bias, const void* ee_pose, const void* wrench);
+/* 1 when the records now in `slot` carry the zero pattern of the compiled Dual-UR5 tree and the fp64 row16 kernel will
+ * therefore run its factorisation in the tree-structured form (M = L^T L from the leaves up, fill-in free: Featherstone's
+ * branch-induced sparsity; rows of Y = L^-T J^T under no end effector skipped), 0 when it runs the dense recursion.  The
+ * verdict is taken when the records arrive: irlosc_upload / irlosc_upload_raw look at every instance (one pass on the device:
+ * M[i][j] exactly 0 unless hinge i is above hinge j or j above i; columns of J exactly 0 for hinges that move no end-effector
+ * candidate -- what mj_fullM / mj_jacBody leave, robot.py:68-72, device.py:115-133), batches of 64 instances and more only;
+ * irlosc_frontend's lane kernel writes such records by construction; irlosc_assemble_device (caller's stream) never
+ * qualifies.  A train of irlosc_step_resident uses the form when every slot in it qualifies.  Results differ from the
+ * dense recursion at rounding level only.  IRLOSC_TREE=0 in the environment turns the form off. */
+int irlosc_slot_structure(const irlosc_ctx* ctx, int32_t slot);
 /* Host -> device copy of the targets for slot `slot`.  tgt_vel may be NULL (all zero). */
 int irlosc_set_targets(irlosc_ctx* ctx, int32_t slot, int32_t B, const void* tgt_pose,
                        const void* tgt_vel);

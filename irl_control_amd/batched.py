@@ -194,6 +194,11 @@ class BatchedOSC:
         self._chk(self.lib.irlosc_download_records(self._h, slot, B, *[_lib.ptr(out.get(k)) for k in ("M", "J", "dq", "bias", "ee_pose")]))
         return out
 
+    def slot_structure(self, slot: int = 0) -> bool:
+        """True when the records in `slot` carry the zero pattern of the Dual-UR5 tree and the fp64 row16 kernel therefore
+        factors M in the tree-structured form (irlosc_slot_structure, include/irlosc.h)."""
+        return bool(self.lib.irlosc_slot_structure(self._h, slot))
+
     @property
     def from_q_name(self) -> str:
         """What step_from_q / step_resident_from_q launch: the fused pair (compact exchange buffer, no dense M / J) when the

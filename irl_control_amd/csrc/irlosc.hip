@@ -88,6 +88,12 @@ struct irlosc_ctx {
     void* tick_hin = nullptr; void* tick_din = nullptr; size_t tick_in_bytes = 0;
     void* tick_hout = nullptr; void* tick_dout = nullptr; size_t tick_out_bytes = 0;
     int32_t* dsym = nullptr;  // symmetry probe of the throughput paths: {count, first instance}
+    // Tree-structured factorisation on dense records (row16 kernel): per slot, 1 when the records in it were verified to carry
+    // the zero pattern of the compiled Dual-UR5 tree (probe at upload) or were written by the lane front end (by construction)
+    std::vector<int> tree_ok;
+    int tree_enabled = 1;              // IRLOSC_TREE=0 turns the form off (A/B measurements)
+    StructureMasks tree_masks;
+    int32_t* dstruct = nullptr;        // result word of the structure probe
     void* dgains = nullptr;   // [nb][ndev][12] in dtype
     void* dnullkv = nullptr;  // [nb]
     int gains_nb = 0;
@@ -195,6 +201,7 @@ static void free_all(irlosc_ctx* c) {
     for (int k = 0; k < R16_TRAIN; ++k) if (c->dr16_list[k]) (void)hipFree(c->dr16_list[k]);
     if (c->dr16_count) (void)hipFree(c->dr16_count);
     if (c->dsym) (void)hipFree(c->dsym);
+    if (c->dstruct) (void)hipFree(c->dstruct);
     if (c->dgains) (void)hipFree(c->dgains);
     if (c->dnullkv) (void)hipFree(c->dnullkv);
     if (c->ddbg) (void)hipFree(c->ddbg);
@@ -264,6 +271,13 @@ static int create_impl(irlosc_ctx* c) {
     c->du = c->du_set[0];
     c->dflags = c->dflags_set[0];
     HIPCHK(nullptr, hipMalloc((void**)&c->dsym, 2 * sizeof(int32_t)));
+    HIPCHK(nullptr, hipMalloc((void**)&c->dstruct, sizeof(int32_t)));
+    c->tree_ok.assign(c->cfg.n_slots, 0);
+    row16_tree_masks(c->tree_masks.mrow, &c->tree_masks.jcols);
+    {
+        const char* e = getenv("IRLOSC_TREE");
+        c->tree_enabled = !(e && !strcmp(e, "0"));
+    }
     HIPCHK(nullptr, hipMalloc(&c->dgains, B * nd * IRLOSC_GAIN_WORDS * e));
     HIPCHK(nullptr, hipMalloc(&c->dnullkv, B * e));
     if (c->kernel != IRLOSC_KERNEL_GENERIC && getenv("IRLOSC_PHASE_TIMING"))     // debug aid: cycles per kernel phase
@@ -414,6 +428,33 @@ static int symmetry_verdict(irlosc_ctx* c, const int32_t res[2]) {
     return IRLOSC_OK;
 }
 
+// the tree-structured form of the row16 kernel applies to the records of this slot
+static bool slot_tree(const irlosc_ctx* c, int slot) {
+    return c->tree_enabled && c->kernel == IRLOSC_KERNEL_ROW16 && c->tree_ok[slot] != 0;
+}
+
+// Zero pattern of the records in a slot (synchronous; a throughput feature: batches under 64 instances keep the dense form).
+// The pattern is that of the compiled Dual-UR5 tree, so the question only arises for its shape (n = 25).
+static int structure_probe(irlosc_ctx* c, int slot, int B) {
+    c->tree_ok[slot] = 0;
+    if (!c->tree_enabled || c->kernel != IRLOSC_KERNEL_ROW16 || B < 64) return IRLOSC_OK;
+    int32_t bad = 0;
+    HIPCHK(c, hipMemsetAsync(c->dstruct, 0, sizeof(int32_t), c->stream));
+    const int rc = c->cfg.dtype == IRLOSC_F64
+        ? launch_structure_probe<double>((const double*)c->dM[slot], (const double*)c->dJ[slot], c->cfg.n, c->k, B, c->tree_masks, c->dstruct, c->stream)
+        : launch_structure_probe<float>((const float*)c->dM[slot], (const float*)c->dJ[slot], c->cfg.n, c->k, B, c->tree_masks, c->dstruct, c->stream);
+    HIPCHK(c, (hipError_t)rc);
+    HIPCHK(c, hipMemcpyAsync(&bad, c->dstruct, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->tree_ok[slot] = bad == 0;
+    return IRLOSC_OK;
+}
+
+extern "C" int irlosc_slot_structure(const irlosc_ctx* c, int32_t slot) {
+    if (!c || slot < 0 || slot >= c->cfg.n_slots) return 0;
+    return slot_tree(c, slot) ? 1 : 0;
+}
+
 extern "C" int irlosc_upload(irlosc_ctx* c, int32_t slot, int32_t B, const void* M, const void* J, const void* dq,
                              const void* bias, const void* ee_pose, const void* wrench) {
     if (!c) return IRLOSC_ERR_ARG;
@@ -447,6 +488,8 @@ extern "C" int irlosc_upload(irlosc_ctx* c, int32_t slot, int32_t B, const void*
         if (rcs) return rcs;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rcp = structure_probe(c, slot, B);
+    if (rcp) return rcp;
     c->uploaded[slot] = B;
     return IRLOSC_OK;
 }
@@ -534,6 +577,8 @@ extern "C" int irlosc_upload_raw(irlosc_ctx* c, int32_t slot, int32_t B, const i
              : upload_raw_t<float>(c, slot, B, rd, qM, qvel, qfrc_bias, jacp, jacr, ee_xpos, ee_xquat, site_xmat, sensordata);
     if (rc) return rc;
     c->has_wrench[slot] = 1;
+    rc = structure_probe(c, slot, B);
+    if (rc) return rc;
     c->uploaded[slot] = B;
     return IRLOSC_OK;
 }
@@ -557,6 +602,7 @@ extern "C" int irlosc_assemble_device(irlosc_ctx* c, int32_t slot, int32_t B, co
                                     : assemble_launch<float>(c, slot, B, rd, dptr, st);
     if (rc) return rc;
     c->has_wrench[slot] = 1;
+    c->tree_ok[slot] = 0;          // enqueued on the caller's stream: no synchronous look at what it writes
     c->uploaded[slot] = B;
     return IRLOSC_OK;
 }
@@ -691,7 +737,7 @@ static int flush_pending(irlosc_ctx* c, hipStream_t st) {
 // up on (net of eigen-candidates full, degenerate A) are recomputed by the generic kernel (Jacobi, fp64 arithmetic) from
 // the lists it leaves behind.
 template <typename T>
-static int row16_train(irlosc_ctx* c, const KParams<T>* ps, int n, hipStream_t st) {
+static int row16_train(irlosc_ctx* c, const KParams<T>* ps, int n, bool tree, hipStream_t st) {
     if (n < 1 || n > R16_TRAIN) return fail(c, IRLOSC_ERR_STATE, "train of %d steps", n);
     Row16Train<T> tr;
     memset(&tr, 0, sizeof tr);
@@ -701,7 +747,7 @@ static int row16_train(irlosc_ctx* c, const KParams<T>* ps, int n, hipStream_t s
         tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[i], c->dr16_count + i, nullptr, nullptr, nullptr, 0};
     }
     if (c->tev_begin) HIPCHK(c, hipEventRecord(c->tev_begin, st));
-    int rc = launch_row16<T>(tr, n, st);
+    int rc = launch_row16<T>(tr, n, tree, st);
     if (rc) return fail(c, IRLOSC_ERR_HIP, "row16 kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     HIPCHK(c, (hipError_t)launch_row16_worklist<T>(tr, n, nullptr, st));
     if (c->tev_end) HIPCHK(c, hipEventRecord(c->tev_end, st));
@@ -711,7 +757,7 @@ static int row16_train(irlosc_ctx* c, const KParams<T>* ps, int n, hipStream_t s
 template <typename T>
 static int launch_t(irlosc_ctx* c, int B, const void* M, const void* J, const void* dq, const void* bias,
                     const void* ee, const void* tgt, const void* tvel, const void* wrench, void* u,
-                    uint32_t* flags, hipStream_t st) {
+                    uint32_t* flags, hipStream_t st, bool tree) {
     KParams<T> p;
     fill_params<T>(c, p, B, M, J, dq, bias, ee, tgt, tvel, wrench, u, flags);
     if (c->kernel == IRLOSC_KERNEL_GROUP) {
@@ -724,18 +770,18 @@ static int launch_t(irlosc_ctx* c, int B, const void* M, const void* J, const vo
             return fail(c, IRLOSC_ERR_ARG, "no fp64 group kernel");
         }
     }
-    if (c->kernel == IRLOSC_KERNEL_ROW16) return row16_train<T>(c, &p, 1, st);
+    if (c->kernel == IRLOSC_KERNEL_ROW16) return row16_train<T>(c, &p, 1, tree, st);
     HIPCHK(c, (hipError_t)launch_generic<T>(p, B, st));
     return IRLOSC_OK;
 }
 
 static int launch(irlosc_ctx* c, int B, const void* M, const void* J, const void* dq, const void* bias,
                   const void* ee, const void* tgt, const void* tvel, const void* wrench, void* u,
-                  uint32_t* flags, hipStream_t st) {
+                  uint32_t* flags, hipStream_t st, bool tree = false) {
     if (B == 0) return IRLOSC_OK;
     if (c->gains_nb == 0) return fail(c, IRLOSC_ERR_STATE, "irlosc_set_gains has not been called");
-    if (c->cfg.dtype == IRLOSC_F64) return launch_t<double>(c, B, M, J, dq, bias, ee, tgt, tvel, wrench, u, flags, st);
-    return launch_t<float>(c, B, M, J, dq, bias, ee, tgt, tvel, wrench, u, flags, st);
+    if (c->cfg.dtype == IRLOSC_F64) return launch_t<double>(c, B, M, J, dq, bias, ee, tgt, tvel, wrench, u, flags, st, tree);
+    return launch_t<float>(c, B, M, J, dq, bias, ee, tgt, tvel, wrench, u, flags, st, tree);
 }
 
 // A step over B instances needs B instances of state AND of targets in the slot (stale or uninitialised HBM otherwise).
@@ -753,7 +799,7 @@ static int launch_slot(irlosc_ctx* c, int slot, int B) {
     if (rcf) return rcf;
     return launch(c, B, c->dM[slot], c->dJ[slot], c->ddq[slot], c->dbias[slot], c->dee[slot], c->dtgt[slot],
                   c->has_tvel[slot] ? c->dtvel[slot] : nullptr, c->has_wrench[slot] ? c->dwrench[slot] : nullptr,
-                  c->du, c->dflags, c->stream);
+                  c->du, c->dflags, c->stream, slot_tree(c, slot));
 }
 
 extern "C" int irlosc_download(irlosc_ctx* c, int32_t B, void* u_host, uint32_t* flags_host) {
@@ -858,10 +904,12 @@ static int row16_resident(irlosc_ctx* c, int first_slot, int B, int iters, const
     while (done < iters) {
         const int n = std::min((int)R16_TRAIN, iters - done);
         KParams<T> ps[R16_TRAIN];
+        bool tree = true;                  // one kernel per train: the tree form only when every slot of it qualifies
         for (int i = 0; i < n; ++i) {
             const int slot = (first_slot + done + i) % c->cfg.n_slots;
             int rcf = check_slot_filled(c, slot, B);
             if (rcf) return rcf;
+            tree = tree && slot_tree(c, slot);
             fill_params<T>(c, ps[i], B, c->dM[slot], c->dJ[slot], c->ddq[slot], c->dbias[slot], c->dee[slot], c->dtgt[slot],
                            c->has_tvel[slot] ? c->dtvel[slot] : nullptr, c->has_wrench[slot] ? c->dwrench[slot] : nullptr,
                            c->du_set[i], c->dflags_set[i]);
@@ -870,7 +918,7 @@ static int row16_resident(irlosc_ctx* c, int first_slot, int B, int iters, const
             c->tev_begin = (*evs)[2 * (launch_no - skip)];
             c->tev_end = (*evs)[2 * (launch_no - skip) + 1];
         }
-        int rc = row16_train<T>(c, ps, n, c->stream);
+        int rc = row16_train<T>(c, ps, n, tree, c->stream);
         c->tev_begin = c->tev_end = nullptr;
         if (rc) return rc;
         c->cur = n - 1;
@@ -1112,6 +1160,7 @@ static int frontend_launch(irlosc_ctx* c, int slot, int B) {
     // The records of this slot are now those of B robots: an earlier, larger upload must not vouch for instances the front
     // end did not write (the wrench of the slot stays what the last irlosc_upload / irlosc_upload_raw put there).
     c->uploaded[slot] = B;
+    c->tree_ok[slot] = c->fe_lane;     // the lane kernel walks the compiled tree: its records carry the tree's zeros by construction
     return IRLOSC_OK;
 }
 

@@ -19,7 +19,8 @@ int launch_generic(const KParams<T>& p, int blocks, hipStream_t st);
 // tu_row16_f64.hip / tu_row16_f32.hip -- fp64-arithmetic row16 path (osc_row16.hpp); TIN = record type
 template <typename TIN> struct Row16Train;
 template <typename TIN>
-int launch_row16(const Row16Train<TIN>& tr, int nsteps, hipStream_t st);
+int launch_row16(const Row16Train<TIN>& tr, int nsteps, bool tree, hipStream_t st);      // tree: tree-structured factorisation
+void row16_tree_masks(uint32_t mrow[32], uint32_t* jcols);      // zero pattern the tree form relies on (osc_row16.hpp)
 template <typename TIN>
 int launch_row16_fromq(const Row16Train<TIN>& tr, int nsteps, hipStream_t st);
 template <typename TIN>
@@ -53,5 +54,8 @@ int launch_assemble(const RawDesc& d, const RawPtrs<T>& r, int B, hipStream_t st
 // out[0] += instances whose M is not symmetric, out[1] = min(out[1], first such instance)
 template <typename T>
 int launch_symmetry_probe(const T* M, int n, int B, int32_t* out, hipStream_t st);
+// out[0] += instances with a non-zero where the masks say zero (M[j][c] outside mrow[j], a column of J outside jcols)
+template <typename T>
+int launch_structure_probe(const T* M, const T* J, int n, int k, int B, const StructureMasks& m, int32_t* out, hipStream_t st);
 
 }  // namespace irlosc

@@ -102,4 +102,27 @@ __global__ __launch_bounds__(64) void osc_symmetry_kernel(const T* __restrict__ 
     }
 }
 
+// Zero pattern of the records (dense-record form of the tree-structured factorisation, osc_row16.hpp): counts the instances
+// with a non-zero entry of M outside mrow[j] or a non-zero column of J outside jcols.  Exact zeros are asked for: that is
+// what mj_fullM / mj_jacBody (and the front end here) leave where the tree has no coupling.
+template <typename T>
+__global__ __launch_bounds__(64) void osc_structure_kernel(const T* __restrict__ M, const T* __restrict__ J, const int n, const int k,
+                                                           const int B, const StructureMasks m, int32_t* __restrict__ out) {
+    const int lane = threadIdx.x;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const T* Mb = M + (size_t)b * n * n;
+        const T* Jb = J + (size_t)b * k * n;
+        bool bad = false;
+        for (int e = lane; e < n * n; e += 64) {
+            const int i = e / n, j = e - i * n;
+            bad = bad || (!((m.mrow[i] >> j) & 1u) && !(Mb[e] == (T)0));       // NaN counts as non-zero
+        }
+        for (int e = lane; e < k * n; e += 64) {
+            const int j = e % n;
+            bad = bad || (!((m.jcols >> j) & 1u) && !(Jb[e] == (T)0));
+        }
+        if (__any(bad) && lane == 0) atomicAdd(&out[0], 1);
+    }
+}
+
 }  // namespace irlosc

@@ -175,4 +175,7 @@ __device__ __forceinline__ T wave_max(T v) {
     return v;
 }
 
+// zero pattern asked of dense records (osc_structure_kernel): bit c of mrow[j]: M[j][c] may be non-zero; bit c of jcols: column c of J
+struct StructureMasks { uint32_t mrow[32]; uint32_t jcols; };
+
 }  // namespace irlosc

@@ -39,6 +39,20 @@
 #include "osc_frontend_lane.hpp" // FeTopo: compile-time queries on a tree shape (FROMQ with a compiled topology)
 #include "osc_row16_asm.hpp"     // generated: the main loop's broadcast-FMA chains as asm blocks
 
+// A/B builds only (tools/build_variant.py): waves per SIMD the register allocator is asked for, prefetch depth of M.
+#ifndef IRLOSC_R16_WAVES
+#define IRLOSC_R16_WAVES 2
+#endif
+#ifndef IRLOSC_R16_PF
+#define IRLOSC_R16_PF 8
+#endif
+#ifndef IRLOSC_EIG_MAXIT
+#define IRLOSC_EIG_MAXIT 12
+#endif
+#ifndef IRLOSC_EIG_EXTRA
+#define IRLOSC_EIG_EXTRA 2
+#endif
+
 namespace irlosc {
 namespace r16 {
 
@@ -241,7 +255,7 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
         double x = l < K ? 0.3 + 0.1 * (double)(((l + 3 * slot) * 5) % 7) - 0.05 * (double)slot : 0.0;
         double lam = 0.0, lam_prev = -1.0;
         bool fin = !active;
-        for (int it = 0; it < 12; ++it) {
+        for (int it = 0; it < IRLOSC_EIG_MAXIT; ++it) {
             double xn = x;
 #pragma unroll
             for (int s0 = 0; s0 < NV - 1; ++s0) {
@@ -262,7 +276,7 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
         // amplified by 1 / lambda_cut: two more steps (each gains at least the factor 4 of the net, typically far more) for
         // every instance, whenever its loop froze (tools/parity_sweep.py --stress --layout k7: errors of 1.2e-5 .. 1.6e-5).
 #pragma unroll
-        for (int ex = 0; ex < 2; ++ex) {
+        for (int ex = 0; ex < IRLOSC_EIG_EXTRA; ++ex) {
             double xn = x;
 #pragma unroll
             for (int s0 = 0; s0 < NV - 1; ++s0) {
@@ -299,7 +313,11 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
     giveup = giveup || (m == NV);               // the net is full: there may be more under it (-> Jacobi)
     // Rayleigh-Ritz on the span of the candidates whenever an instance has more than one: H = V^T A V (4 x 4, the
     // unused vectors are zero), cyclic Jacobi on H with the rotations applied to V.  Rare, wave-uniform branch.
+#ifdef IRLOSC_EIG_NORR
+    if (false) {
+#else
     if (__any(m >= 2)) {
+#endif
         double av[NV], h[NV][NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) av[i] = matvec16<K>(v[i], Ac);
@@ -355,7 +373,11 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
         const bool below = has[i] && th[i] <= 1e-5 * lo;
         const bool ask = has[i] && !below && th[i] <= 1e-5 * hi;
         bool cut = below;
+#ifdef IRLOSC_EIG_NOASK
+        if (false) {
+#else
         if (__any(ask)) {
+#endif
             double A2[K], Ft[K], Gt[K], invt = 0.0, dett = 1.0;
             bool pdt = true;
 #pragma unroll
@@ -421,6 +443,33 @@ constexpr bool tree_subtree_contiguous(int j) {
     return true;
 }
 
+// hinge j moves a body that may be named as an end effector: every other column of J is structurally zero, and with the
+// factorisation running from the leaves up (row j of Y = L^-T J^T only sees rows of its own subtree) so is that row of Y
+template <class TOPO>
+constexpr bool tree_moves_ee(int j) {
+    for (int b = 0; b < TOPO::NB; ++b)
+        if (TOPO::ee_cand[b] != 0 && FeTopo<TOPO>::moves(j, b)) return true;
+    return false;
+}
+template <class TOPO>
+constexpr int tree_ee_run(int c0, int cend) {          // length of the run of columns from c0 that are all EE hinges / all not
+    int n = 1;
+    while (c0 + n < cend && tree_moves_ee<TOPO>(c0 + n) == tree_moves_ee<TOPO>(c0)) ++n;
+    return n;
+}
+// bit c of word j: M[j][c] may be non-zero (c at or above j, or j above c); bit c of *jcols: column c of J may be non-zero
+template <class TOPO>
+inline void tree_structure_masks(uint32_t mrow[32], uint32_t* jcols) {
+    *jcols = 0;
+    for (int j = 0; j < 32; ++j) {
+        mrow[j] = 0;
+        if (j >= TOPO::NJ) continue;
+        for (int c = 0; c < TOPO::NJ; ++c)
+            if (FeTopo<TOPO>::above(j, c) || FeTopo<TOPO>::above(c, j)) mrow[j] |= 1u << c;
+        if (tree_moves_ee<TOPO>(j)) *jcols |= 1u << j;
+    }
+}
+
 // LDS hand-over inside ONE wave (64-thread blocks): DS operations of a wave execute in order, so a compile-time
 // ordering point plus "all my DS operations are done" is a complete synchronisation.  __syncthreads() would also drain
 // every global load in flight (its fence covers all address spaces: s_waitcnt vmcnt(0)), i.e. the prefetched M stream.
@@ -474,16 +523,42 @@ struct Row16Train {
 // slot-1 rows are already eliminated) -- 283 broadcast-FMAs per wave instead of 745.  The entries of unrelated pairs come out
 // as exact zeros (0 - sum of products with exact zeros, scaled), so nothing has to be masked; Y = L^-T J^T rides along as
 // before and J M^-1 J^T = Y^T Y is the same identity.  Records of unknown origin (TOPO = void) keep the dense recursion.
+template <class TOPO>
+constexpr bool tree_row_of_y(int i) {
+    if constexpr (std::is_void_v<TOPO>) return true;
+    else return r16::tree_moves_ee<TOPO>(i);
+}
+// Column terms c = C0 .. C0 + NC - 1 (the subtree of hinge J below it) of the tree-structured recursion: the rows of the
+// factor in R0 / R1, of Y in T; runs of columns under an end effector carry the Y chain, the others (T[c] = 0) do not.
+template <class TOPO, int J, int C0, int NC, int NR0, int NR1, int NT>
+__device__ __forceinline__ void tree_chains(double& m0, double& m1, double& tj, const double (&R0)[NR0], const double (&R1)[NR1],
+                                            const double (&T)[NT]) {
+    if constexpr (NC > 0) {
+        constexpr int gj = J & 15;
+        constexpr int RUN = r16::tree_ee_run<TOPO>(C0, C0 + NC);
+        constexpr bool y = r16::tree_moves_ee<TOPO>(J) && r16::tree_moves_ee<TOPO>(C0);
+        if constexpr (J >= 16) {                                  // row J is a slot-1 row: the broadcasts come from R1
+            if constexpr (y) r16::fmac3_chain<gj, C0, RUN>(m1, m0, tj, R1, R0, T);
+            else r16::fmac2_chain<gj, C0, RUN>(m1, m0, R1, R0);
+        } else {                                                  // slot-1 rows are done
+            if constexpr (y) r16::fmac2_chain<gj, C0, RUN>(m0, tj, R0, T);
+            else r16::static_for<C0, C0 + RUN>([&](auto cc) { r16::fmac_bc_n<gj>(m0, R0[decltype(cc)::value], R0[decltype(cc)::value]); });
+        }
+        tree_chains<TOPO, J, C0 + RUN, NC - RUN>(m0, m1, tj, R0, R1, T);
+    }
+}
+
 template <int K, int NDEV, typename TIN, int N, bool FROMQ = false, class TOPO = void>
-__global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> tr) {
+__global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const Row16Train<TIN> tr) {
     using namespace r16;
-    constexpr bool TREE = FROMQ && !std::is_void_v<TOPO>;
+    constexpr bool TREE = !std::is_void_v<TOPO>;      // the records carry the zero pattern of this tree (fused path: by
+                                                      // construction; dense records: verified when they were uploaded)
     const KParams<TIN>& p = tr.p[blockIdx.y];
     const Row16Extra& x = tr.x[blockIdx.y];
     using TM = std::conditional_t<FROMQ, double, TIN>;      // type the M / J / dq / bias operands arrive in
     static_assert(N > 16 && N <= 32 && K >= 1 && K <= 16 && NDEV >= 1 && NDEV <= 4, "shape");
     constexpr int N1 = N - 16;                 // real rows in slot 1
-    constexpr int PF = 8;                      // rows of M in flight ahead of the column being eliminated
+    constexpr int PF = IRLOSC_R16_PF;          // rows of M in flight ahead of the column being eliminated
     __shared__ double Jl[4 * (K + 1) * N + 16];   // [q][r][i]; row K of each instance is zeros (lanes >= K read it)
     __shared__ double Wl[4][16];               // task vector, written by the device lanes
     __shared__ double Dxl[4][16];              // dx for the target-velocity branch
@@ -597,7 +672,10 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
         bias0_in = side_ld(use_g ? x.tables->btab[l] : zb);
         bias1_in = side_ld(use_g ? x.tables->btab[16 + l] : zb);
     } else {
-        static_for<0, PF>([&](auto jc) { constexpr int j = decltype(jc)::value; pm0[j] = m0p[j * N]; pm1[j] = m1p[j * N]; });
+        static_for<0, PF>([&](auto jc) {
+            constexpr int j = TREE ? N - 1 - decltype(jc)::value : decltype(jc)::value;
+            pm0[j] = m0p[j * N]; pm1[j] = m1p[j * N];
+        });
         const TIN* __restrict__ Jb = p.J + (size_t)bc * (K * N);
         const TIN* __restrict__ Jb1 = v1 ? Jb + 16 + l : zeros;
 #pragma unroll
@@ -707,22 +785,24 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
             constexpr int sj = j >> 4, gj = j & 15;
             constexpr int SZ = tree_subtree_size<TOPO>(j);          // hinges j .. j + SZ - 1 are the subtree of j
             static_assert(tree_subtree_contiguous<TOPO>(j), "depth-first numbering: a subtree is a run of indices");
+            constexpr bool EEJ = tree_moves_ee<TOPO>(j);            // otherwise column j of J and row j of Y are zero
             if constexpr (j - PF >= 0) {
-                pm0[j - PF] = side_at(mo0); pm1[j - PF] = side_at(mo1);
-                if constexpr (j - PF - 1 >= 0) { mo0 = Mt[(j - PF - 1) * 32 + l]; mo1 = Mt[(j - PF - 1) * 32 + 16 + l]; }
+                if constexpr (FROMQ) {
+                    pm0[j - PF] = side_at(mo0); pm1[j - PF] = side_at(mo1);
+                    if constexpr (j - PF - 1 >= 0) { mo0 = Mt[(j - PF - 1) * 32 + l]; mo1 = Mt[(j - PF - 1) * 32 + 16 + l]; }
+                } else {
+                    pm0[j - PF] = m0p[(j - PF) * N]; pm1[j - PF] = m1p[(j - PF) * N];
+                }
             }
             double m0 = (double)pm0[j], m1 = (double)pm1[j];
-            double tj = tnext;
-            if constexpr (j > 0) tnext = trow[j - 1];
+            double tj = EEJ ? tnext : 0.0;
+            if constexpr (j > 0) { if constexpr (tree_moves_ee<TOPO>(j - 1)) tnext = trow[j - 1]; }
             const double dqs = sj ? dq1 : dq0;
             __builtin_amdgcn_sched_barrier(0);
             fmac_bc_nop<gj>(mdq0, dqs, m0);
             fmac_bc<gj>(mdq1, dqs, m1);
-            fmac_bc<gj>(dx, dqs, tj);
-            if constexpr (SZ > 1) {
-                if constexpr (j >= 16) fmac3_chain<gj, j + 1, SZ - 1>(m1, m0, tj, R1, R0, T);      // row j is a slot-1 row
-                else fmac2_chain<gj, j + 1, SZ - 1>(m0, tj, R0, T);                              // slot-1 rows are done
-            }
+            if constexpr (EEJ) fmac_bc<gj>(dx, dqs, tj);
+            tree_chains<TOPO, j, j + 1, SZ - 1>(m0, m1, tj, R0, R1, T);
             double d = bc_nop<gj>(sj ? m1 : m0);
             flags |= !(d > 0.0) ? IRLOSC_FLAG_M_NOT_PD : 0u;      // also catches NaN
             d = fmax(d, 1e-300);
@@ -775,11 +855,13 @@ __global__ __launch_bounds__(64, 2) void osc_row16_kernel(const Row16Train<TIN> 
     for (int r = 0; r < K; ++r) A[r] = 0.0;
     static_for<0, N>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        static_for<0, K>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            if constexpr (i == 0 && r == 0) fmac_bc_nop<r>(A[r], T[i], T[i]);
-            else fmac_bc<r>(A[r], T[i], T[i]);
-        });
+        if constexpr (tree_row_of_y<TOPO>(i)) {               // tree: the rows of Y under no end effector are zero
+            static_for<0, K>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                if constexpr (i == 0 && r == 0) fmac_bc_nop<r>(A[r], T[i], T[i]);
+                else fmac_bc<r>(A[r], T[i], T[i]);
+            });
+        }
     });
     __builtin_amdgcn_sched_barrier(0);
 

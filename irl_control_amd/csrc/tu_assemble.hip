@@ -22,4 +22,13 @@ int launch_symmetry_probe(const T* M, int n, int B, int32_t* out, hipStream_t st
 template int launch_symmetry_probe<float>(const float*, int, int, int32_t*, hipStream_t);
 template int launch_symmetry_probe<double>(const double*, int, int, int32_t*, hipStream_t);
 
+template <typename T>
+int launch_structure_probe(const T* M, const T* J, int n, int k, int B, const StructureMasks& m, int32_t* out, hipStream_t st) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(osc_structure_kernel<T>, dim3(B < 16384 ? B : 16384), dim3(64), 0, st, M, J, n, k, B, m, out);
+    return (int)hipGetLastError();
+}
+template int launch_structure_probe<float>(const float*, const float*, int, int, int, const StructureMasks&, int32_t*, hipStream_t);
+template int launch_structure_probe<double>(const double*, const double*, int, int, int, const StructureMasks&, int32_t*, hipStream_t);
+
 }  // namespace irlosc

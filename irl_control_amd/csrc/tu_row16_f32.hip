@@ -7,11 +7,19 @@
 namespace irlosc {
 
 // nsteps steps of equal batch size B (the steps of one train), blockIdx.y = step
+// tree: see tu_row16_f64.hip
 template <typename TIN>
-int launch_row16(const Row16Train<TIN>& tr, int nsteps, hipStream_t st) {
+int launch_row16(const Row16Train<TIN>& tr, int nsteps, bool tree, hipStream_t st) {
     const KParams<TIN>& p = tr.p[0];
     if (p.B <= 0 || nsteps <= 0) return 0;
     const dim3 grid((p.B + 3) / 4, nsteps);
+    if (tree) {
+        if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25, false, TopoDualUr5>), grid, dim3(64), 0, st, tr);
+        else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<12, 2, TIN, 25, false, TopoDualUr5>), grid, dim3(64), 0, st, tr);
+        else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<7, 3, TIN, 25, false, TopoDualUr5>), grid, dim3(64), 0, st, tr);
+        else return (int)hipErrorNotSupported;
+        return (int)hipGetLastError();
+    }
     if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25>), grid, dim3(64), 0, st, tr);
     else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<12, 2, TIN, 25>), grid, dim3(64), 0, st, tr);
     else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<7, 3, TIN, 25>), grid, dim3(64), 0, st, tr);
@@ -45,7 +53,7 @@ int launch_row16_worklist(const Row16Train<TIN>& tr, int nsteps, int32_t* reset,
     return (int)hipGetLastError();
 }
 
-template int launch_row16<float>(const Row16Train<float>&, int, hipStream_t);
+template int launch_row16<float>(const Row16Train<float>&, int, bool, hipStream_t);
 template int launch_row16_fromq<float>(const Row16Train<float>&, int, hipStream_t);
 template int launch_row16_worklist<float>(const Row16Train<float>&, int, int32_t*, hipStream_t);
 

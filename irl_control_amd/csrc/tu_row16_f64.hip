@@ -7,11 +7,20 @@
 namespace irlosc {
 
 // nsteps steps of equal batch size B (the steps of one train), blockIdx.y = step
+// tree: every record of the train carries the zero pattern of the compiled Dual-UR5 tree (irlosc.hip keeps that verdict per
+// slot) -- the factorisation then runs in the tree-structured form on the dense records.
 template <typename TIN>
-int launch_row16(const Row16Train<TIN>& tr, int nsteps, hipStream_t st) {
+int launch_row16(const Row16Train<TIN>& tr, int nsteps, bool tree, hipStream_t st) {
     const KParams<TIN>& p = tr.p[0];
     if (p.B <= 0 || nsteps <= 0) return 0;
     const dim3 grid((p.B + 3) / 4, nsteps);
+    if (tree) {
+        if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25, false, TopoDualUr5>), grid, dim3(64), 0, st, tr);
+        else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<12, 2, TIN, 25, false, TopoDualUr5>), grid, dim3(64), 0, st, tr);
+        else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<7, 3, TIN, 25, false, TopoDualUr5>), grid, dim3(64), 0, st, tr);
+        else return (int)hipErrorNotSupported;
+        return (int)hipGetLastError();
+    }
     if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25>), grid, dim3(64), 0, st, tr);
     else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<12, 2, TIN, 25>), grid, dim3(64), 0, st, tr);
     else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<7, 3, TIN, 25>), grid, dim3(64), 0, st, tr);
@@ -45,8 +54,10 @@ int launch_row16_worklist(const Row16Train<TIN>& tr, int nsteps, int32_t* reset,
     return (int)hipGetLastError();
 }
 
-template int launch_row16<double>(const Row16Train<double>&, int, hipStream_t);
+template int launch_row16<double>(const Row16Train<double>&, int, bool, hipStream_t);
 template int launch_row16_fromq<double>(const Row16Train<double>&, int, hipStream_t);
 template int launch_row16_worklist<double>(const Row16Train<double>&, int, int32_t*, hipStream_t);
+
+void row16_tree_masks(uint32_t mrow[32], uint32_t* jcols) { r16::tree_structure_masks<TopoDualUr5>(mrow, jcols); }
 
 }  // namespace irlosc

@@ -33,6 +33,18 @@ def make_layout(cfg: str) -> OSCLayout:
                      admittance=fl.get("admittance", False))
 
 
+def targets_near(ee_pose: np.ndarray, rng: np.random.Generator) -> np.ndarray:
+    """Target poses around given end-effector poses [B, ndev, 7], the recipe of SURVEY.md section 8d: position + N(0, 0.2^2) per
+    axis (a mix of velocity-saturated and unsaturated errors), orientation turned by U(0, 0.5 rad) about a random axis."""
+    ee = np.asarray(ee_pose, dtype=np.float64)
+    B, nd = ee.shape[:2]
+    ang = rng.uniform(0.0, 0.5, size=(B, nd, 1))
+    ax = rng.normal(size=(B, nd, 3))
+    ax /= np.linalg.norm(ax, axis=2, keepdims=True)
+    dquat = np.concatenate([np.cos(ang / 2), np.sin(ang / 2) * ax], axis=2)
+    return np.concatenate([ee[:, :, :3] + rng.normal(0.0, 0.2, size=(B, nd, 3)), quat_mul(ee[:, :, 3:], dquat)], axis=2)
+
+
 def make_batch(cfg: str, B: int, seed: int = 0, dtype=np.float64, per_instance_gains: bool = False):
     """-> (layout, gains dict, arrays dict) with arrays in the C-ABI record layout."""
     rng = np.random.default_rng(seed)

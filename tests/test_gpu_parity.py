@@ -1314,3 +1314,109 @@ def test_fleet_action_sequence_lockstep_equals_solo_runs():
         n = solo["u"].shape[0]
         assert n == 600
         assert np.array_equal(solo["u"][:, 0], fleet["u"][:n, b])
+
+
+# ---- tree-structured factorisation on DENSE records (irlosc_slot_structure) ------------------------------------------------
+def _physical_records(cfg, B, dtype, seed, singular_every=7):
+    """Dense records of random robot states as the front end writes them (+ the setup's targets and gains)."""
+    lay, gains, g, model, osc, states = _from_q_setup(cfg, B, dtype, seed=seed, singular_every=singular_every)
+    osc.frontend()
+    assert osc.slot_structure(0)                          # the lane kernel's records: tree form by construction
+    rec = osc.download_records(0)
+    u, fl = osc.step(return_flags=True)
+    osc.close()
+    if lay.admittance:
+        rec["wrench"] = g["wrench"]
+    return lay, gains, g, rec, u, fl
+
+
+def _run_uploaded(lay, gains, g, rec, dtype, n_slots=1):
+    B = rec["M"].shape[0]
+    osc = BatchedOSC(lay, B, dtype=dtype, n_slots=n_slots, kernel=_lib.KERNEL_ROW16)
+    osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+    osc.upload(rec["M"], rec["J"], rec["dq"], rec["bias"], rec["ee_pose"], rec.get("wrench"))
+    osc.set_targets(g["tgt_pose"][:B], g.get("tgt_vel"))
+    st = osc.slot_structure(0)
+    u, fl = osc.step(return_flags=True)
+    osc.close()
+    return st, u, fl
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("cfg", ["k13", "k7", "k12_admit"])
+def test_tree_form_on_dense_records_equals_the_dense_recursion_and_the_oracle(cfg, dtype, monkeypatch):
+    """Records of physical robot states carry the zeros of the kinematic tree (what mj_fullM / mj_jacBody leave,
+    robot.py:68-72, device.py:115-133).  Uploaded, they are probed and the row16 kernel factors M in the tree-structured
+    form; the same records with IRLOSC_TREE=0 go through the dense recursion.  Same flags, torques equal to rounding, both
+    within north_star's 1e-5 of the float64 oracle on the same records."""
+    B = 1024 + 13
+    lay, gains, g, rec, u_fe, fl_fe = _physical_records(cfg, B, dtype, seed=41)
+    st_t, u_t, fl_t = _run_uploaded(lay, gains, g, rec, dtype)
+    assert st_t                                             # the probe accepted the uploaded records
+    if not lay.admittance:                                  # (the front end's slot had no wrench yet)
+        assert np.array_equal(u_t, u_fe) and np.array_equal(fl_t, fl_fe)      # same kernel as on the front end's own records
+    monkeypatch.setenv("IRLOSC_TREE", "0")
+    st_d, u_d, fl_d = _run_uploaded(lay, gains, g, rec, dtype)
+    assert not st_d
+    d = rel_err(u_t, u_d.astype(np.float64))
+    assert np.array_equal(fl_t, fl_d)
+    assert d.max() <= (1e-8 if dtype == np.float64 else 5e-7), float(d.max())      # float32 records: the outputs are rounded to float32
+    if cfg != "k7":
+        assert (fl_t & _lib.FLAG_EIGEN_PATH).mean() > 0.02
+    r = {k: np.asarray(v, dtype=np.float64) for k, v in rec.items()}
+    n = 256
+    ref = osc_oracle.generate_batch(lay.as_oracle_dict(), gains, r["M"][:n], r["J"][:n], r["dq"][:n], r["bias"][:n], r["ee_pose"][:n],
+                                    np.asarray(g["tgt_pose"][:n], dtype=np.float64), r["wrench"][:n] if "wrench" in r else None)
+    dom = np.array([in_parity_domain(*osc_oracle.task_inertia(r["J"][b], r["M"][b])[2:]) for b in range(n)])
+    assert dom.sum() >= n // 2
+    assert rel_err(u_t[:n], ref)[dom].max() <= TOL64 and rel_err(u_d[:n], ref)[dom].max() <= TOL64
+
+
+def test_structure_probe_refuses_what_does_not_carry_the_tree_zeros():
+    """irlosc_slot_structure: the verdict is per slot and exact -- one non-zero where the tree has no coupling (between the
+    two arms in M; a gripper column of J), a batch under 64 instances, records of unknown origin (synthetic dense M): dense
+    recursion, and the answer is the dense recursion's bit for bit."""
+    B = 256
+    lay, gains, g, rec, _, _ = _physical_records("k13", B, np.float64, seed=43)
+    st, u_ok, fl_ok = _run_uploaded(lay, gains, g, rec, np.float64)
+    assert st
+    bad = {k: v.copy() for k, v in rec.items()}
+    bad["M"][5, 3, 20] = bad["M"][5, 20, 3] = 1e-9          # right arm <-> left arm
+    st_m, u_m, _ = _run_uploaded(lay, gains, g, bad, np.float64)
+    assert not st_m and np.all(np.isfinite(u_m))
+    bad = {k: v.copy() for k, v in rec.items()}
+    bad["J"][7, 0, 9] = 1e-12                               # a gripper hinge moving an end effector
+    st_j, u_j, _ = _run_uploaded(lay, gains, g, bad, np.float64)
+    assert not st_j
+    small = {k: v[:63] for k, v in rec.items()}
+    st_s, u_s, fl_s = _run_uploaded(lay, gains, g, small, np.float64)
+    assert not st_s
+    assert rel_err(u_s, u_ok[:63]).max() <= 1e-8 and np.array_equal(fl_s, fl_ok[:63])
+    _, gains2, a = synth.make_batch("k13", B, seed=3, dtype=np.float64)
+    st_x, _, _ = _run_uploaded(lay, gains2, a, a, np.float64)
+    assert not st_x
+
+
+def test_trains_mixing_tree_and_dense_slots_fall_back_to_the_dense_recursion():
+    """One launch per train, one kernel per launch: a train of irlosc_step_resident uses the tree form only when every slot
+    in it qualifies.  Two slots, one of them with synthetic dense records: every slot's result equals its own single step
+    bit for bit (tree slot: its dense-recursion result)."""
+    B = 512
+    lay, gains, g, rec, _, _ = _physical_records("k13", B, np.float64, seed=47)
+    _, _, a = synth.make_batch("k13", B, seed=9, dtype=np.float64)
+    osc = BatchedOSC(lay, B, dtype=np.float64, n_slots=2, kernel=_lib.KERNEL_ROW16)
+    osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+    osc.upload(rec["M"], rec["J"], rec["dq"], rec["bias"], rec["ee_pose"], slot=0)
+    osc.upload(a["M"], a["J"], a["dq"], a["bias"], a["ee_pose"], slot=1)
+    osc.set_targets(g["tgt_pose"][:B], slot=0)
+    osc.set_targets(a["tgt_pose"], slot=1)
+    assert osc.slot_structure(0) and not osc.slot_structure(1)
+    u0_tree = osc.step(slot=0)
+    u1 = osc.step(slot=1)
+    osc.step_resident(2, first_slot=0)                      # train {0, 1}: dense recursion for both; last step = slot 1
+    u_last, _ = osc.download(B)
+    assert np.array_equal(u_last, u1)
+    osc.step_resident(3, first_slot=0)                      # train {0, 1, 0}: last step = slot 0 through the dense recursion
+    u_last0, _ = osc.download(B)
+    osc.close()
+    assert rel_err(u_last0, u0_tree.astype(np.float64)).max() <= 1e-8

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Mean cycles per kernel phase (IRLOSC_PHASE_TIMING=1 debug aid of libirlosc).  usage: phase_timing.py [f32|f64] [layout] [B]"""
+"""Mean cycles per kernel phase (IRLOSC_PHASE_TIMING=1 debug aid of libirlosc).  usage: phase_timing.py [f32|f64] [layout] [B] [phys]
+"phys": records of physical robot states (front end), which qualify for the tree-structured form (IRLOSC_TREE=0: dense)."""
 import os
 import sys
 os.environ["IRLOSC_PHASE_TIMING"] = "1"
@@ -13,8 +14,19 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 lay, gains, arr = synth.make_batch(cfg, B, seed=7, dtype=dt)
 osc = BatchedOSC(lay, B, dtype=dt)
 osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
-osc.upload(arr["M"], arr["J"], arr["dq"], arr["bias"], arr["ee_pose"], arr.get("wrench"))
-osc.set_targets(arr["tgt_pose"], arr.get("tgt_vel"))
+if len(sys.argv) > 4 and sys.argv[4] == "phys":
+    from irl_control_amd.rigid_body import RigidBodyModel
+    model = RigidBodyModel.load("dual_ur5")
+    rng = np.random.default_rng(5)
+    osc.set_model(model)
+    osc.upload_q(*model.random_state(rng, B))
+    osc.frontend()
+    ee = osc.download_records(0, keys=("ee_pose",))["ee_pose"].astype(np.float64)
+    osc.set_targets(synth.targets_near(ee, rng).astype(dt))
+    print("tree form:", osc.slot_structure(0))
+else:
+    osc.upload(arr["M"], arr["J"], arr["dq"], arr["bias"], arr["ee_pose"], arr.get("wrench"))
+    osc.set_targets(arr["tgt_pose"], arr.get("tgt_vel"))
 for _ in range(3):
     osc.step_resident(50)
     osc.download(B)       # prints the phase table to stderr
