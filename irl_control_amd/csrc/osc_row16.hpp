@@ -327,12 +327,14 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
             for (int j = i; j < NV; ++j) { h[i][j] = row_sum(v[i] * av[j]); h[j][i] = h[i][j]; }
         }
         for (int sweep = 0; sweep < 6; ++sweep) {
+            bool turned = false;               // a sweep without a rotation anywhere in the wave: all later ones are identities
 #pragma unroll
             for (int p2 = 0; p2 < NV - 1; ++p2) {
 #pragma unroll
                 for (int q2 = p2 + 1; q2 < NV; ++q2) {
                     const double hpq = h[p2][q2], hpp = h[p2][p2], hqq = h[q2][q2];
                     const bool rot = has[p2] && has[q2] && fabs(hpq) > 1e-300 && fabs(hpq) > 1e-18 * (fabs(hpp) + fabs(hqq));
+                    turned = turned || rot;
                     double theta = (hqq - hpp) * rcp_refined(rot ? 2.0 * hpq : 1.0);
                     theta = fmin(fmax(theta, -1e100), 1e100);      // theta^2 must stay finite (then t ~ 1 / (2 theta) ~ 0)
                     const double tq = (theta >= 0.0 ? 1.0 : -1.0) * rcp_refined(fabs(theta) + sqrt_fast(theta * theta + 1.0));
@@ -355,6 +357,7 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
                     v[q2] = sn * vp + cs * vq;
                 }
             }
+            if (!__any(turned)) break;
         }
 #pragma unroll
         for (int i = 0; i < NV; ++i) th[i] = (m >= 2 && has[i]) ? h[i][i] - 0.0 : th[i];
@@ -390,11 +393,16 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
     }
     // t = P (A + sigma)^-1 P w
     double tt = w;
+    bool live[NV];                     // a vector that is zero in every lane of the wave projects nothing (the usual case:
+#pragma unroll                         // one eigenvector cut, or none)
+    for (int s0 = 0; s0 < NV; ++s0) live[s0] = __any(v[s0] != 0.0);
 #pragma unroll
-    for (int s0 = 0; s0 < NV; ++s0) tt = fma(-row_sum(v[s0] * tt), v[s0], tt);
+    for (int s0 = 0; s0 < NV; ++s0)
+        if (live[s0]) tt = fma(-row_sum(v[s0] * tt), v[s0], tt);
     solve16<K>(tt, F, G, invd_own);
 #pragma unroll
-    for (int s0 = 0; s0 < NV; ++s0) tt = fma(-row_sum(v[s0] * tt), v[s0], tt);
+    for (int s0 = 0; s0 < NV; ++s0)
+        if (live[s0]) tt = fma(-row_sum(v[s0] * tt), v[s0], tt);
     t = tt;
     fl = ncut > 0 ? IRLOSC_FLAG_TRUNCATED : 0u;
 }
