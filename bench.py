@@ -8,6 +8,15 @@ A "step" is one pass of the OSC hot path over one resident batch of B synthetic 
 terms on: BASELINE.json configs[2]).  Inputs are resident in HBM before the timed region; `--slots` distinct
 batches are rotated so that successive launches do not re-hit the 256 MiB Infinity Cache.
 
+--workload names where the dense records (M, J, dq, bias, EE poses: 8 536 B per instance in float64) come from:
+  physical   (default) SURVEY.md section 8d's "true CRBA on random qpos": uniformly random joint states of the Dual-UR5, their
+             records computed ONCE by the rigid-body front end before the timed region, targets scattered around the end
+             effectors.  Such records carry the zeros of the kinematic tree (the two arms do not couple in M, the gripper
+             joints move no end effector) exactly as MuJoCo's mj_fullM / mj_jacBody leave them, the library verifies
+             that when records arrive, and the fp64 row16 kernel then factors M in the tree-structured form.
+  synthetic  the recipe of the same section for when there is no front end: a random dense SPD M (no structural zeros),
+             random J with the physical column pattern.  The headline of rounds 1-3; still reported under "secondary".
+
 --dtype names the ARITHMETIC of the measured path:
   f64    float64 records, float64 arithmetic (osc_row16 kernel)  - the reference's precision, meets north_star's 1e-5
   mixed  float32 records, float64 arithmetic (osc_row16 kernel)  - BASELINE configs[2]'s fp32 storage at the 1e-5 bar
@@ -382,6 +391,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other arithmetic / storage variants")
     ap.add_argument("--no-from-q", action="store_true", help="skip the joint-coordinates path (front end + step)")
+    ap.add_argument("--workload", default="physical", choices=["physical", "synthetic"],
+                    help="physical: records of random joint states from the front end (tree zeros); synthetic: random dense SPD M")
+    ap.add_argument("--mint-physical", default=None, help=argparse.SUPPRESS)   # internal: write slot 0 of the physical workload to this directory
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -401,14 +413,44 @@ def main():
     def make_slot(mode, s):
         return synth.make_batch(args.layout, B, seed=20241008 + 1000 * 2 + 17 * s + 101 * rank, dtype=MODES[mode][0])
 
-    def measure(mode, steps, warmup, preroll):
-        dt, arith, kern = MODES[mode]
-        if args.kernel >= 0:
-            kern = args.kernel
-        esz = np.dtype(dt).itemsize
-        lay = synth.make_layout(args.layout)
-        osc = BatchedOSC(lay, B, dtype=dt, hip_device=local_rank, n_slots=args.slots, kernel=kern)
+    def fill_physical(osc, lay, dt, s, model):
+        """Slot s of the physical workload: random joint states -> front end (records stay in HBM) -> targets around the end
+        effectors it found (-> wrench for the admittance layout, which only arrives with an upload of records).  Returns
+        slot 0's records as host arrays (what the oracle legs are run on), None for the other slots."""
+        rng = np.random.default_rng(20241008 + 1000 * 2 + 17 * s + 101 * rank + 500000)
+        qpos, qvel = model.random_state(rng, B)
+        osc.upload_q(qpos, qvel, slot=s)
+        osc.frontend(slot=s)
+        ee = osc.download_records(s, keys=("ee_pose",))["ee_pose"]
+        tgt = synth.targets_near(ee.astype(np.float64), rng).astype(dt)
+        wrench = rng.normal(0.0, 5.0, size=(B, lay.ndev, 6)).astype(dt) if lay.admittance else None
+        rec = None
+        if wrench is not None or s == 0:
+            rec = osc.download_records(s)
+        if wrench is not None:
+            osc.upload(rec["M"], rec["J"], rec["dq"], rec["bias"], rec["ee_pose"], wrench, slot=s)
+        osc.set_targets(tgt, None, slot=s)
+        if s != 0:
+            return None
+        rec["tgt_pose"] = tgt
+        if wrench is not None:
+            rec["wrench"] = wrench
+        return rec
+
+    def fill_slots(osc, lay, mode, workload):
+        """-> (gains, slot 0 as host arrays)."""
+        dt = MODES[mode][0]
         slot0 = None
+        if workload == "physical":
+            from irl_control_amd.rigid_body import RigidBodyModel
+            model = RigidBodyModel.load("dual_ur5")
+            osc.set_model(model)
+            _, gains, _ = synth.make_batch(args.layout, 2, seed=1, dtype=dt)       # the YAML gain set of the layout
+            osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+            for s in range(args.slots):
+                r = fill_physical(osc, lay, dt, s, model)
+                slot0 = r if s == 0 else slot0
+            return gains, slot0
         for s in range(args.slots):
             _, gains, arr = make_slot(mode, s)
             osc.upload(arr["M"], arr["J"], arr["dq"], arr["bias"], arr["ee_pose"], arr.get("wrench"), slot=s)
@@ -419,6 +461,29 @@ def main():
                               gains["null_kv"])
             else:
                 del arr
+        return gains, slot0
+
+    if args.mint_physical:        # internal: slot 0 of the physical workload as .npy files, for the CPU legs of the parent process
+        dt = MODES[args.dtype][0]
+        lay = synth.make_layout(args.layout)
+        osc = BatchedOSC(lay, B, dtype=dt, hip_device=local_rank, n_slots=args.slots, kernel=MODES[args.dtype][2])
+        from irl_control_amd.rigid_body import RigidBodyModel
+        model = RigidBodyModel.load("dual_ur5")
+        osc.set_model(model)
+        rec = fill_physical(osc, lay, dt, 0, model)
+        osc.close()
+        for k2, v in rec.items():
+            np.save(os.path.join(args.mint_physical, k2 + ".npy"), v)
+        return
+
+    def measure(mode, steps, warmup, preroll, workload):
+        dt, arith, kern = MODES[mode]
+        if args.kernel >= 0:
+            kern = args.kernel
+        esz = np.dtype(dt).itemsize
+        lay = synth.make_layout(args.layout)
+        osc = BatchedOSC(lay, B, dtype=dt, hip_device=local_rank, n_slots=args.slots, kernel=kern)
+        gains, slot0 = fill_slots(osc, lay, mode, workload)
         if preroll > 0:                                          # untimed: lets the clocks settle after the idle set-up
             osc.step_resident(preroll)
         if warmup > 0:
@@ -443,12 +508,15 @@ def main():
             ms_dom = comm.reduce(0.0, ms_dom)[1]
             ms_kernel = comm.reduce(0.0, ms_kernel)[1]
         achieved = bytes_launch / (ms_dom * 1e-3) / 1e9
-        kname = osc.kernel_name
+        tree = all(osc.slot_structure(sl) for sl in range(args.slots))
+        kname = osc.kernel_name + ("+tree" if tree else "")
         note = ""
         if "group" in kname:
             note = ":fused(stage 1 of %d chained steps + riding stage 2 of the previous launch)" % spl
         elif "row16" in kname:
-            note = ":step(all instances incl. the in-kernel truncated-pinv stage; + the give-up list launch)"
+            note = ":step(all instances incl. the in-kernel truncated-pinv stage; + the give-up list launch)" + (
+                "; tree-structured factorisation M = L^T L on the dense records (their zero pattern verified at upload / by construction)"
+                if tree else "")
         prof = measured_profile(kname)
         roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=achieved / HBM_PEAK_GBS, traffic=prof.get("traffic_bytes_per_launch"),
@@ -462,7 +530,7 @@ def main():
             roof["rocprof_kernel_ms"] = prof["rocprof_avg_us"] * 1e-3
             roof["frac_rocprof"] = bytes_launch / (prof["rocprof_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
         res = dict(value=rate, ms_per_step=elapsed / steps * 1e3, kernel=kname, mode=mode, arith=arith,
-                   records="float64" if esz == 8 else "float32", layout=lay, roofline=roof)
+                   records="float64" if esz == 8 else "float32", layout=lay, roofline=roof, workload=workload)
         osc.step(slot=0)
         u, fl = osc.download(B)
         res["checksum"] = sharding.checksum_u64(u)
@@ -471,18 +539,33 @@ def main():
 
     # CPU legs first: their worker processes are forked before this process has initialised the HIP runtime
     cb = ref = ref_idx = fq_state = fq_ref = None
-    sec_refs = {}
     others = [m for m in ("f64", "mixed", "f32") if m != args.dtype] if (world == 1 and not args.no_secondary) else []
+    NSEC = 4096                       # instances of slot 0 the secondary modes are checked on (oracle in this process)
+    minted_crc = None
     if world == 1 and not args.no_cpu_baseline:
-        lay0, gains0, arr0 = make_slot(args.dtype, 0)
+        if args.workload == "physical":
+            # The records of the physical workload come from the GPU front end, and the CPU legs fork their workers before
+            # THIS process touches the HIP runtime: a child process computes slot 0 (same seeds, same kernel: the same bits,
+            # checked below) and leaves it in a private directory.
+            import shutil
+            import tempfile
+            base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+            d = tempfile.mkdtemp(prefix="irlosc_mint_", dir=base)
+            try:
+                cmd = [sys.executable, os.path.abspath(__file__), "--mint-physical", d, "--batch", str(B), "--layout", args.layout,
+                       "--dtype", args.dtype, "--slots", "1"]
+                env = dict(os.environ)
+                env["IRLOSC_BENCH_DEVICE"] = str(local_rank)
+                subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL)
+                arr0 = {f[:-4]: np.load(os.path.join(d, f)) for f in sorted(os.listdir(d)) if f.endswith(".npy")}
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+            lay0 = synth.make_layout(args.layout)
+            _, gains0, _ = synth.make_batch(args.layout, 2, seed=1, dtype=MODES[args.dtype][0])
+            minted_crc = sharding.checksum_u64(arr0["M"])
+        else:
+            lay0, gains0, arr0 = make_slot(args.dtype, 0)
         cb, ref, ref_idx = cpu_baseline(lay0, gains0, arr0)
-        # the same instances through the oracle on float32-rounded records, for the modes that store float32
-        NSEC = 4096
-        for other in others:
-            if MODES[other][0] != MODES[args.dtype][0] and MODES[other][0] not in sec_refs:
-                _, g_o, arr_o = make_slot(other, 0)
-                sec_refs[MODES[other][0]] = oracle_reference(lay0, g_o, arr_o, 0, min(NSEC, B))
-                del arr_o
         if not args.no_from_q and args.layout in ("k13", "k7"):
             from irl_control_amd.rigid_body import RigidBodyModel
             model = RigidBodyModel.load("dual_ur5")
@@ -491,7 +574,9 @@ def main():
             fq_ref = from_q_reference(lay0, gq, fq_state[0], fq_state[1], aq["tgt_pose"], 4096, effective_cores()[0])
             del aq
         del arr0
-    primary, chk = measure(args.dtype, args.steps, args.warmup, preroll=args.preroll)
+    primary, chk = measure(args.dtype, args.steps, args.warmup, preroll=args.preroll, workload=args.workload)
+    if minted_crc is not None and sharding.checksum_u64(chk[2]["M"]) != minted_crc:
+        raise RuntimeError("slot 0 of the physical workload differs between the minting process and this one")
     lay = primary.pop("layout")
     names = ", ".join(f"{nm}:{r}" for nm, r in zip(lay.dev_names, lay.dev_rows))
     out = {
@@ -500,13 +585,16 @@ def main():
         "higher_is_better": True, "scaling": "strong" if args.total_batch else "weak", "vs_baseline": None,
         "dtype": primary["arith"], "data": "synthetic",
         "config": {"workload": f"{B} Dual-UR5 instances per GPU ({baseline_config_of(args.layout, B, world, args.dtype)}), "
+                               + ("records of uniformly random joint states (SURVEY.md 8d: true CRBA on random qpos) computed once by "
+                                  "the rigid-body front end before the timed region, targets scattered around the end effectors, "
+                                  if args.workload == "physical" else "synthetic records (random dense SPD M, SURVEY.md 8d), ") +
                                f"n={lay.n} joints, layout {args.layout}: k={lay.k} task rows over {lay.ndev} target devices "
                                f"({names}), gravity {'on' if lay.use_g else 'off'}, null-space {'on' if lay.nullspace else 'off'}, "
                                f"admittance wrench term {'on' if lay.admittance else 'off'}, {primary['records']} records, "
                                f"{primary['arith']} arithmetic, inputs resident in HBM, {args.slots} rotating batches",
                    "instances_per_gpu": B, "layout": args.layout, "k": lay.k, "ndev": lay.ndev,
                    "admittance": bool(lay.admittance), "records": primary["records"], "arithmetic": primary["arith"],
-                   "kernel": primary["kernel"], "preroll_steps": args.preroll,
+                   "kernel": primary["kernel"], "records_from": args.workload, "preroll_steps": args.preroll,
                    "steps_per_launch": primary["roofline"]["steps_per_launch"],
                    "sharding": f"{world} x independent shards, no data-path collective; barrier and final sum(steps) / "
                                f"max(elapsed) reduction: {comm_note}"},
@@ -522,35 +610,32 @@ def main():
         if cb is not None:
             out["cpu_baseline"] = cb
             out["parity_sample"] = parity_sample(arr, u, ref, ref_idx)
-    if others:
+    runs = [(m, args.workload) for m in others]
+    if others and args.workload == "physical":
+        runs.append((args.dtype, "synthetic"))         # the workload of rounds 1-3 (dense M without structural zeros), for comparison
+    if runs:
         out["secondary"] = []
-        for other in others:
+        for other, wl in runs:
             try:
                 sec, schk = measure(other, max(24, min(200, args.steps // 4)), max(8, min(24, args.warmup // 4)),
-                                    preroll=min(args.preroll, 100))
+                                    preroll=min(args.preroll, 100), workload=wl)
             except Exception as e:                       # e.g. a layout without a group kernel
-                out["secondary"].append({"mode": other, "error": str(e)})
+                out["secondary"].append({"mode": other, "records_from": wl, "error": str(e)})
                 continue
-            sec.pop("layout")
-            entry = {"mode": other, "dtype": sec["arith"], "records": sec["records"], "value": sec["value"],
+            slay = sec.pop("layout")
+            entry = {"mode": other, "records_from": wl, "dtype": sec["arith"], "records": sec["records"], "value": sec["value"],
                      "ms_per_step": sec["ms_per_step"], "kernel": sec["kernel"], "roofline": sec["roofline"]}
-            rdt = MODES[other][0]
-            sref = sec_refs.get(rdt) if rdt != MODES[args.dtype][0] else (None if ref is None else ref)
-            if sref is not None:
-                _, _, sarr, su, _ = schk
-                if rdt != MODES[args.dtype][0]:
-                    n = len(sref)
-                    full = np.full((su.shape[0], su.shape[1]), np.nan)
-                    full[:n] = sref
-                    sidx = range(n)
-                else:
-                    full, sidx = sref, ref_idx
+            if not args.no_cpu_baseline:                 # the oracle in this process on the first instances of slot 0
+                _, sgains, sarr, su, _ = schk
+                n = min(NSEC, B)
+                full = np.full((su.shape[0], su.shape[1]), np.nan)
+                full[:n] = oracle_reference(slay, sgains, sarr, 0, n)
                 f32 = sec["arith"] == "f32"
                 entry["parity_sample"] = parity_sample(
-                    sarr, su, full, sidx, tol=1e-5,
+                    sarr, su, full, range(n), tol=1e-5,
                     note=("float32 ARITHMETIC: error ~ eps32 * cond(J M^-1 J^T); this mode is the fastest one and does NOT meet "
                           "north_star's 1e-5 (n_over_tol says by how much); " if f32 else "")
-                         + "GPU vs float64 oracle on the same float32-rounded records; parity domain per SURVEY.md 8c")
+                         + "GPU vs float64 oracle on the same (record-dtype-rounded) records; parity domain per SURVEY.md 8c")
             out["secondary"].append(entry)
     if world == 1 and not args.no_from_q:
         out["from_q"] = measure_from_q(BatchedOSC, synth, args, B, local_rank, fq_state, fq_ref)

@@ -39,12 +39,17 @@
 #include "osc_frontend_lane.hpp" // FeTopo: compile-time queries on a tree shape (FROMQ with a compiled topology)
 #include "osc_row16_asm.hpp"     // generated: the main loop's broadcast-FMA chains as asm blocks
 
-// A/B builds only (tools/build_variant.py): waves per SIMD the register allocator is asked for, prefetch depth of M.
+// Waves per SIMD the register allocator is asked for, and the prefetch depth of M (rows in flight ahead of the column being
+// eliminated).  Three waves need <= 168 registers: every shape compiles to that WITHOUT scratch at depth 4 (at depth 5 and
+// more the k = 13 shapes spill, and a kernel that touches scratch at all loses far more than the third wave brings: 175 vs
+// 121 us per step).  What made room: the pivot tests pinned where they happen (pinned_ballot), bias / null-space gain /
+// instance id fetched where they are used, M dq parked in two free LDS rows across the k x k and eigen stages.
+// tools/build_variant.py overrides both for A/B builds.
 #ifndef IRLOSC_R16_WAVES
-#define IRLOSC_R16_WAVES 2
+#define IRLOSC_R16_WAVES 3
 #endif
 #ifndef IRLOSC_R16_PF
-#define IRLOSC_R16_PF 8
+#define IRLOSC_R16_PF 4
 #endif
 #ifndef IRLOSC_EIG_MAXIT
 #define IRLOSC_EIG_MAXIT 12
@@ -252,7 +257,9 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
 #pragma unroll
     for (int slot = 0; slot < NV; ++slot) {
         if (!__any(active)) break;
-        double x = l < K ? 0.3 + 0.1 * (double)(((l + 3 * slot) * 5) % 7) - 0.05 * (double)slot : 0.0;
+        int lq = l;
+        asm volatile("" : "+v"(lq));       // (keeps the four start vectors from being computed ahead of the stage and carried through it)
+        double x = lq < K ? 0.3 + 0.1 * (double)(((lq + 3 * slot) * 5) % 7) - 0.05 * (double)slot : 0.0;
         double lam = 0.0, lam_prev = -1.0;
         bool fin = !active;
         for (int it = 0; it < IRLOSC_EIG_MAXIT; ++it) {
@@ -478,6 +485,14 @@ inline void tree_structure_masks(uint32_t mrow[32], uint32_t* jcols) {
     }
 }
 
+// The lanes where `c` holds, as a scalar mask, evaluated HERE: without the pin the compiler sinks the 25 pivot tests of the
+// main loop to where `flags` is finally used and carries all 25 pivots there in vector registers.
+__device__ __forceinline__ unsigned long long pinned_ballot(const bool c) {
+    unsigned long long m = __ballot(c);
+    asm volatile("" : "+s"(m));
+    return m;
+}
+
 // LDS hand-over inside ONE wave (64-thread blocks): DS operations of a wave execute in order, so a compile-time
 // ordering point plus "all my DS operations are done" is a complete synchronisation.  __syncthreads() would also drain
 // every global load in flight (its fence covers all address spaces: s_waitcnt vmcnt(0)), i.e. the prefetched M stream.
@@ -662,7 +677,7 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
     // ---- prologue: first rows of M in flight, J (coalesced) into LDS, dq ------------------------------------------
     TM pm0[N], pm1[N];
     TM jl0[K], jl1[K];
-    TM dq0_in, dq1_in, bias0_in, bias1_in;
+    TM dq0_in, dq1_in;
     const bool use_g = (p.cfgflags & IRLOSC_USE_G) != 0;
     unsigned mo0 = 0, mo1 = 0;      // FROMQ: entries of the next row of M to be requested (table reads run one column ahead)
     if constexpr (FROMQ) {
@@ -677,8 +692,6 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
         for (int r = 0; r < K; ++r) { jl0[r] = side_at(Jt[r * 32 + l]); jl1[r] = side_at(Jt[r * 32 + 16 + l]); }
         dq0_in = x.qvel[(size_t)bc * N + l];
         dq1_in = v1 ? x.qvel[(size_t)bc * N + 16 + l] : 0.0;
-        bias0_in = side_ld(use_g ? x.tables->btab[l] : zb);
-        bias1_in = side_ld(use_g ? x.tables->btab[16 + l] : zb);
     } else {
         static_for<0, PF>([&](auto jc) {
             constexpr int j = TREE ? N - 1 - decltype(jc)::value : decltype(jc)::value;
@@ -690,8 +703,6 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
         for (int r = 0; r < K; ++r) { jl0[r] = Jb[r * N + l]; jl1[r] = Jb1[r * N]; }
         dq0_in = p.dq[(size_t)bc * N + l];
         dq1_in = (v1 ? p.dq + (size_t)bc * N + 16 + l : zeros)[0];
-        bias0_in = (use_g ? p.bias + (size_t)bc * N + l : zeros)[0];
-        bias1_in = (use_g && v1 ? p.bias + (size_t)bc * N + 16 + l : zeros)[0];
     }
     Wl[q][l] = 0.0;
     lds_sync();
@@ -699,7 +710,22 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
     // ---- task-space signal, part 1 (osc.py:101-118,70-99,160-168): quad d of the row = device d -------------------
     // Lane a of the quad evaluates ONE of the three Euler angles (the fp64 atan2 is the expensive part), the quad
     // broadcasts them, every lane of the quad finishes the gains, lane 0 parks the controlled rows in LDS.
-    const double kvn = (p.cfgflags & IRLOSC_NULLSPACE) ? (double)p.null_kv[p.gains_per_instance ? bc : 0] : 0.0;
+    // Values that are needed once in the middle and once at the very end -- the null-space gain, the bias forces, the instance
+    // id -- are fetched / recomputed WHERE they are used (cached lines, a handful of instructions) instead of riding through
+    // the whole kernel in vector registers: `late()` makes the lane id opaque so that the compiler cannot share the early copy.
+    auto late_lane = [&]() { int t2 = threadIdx.x; asm volatile("" : "+v"(t2)); return t2; };
+    auto late_bc = [&](const int lane2) {
+        int blk2 = blockIdx.x;
+        if constexpr (FROMQ) {
+            if (x.xcd_map) { const int r = blk2 & 127; blk2 = ((blk2 >> 7) * 8 + (r & 7)) * 16 + (r >> 3); }
+        }
+        return blk2 * 4 + (lane2 >> 4);
+    };
+    auto load_kvn = [&]() -> double {
+        if (!(p.cfgflags & IRLOSC_NULLSPACE)) return 0.0;
+        const int b2 = late_bc(late_lane());
+        return (double)p.null_kv[p.gains_per_instance ? (b2 < p.B ? b2 : p.B - 1) : 0];
+    };
     const bool has_wr = (p.cfgflags & IRLOSC_ADMITTANCE) && p.wrench != nullptr;
     const DevMeta dm = p.dev[dd];
     bool own_brB = false;
@@ -781,6 +807,7 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
     // ---- main loop: Cholesky of M, Y = L^-1 J^T (as T), M dq, J dq ------------------------------------------------
     double T[N];
     double mdq0 = 0.0, mdq1 = 0.0, dx = 0.0;
+    unsigned long long npd_mask = 0;      // lanes that saw a non-positive pivot of M (scalar registers: see pinned_ballot)
     const double* trow = Jq + (l < K ? l : K) * N;
     if constexpr (TREE) {
         // M = L^T L, columns N - 1 .. 0; R0[c] = L[c][l], R1[c] = L[c][16 + l] (the lane's two COLUMNS of L)
@@ -812,7 +839,7 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
             if constexpr (EEJ) fmac_bc<gj>(dx, dqs, tj);
             tree_chains<TOPO, j, j + 1, SZ - 1>(m0, m1, tj, R0, R1, T);
             double d = bc_nop<gj>(sj ? m1 : m0);
-            flags |= !(d > 0.0) ? IRLOSC_FLAG_M_NOT_PD : 0u;      // also catches NaN
+            npd_mask |= pinned_ballot(!(d > 0.0));      // also catches NaN
             d = fmax(d, 1e-300);
             const double dinv = rsq_refined(d);
             R0[j] = m0 * dinv;
@@ -846,7 +873,7 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
         if constexpr (j > 0 && j < 16) fmac3_chain<gj, 0, j>(m0, m1, tj, L0, L1, T);
         else if constexpr (j >= 16) fmac2_chain<gj, 0, j>(m1, tj, L1, T);
         double d = bc_nop<gj>(sj ? m1 : m0);
-        flags |= !(d > 0.0) ? IRLOSC_FLAG_M_NOT_PD : 0u;      // also catches NaN
+        npd_mask |= pinned_ballot(!(d > 0.0));      // also catches NaN
         d = fmax(d, 1e-300);
         const double dinv = rsq_refined(d);
         if constexpr (j < 15) L0[j] = m0 * dinv;
@@ -856,6 +883,7 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
     });
     }
 
+    flags |= ((npd_mask >> lane) & 1ull) ? IRLOSC_FLAG_M_NOT_PD : 0u;
     IRLOSC_TS(3);
     // ---- A = Y^T Y: lane c ends up with A[r][c], r = 0..K-1 -------------------------------------------------------
     double A[K];
@@ -898,7 +926,11 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
     }
     lds_sync();
     // w = u_task_all [+ ext_f] - kvn * dx  (null-space term folded in: osc_generic.hpp header)
-    const double w = Wl[q][l] - kvn * dx;
+    const double w = Wl[q][l] - load_kvn() * dx;
+    // M dq is next needed for the torques at the very end: it waits in the two LDS rows that are free from here on (every
+    // lane its own slot; all cross-lane reads of Wl / Dxl are behind the lds_sync above)
+    Dxl[q][l] = mdq0;
+    Wl[q][l] = mdq1;
 
     // ---- k x k: A = L~ D L~^T, column c (= row c) of everything in lane c -------------------------------------------
     double nA2 = 0.0;
@@ -969,6 +1001,22 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
     IRLOSC_TS(6);
     // ---- joint torques of the own rows: u = u0 + bias - kvn * Mdq - J^T t (osc.py:174,184-200) --------------------
     double jt0 = 0.0, jt1 = 0.0;
+    const int lane2 = late_lane(), l2 = lane2 & 15;
+    const int b2 = late_bc(lane2);
+    const bool live2 = b2 < p.B;
+    const int bc2 = live2 ? b2 : p.B - 1;
+    TM bias0_in, bias1_in;                 // requested here, consumed behind the J^T t products
+    if constexpr (FROMQ) {
+        const unsigned lo2 = (unsigned)(bc2 & 63) * 8u;
+        bias0_in = *reinterpret_cast<const double*>(sbase + (((unsigned)(use_g ? x.tables->btab[l2] : zb) << 9) + lo2));
+        bias1_in = *reinterpret_cast<const double*>(sbase + (((unsigned)(use_g ? x.tables->btab[16 + l2] : zb) << 9) + lo2));
+    } else {
+        bias0_in = (use_g ? p.bias + (size_t)bc2 * N + l2 : zeros)[0];
+        bias1_in = (use_g && l2 < N1 ? p.bias + (size_t)bc2 * N + 16 + l2 : zeros)[0];
+    }
+    const double kvn = load_kvn();
+    mdq0 = Dxl[lane2 >> 4][l2];
+    mdq1 = Wl[lane2 >> 4][l2];
     {
         double jr0[K], jr1[K];
 #pragma unroll
@@ -1004,12 +1052,12 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
         const unsigned long long m = __ballot((flags >> bit) & 1u);
         if ((m >> (q * 16)) & 0xffffull) flags |= 1u << bit;
     }
-    if (live) {
-        p.u[(size_t)b * N + l] = (TIN)u0;
-        if (v1) p.u[(size_t)b * N + 16 + l] = (TIN)u1;
-        if (l == 0) {
-            p.flags[b] = flags;
-            if (giveup) x.worklist[atomicAdd(x.workcount, 1)] = b;
+    if (live2) {
+        p.u[(size_t)b2 * N + l2] = (TIN)u0;
+        if (l2 < N1) p.u[(size_t)b2 * N + 16 + l2] = (TIN)u1;
+        if (l2 == 0) {
+            p.flags[b2] = flags;
+            if (giveup) x.worklist[atomicAdd(x.workcount, 1)] = b2;
         }
     }
     IRLOSC_TS(7);
