@@ -519,7 +519,8 @@ def main():
                 if tree else "")
         prof = measured_profile(kname)
         roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=prof.get("traffic_bytes_per_launch"),
+                    frac=achieved / HBM_PEAK_GBS,
+                    traffic=prof.get("traffic_bytes_per_launch") if prof.get("instances", B) == B else None,
                     kernel=kname + note, kernel_ms=ms_dom, steps_per_launch=spl, step_ms_events=ms_kernel,
                     whole_step_achieved=bytes_step / (ms_kernel * 1e-3) / 1e9,
                     algorithmic_bytes_per_launch=bytes_launch,

@@ -66,9 +66,12 @@ for sd in range(a.seeds):
     for name, kern, kdt, data in (("row16", _lib.KERNEL_AUTO if a.mode == "f32" else _lib.KERNEL_ROW16, dt, g), ("generic", 1, np.float64, g64)):
         osc = BatchedOSC(lay, B, dtype=kdt, kernel=kern)
         osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
-        res[name] = osc.generate_batched(data["M"], data["J"], data["dq"], data["bias"], data["ee_pose"], data["tgt_pose"],
-                                         data.get("tgt_vel"), data.get("wrench"), return_flags=True)
-        res[name + "_kernel"] = osc.kernel_name
+        # upload + step (not the one-call tick): uploaded records are probed for the kinematic tree's zero pattern, and physical
+        # ones then go through the tree-structured form of the row16 kernel -- the form the sweep is meant to exercise
+        osc.upload(data["M"], data["J"], data["dq"], data["bias"], data["ee_pose"], data.get("wrench"))
+        osc.set_targets(data["tgt_pose"], data.get("tgt_vel"))
+        res[name] = osc.step(return_flags=True)
+        res[name + "_kernel"] = osc.kernel_name + ("+tree" if osc.slot_structure(0) else "")
         osc.close()
     (u, fl), (ug, flg) = res["row16"], res["generic"]
     err = np.max(np.abs(u.astype(np.float64) - ug), axis=1) / np.maximum(np.max(np.abs(ug), axis=1), 1e-300)

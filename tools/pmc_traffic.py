@@ -25,8 +25,9 @@ def trace_avg(db, sub):
     cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
     name_c = "name" if "name" in cols else "kernel_name"
     d = [(e - s) / 1e3 for s, e in con.execute(f"select start, end from kernels where {name_c} like ?", (f"%{sub}%",))]
-    top = max(d)
-    full = [v for v in d if v >= 0.7 * top]           # full trains only (a bench run also issues a few shorter launches)
+    med = sorted(d)[len(d) // 2]
+    full = [v for v in d if v >= 0.5 * med]           # full trains only (a bench run also issues a few shorter launches; relative
+                                                      # to the median: one slow outlier must not define what "full" means)
     return sum(full) / len(full), len(full)
 
 
