@@ -51,6 +51,9 @@
 #ifndef IRLOSC_R16_PF
 #define IRLOSC_R16_PF 4
 #endif
+#ifndef IRLOSC_R16_TREE_BUDGET          // doubles per lane in flight ahead of the tree form's recursion (dense records)
+#define IRLOSC_R16_TREE_BUDGET (2 * IRLOSC_R16_PF)
+#endif
 #ifndef IRLOSC_EIG_MAXIT
 #define IRLOSC_EIG_MAXIT 12
 #endif
@@ -472,6 +475,44 @@ constexpr int tree_ee_run(int c0, int cend) {          // length of the run of c
     while (c0 + n < cend && tree_moves_ee<TOPO>(c0 + n) == tree_moves_ee<TOPO>(c0)) ++n;
     return n;
 }
+// row j of M has no structural non-zero in columns 16 .. NJ - 1 (its slot-1 half): nothing to load, nothing to multiply
+template <class TOPO>
+constexpr bool tree_slot1_zero(int j) {
+    for (int c = 16; c < TOPO::NJ; ++c)
+        if (FeTopo<TOPO>::above(j, c) || FeTopo<TOPO>::above(c, j)) return false;
+    return true;
+}
+// Prefetch plan of the tree form on dense records: rows are requested in processing order (NJ - 1 .. 0) so that at most
+// BUDGET doubles per lane are in flight -- a row with an empty slot-1 half costs one register pair instead of two, so twice
+// as many of those fit.  Entry 0 = the prologue, entry i + 1 = what step i requests once it has taken its own row;
+// first / count are POSITIONS in the processing order (position p = row NJ - 1 - p).
+template <class TOPO, int BUDGET>
+struct TreeFetch {
+    int first[TOPO::NJ + 1];
+    int count[TOPO::NJ + 1];
+};
+template <class TOPO, int BUDGET>
+constexpr TreeFetch<TOPO, BUDGET> tree_fetch() {
+    constexpr int NJ = TOPO::NJ;
+    static_assert(BUDGET >= 2, "a full row must fit");
+    TreeFetch<TOPO, BUDGET> f{};
+    int next = 0, inflight = 0;
+    for (int e = 0; e <= NJ; ++e) {
+        if (e > 0) inflight -= tree_slot1_zero<TOPO>(NJ - e) ? 1 : 2;      // step e - 1 has taken row NJ - 1 - (e - 1)
+        f.first[e] = next;
+        int n = 0;
+        while (next < NJ && inflight + (tree_slot1_zero<TOPO>(NJ - 1 - next) ? 1 : 2) <= BUDGET) {
+            inflight += tree_slot1_zero<TOPO>(NJ - 1 - next) ? 1 : 2;
+            ++next;
+            ++n;
+        }
+        f.count[e] = n;
+    }
+    return f;
+}
+template <class TOPO, int BUDGET>
+inline constexpr TreeFetch<TOPO, BUDGET> kTreeFetch = tree_fetch<TOPO, BUDGET>();
+
 // bit c of word j: M[j][c] may be non-zero (c at or above j, or j above c); bit c of *jcols: column c of J may be non-zero
 template <class TOPO>
 inline void tree_structure_masks(uint32_t mrow[32], uint32_t* jcols) {
@@ -546,6 +587,11 @@ struct Row16Train {
 // slot-1 rows are already eliminated) -- 283 broadcast-FMAs per wave instead of 745.  The entries of unrelated pairs come out
 // as exact zeros (0 - sum of products with exact zeros, scaled), so nothing has to be masked; Y = L^-T J^T rides along as
 // before and J M^-1 J^T = Y^T Y is the same identity.  Records of unknown origin (TOPO = void) keep the dense recursion.
+template <class TOPO>
+constexpr bool tree_row_slot1_zero(int j) {
+    if constexpr (std::is_void_v<TOPO>) return false;
+    else return r16::tree_slot1_zero<TOPO>(j);
+}
 template <class TOPO>
 constexpr bool tree_row_of_y(int i) {
     if constexpr (std::is_void_v<TOPO>) return true;
@@ -684,19 +730,26 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
         lds_sync();                 // the entry tables are in LDS
         static_for<0, PF>([&](auto jc) {      // TREE: the recursion runs from the last column down
             constexpr int j = TREE ? N - 1 - decltype(jc)::value : decltype(jc)::value;
-            pm0[j] = side_at(Mt[j * 32 + l]); pm1[j] = side_at(Mt[j * 32 + 16 + l]);
+            pm0[j] = side_at(Mt[j * 32 + l]);
+            if constexpr (!tree_row_slot1_zero<TOPO>(j)) pm1[j] = side_at(Mt[j * 32 + 16 + l]);
         });
         constexpr int jn = TREE ? N - 1 - PF : PF;
-        mo0 = Mt[jn * 32 + l]; mo1 = Mt[jn * 32 + 16 + l];
+        mo0 = Mt[jn * 32 + l];
+        if constexpr (!tree_row_slot1_zero<TOPO>(jn)) mo1 = Mt[jn * 32 + 16 + l];
 #pragma unroll
         for (int r = 0; r < K; ++r) { jl0[r] = side_at(Jt[r * 32 + l]); jl1[r] = side_at(Jt[r * 32 + 16 + l]); }
         dq0_in = x.qvel[(size_t)bc * N + l];
         dq1_in = v1 ? x.qvel[(size_t)bc * N + 16 + l] : 0.0;
     } else {
-        static_for<0, PF>([&](auto jc) {
-            constexpr int j = TREE ? N - 1 - decltype(jc)::value : decltype(jc)::value;
-            pm0[j] = m0p[j * N]; pm1[j] = m1p[j * N];
-        });
+        if constexpr (TREE) {
+            static_for<0, kTreeFetch<TOPO, IRLOSC_R16_TREE_BUDGET>.count[0]>([&](auto pc) {
+                constexpr int j = N - 1 - decltype(pc)::value;
+                pm0[j] = m0p[j * N];
+                if constexpr (!tree_slot1_zero<TOPO>(j)) pm1[j] = m1p[j * N];
+            });
+        } else {
+            static_for<0, PF>([&](auto jc) { constexpr int j = decltype(jc)::value; pm0[j] = m0p[j * N]; pm1[j] = m1p[j * N]; });
+        }
         const TIN* __restrict__ Jb = p.J + (size_t)bc * (K * N);
         const TIN* __restrict__ Jb1 = v1 ? Jb + 16 + l : zeros;
 #pragma unroll
@@ -821,21 +874,33 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
             constexpr int SZ = tree_subtree_size<TOPO>(j);          // hinges j .. j + SZ - 1 are the subtree of j
             static_assert(tree_subtree_contiguous<TOPO>(j), "depth-first numbering: a subtree is a run of indices");
             constexpr bool EEJ = tree_moves_ee<TOPO>(j);            // otherwise column j of J and row j of Y are zero
-            if constexpr (j - PF >= 0) {
-                if constexpr (FROMQ) {
-                    pm0[j - PF] = side_at(mo0); pm1[j - PF] = side_at(mo1);
-                    if constexpr (j - PF - 1 >= 0) { mo0 = Mt[(j - PF - 1) * 32 + l]; mo1 = Mt[(j - PF - 1) * 32 + 16 + l]; }
-                } else {
-                    pm0[j - PF] = m0p[(j - PF) * N]; pm1[j - PF] = m1p[(j - PF) * N];
+            constexpr bool S1Z = tree_slot1_zero<TOPO>(j);          // no slot-1 half: m1 = 0, nothing loaded for it
+            if constexpr (FROMQ) {
+                if constexpr (j - PF >= 0) {
+                    pm0[j - PF] = side_at(mo0);
+                    if constexpr (!tree_slot1_zero<TOPO>(j - PF)) pm1[j - PF] = side_at(mo1);
+                    if constexpr (j - PF - 1 >= 0) {
+                        mo0 = Mt[(j - PF - 1) * 32 + l];
+                        if constexpr (!tree_slot1_zero<TOPO>(j - PF - 1)) mo1 = Mt[(j - PF - 1) * 32 + 16 + l];
+                    }
                 }
             }
-            double m0 = (double)pm0[j], m1 = (double)pm1[j];
+            double m0 = (double)pm0[j], m1 = 0.0;
+            if constexpr (!S1Z) m1 = (double)pm1[j];
+            if constexpr (!FROMQ) {      // dense records: the rows the prefetch plan releases now that row j's registers are free
+                constexpr int e = N - j;                            // step N - 1 - j, entry e = step + 1
+                static_for<0, kTreeFetch<TOPO, IRLOSC_R16_TREE_BUDGET>.count[e]>([&](auto pc) {
+                    constexpr int jn = N - 1 - (kTreeFetch<TOPO, IRLOSC_R16_TREE_BUDGET>.first[e] + decltype(pc)::value);
+                    pm0[jn] = m0p[jn * N];
+                    if constexpr (!tree_slot1_zero<TOPO>(jn)) pm1[jn] = m1p[jn * N];
+                });
+            }
             double tj = EEJ ? tnext : 0.0;
             if constexpr (j > 0) { if constexpr (tree_moves_ee<TOPO>(j - 1)) tnext = trow[j - 1]; }
             const double dqs = sj ? dq1 : dq0;
             __builtin_amdgcn_sched_barrier(0);
             fmac_bc_nop<gj>(mdq0, dqs, m0);
-            fmac_bc<gj>(mdq1, dqs, m1);
+            if constexpr (!S1Z) fmac_bc<gj>(mdq1, dqs, m1);
             if constexpr (EEJ) fmac_bc<gj>(dx, dqs, tj);
             tree_chains<TOPO, j, j + 1, SZ - 1>(m0, m1, tj, R0, R1, T);
             double d = bc_nop<gj>(sj ? m1 : m0);
