@@ -113,13 +113,11 @@ __global__ __launch_bounds__(64) void osc_structure_kernel(const T* __restrict__
         const T* Mb = M + (size_t)b * n * n;
         const T* Jb = J + (size_t)b * k * n;
         bool bad = false;
-        for (int e = lane; e < n * n; e += 64) {
-            const int i = e / n, j = e - i * n;
-            bad = bad || (!((m.mrow[i] >> j) & 1u) && !(Mb[e] == (T)0));       // NaN counts as non-zero
-        }
-        for (int e = lane; e < k * n; e += 64) {
-            const int j = e % n;
-            bad = bad || (!((m.jcols >> j) & 1u) && !(Jb[e] == (T)0));
+        const int c = lane & 31, half = lane >> 5;                 // two rows per pass, lane = column (n <= 32; no division)
+        if (c < n) {
+            for (int i = half; i < n; i += 2) bad = bad || (!((m.mrow[i] >> c) & 1u) && !(Mb[i * n + c] == (T)0));   // NaN counts as non-zero
+            if (!((m.jcols >> c) & 1u))
+                for (int r = half; r < k; r += 2) bad = bad || !(Jb[r * n + c] == (T)0);
         }
         if (__any(bad) && lane == 0) atomicAdd(&out[0], 1);
     }
