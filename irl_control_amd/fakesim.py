@@ -135,6 +135,9 @@ class FakeData:
     def set_mocap_pos(self, name, pos):
         self.body_xpos[self._bid(name)] = pos
 
+    def set_mocap_quat(self, name, quat):
+        self.body_xquat[self._bid(name)] = quat
+
     def get_joint_qpos(self, name):
         """qpos of a joint: one value for a hinge, pos + quat (7) for a free joint (mujoco_py's MjSimState helper)."""
         m = self._model
@@ -147,9 +150,11 @@ class FakeSim:
     derived arrays from qpos/qvel; without it the arrays are whatever the caller wrote."""
 
     def __init__(self, model: Optional[FakeModel] = None, n_free_bodies: int = 0,
-                 dynamics: Optional[Callable[["FakeSim"], None]] = None, free_joint_names=None):
+                 dynamics: Optional[Callable[["FakeSim"], None]] = None, free_joint_names=None, mocap_names=()):
         if model is None:
             names, parent, joints = dual_ur5_tree()
+            for mn in mocap_names:          # extra mocap bodies of a scene (space_mouse_scene.xml:6-14: plate, hand_ur5right, ...)
+                names.append(mn); parent.append(0); joints.append([])
             if free_joint_names is not None:
                 n_free_bodies = len(free_joint_names)
             model = FakeModel(names, parent, joints, dual_ur5_actuated_joints(), n_free_bodies, free_joint_names)

@@ -8,7 +8,7 @@ listed in fakesim.py; this adapter provides exactly that set on top of ``mujoco.
   model: body_name2id, body_parentid, body_jntadr, body_jntnum, joint_id2name, joint_name2id, jnt_qposadr,
          actuator_trnid, nv, nu
   data : qpos, qvel, qacc, qM, qfrc_bias, sensordata, ctrl, xfrc_applied, get_body_xpos / xquat / xvelp / jacp / jacr,
-         get_site_xmat, set_mocap_pos, get_joint_qpos / get_joint_qvel / set_joint_qpos / set_joint_qvel
+         get_site_xmat, set_mocap_pos / set_mocap_quat, get_joint_qpos / get_joint_qvel / set_joint_qpos / set_joint_qvel
   sim  : model, data, forward(), step(), fullM(), inverse()
 
 ``import mujoco`` happens only when an adapter is created, so the package works without MuJoCo (FakeSim, or the GPU
@@ -79,6 +79,9 @@ class _Data:
 
     def set_mocap_pos(self, name, pos):
         self._d.mocap_pos[self._m.body_mocapid[self._model.body_name2id(name)]] = pos
+
+    def set_mocap_quat(self, name, quat):
+        self._d.mocap_quat[self._m.body_mocapid[self._model.body_name2id(name)]] = quat
 
     # mujoco_py's per-joint accessors (examples/insertion_task.py:227,251 read the pose of an action object's free joint):
     # width by joint type -- mjJNT_FREE 7 qpos / 6 dofs, mjJNT_BALL 4 / 3, slide and hinge 1 / 1 (returned as a scalar).

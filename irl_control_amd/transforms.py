@@ -4,7 +4,7 @@ The reference takes these from the third-party ``transforms3d`` package
 (call sites: /root/reference/irl_control/osc.py:4-7,115-117 and
 /root/reference/irl_control/utils.py:3,14-15,30,33,53,57,67).  That package is neither vendored by
 the reference nor installed in this image, so these are restatements of its published formulas for
-the one convention the reference uses (axes='sxyz').  They are cross-checked against
+the conventions the reference uses (axes='sxyz' on the OSC path; 'rxyz' in the space-mouse caller).  They are cross-checked against
 ``scipy.spatial.transform.Rotation`` in tests/test_transforms.py.  PARITY UNPINNED with respect to
 transforms3d itself (SURVEY.md §8 a6').
 """
@@ -68,8 +68,35 @@ def quat2euler(q):
     return mat2euler(quat2mat(q))
 
 
-def euler2quat(ai, aj, ak):
-    """'sxyz' Euler angles -> (w,x,y,z)."""
+_AXIS = {"x": 0, "y": 1, "z": 2}
+
+
+def _axes_sequence(axes):
+    """'sxyz' / 'rzyx' / ... -> the three (axis index, angle slot) rotations in the order they are applied about FIXED axes.
+    transforms3d's naming (call sites: examples/space_mouse_example.py:59,121): first letter s = static frame (rotate about
+    fixed x, then fixed y, then fixed z for 'sxyz'), r = rotating frame (about x, then the NEW y, then the NEW z for
+    'rxyz'), which is the same rotation as the static sequence taken in the opposite order."""
+    if len(axes) != 4 or axes[0] not in "sr" or any(c not in _AXIS for c in axes[1:]) or axes[1] == axes[2] or axes[2] == axes[3]:
+        raise ValueError(f"axes={axes!r}")
+    seq = [(_AXIS[c], slot) for slot, c in enumerate(axes[1:])]
+    return seq if axes[0] == "s" else seq[::-1]
+
+
+def _axis_quat(axis, angle):
+    q = np.zeros(4)
+    q[0] = math.cos(angle / 2.0)
+    q[1 + axis] = math.sin(angle / 2.0)
+    return q
+
+
+def euler2quat(ai, aj, ak, axes="sxyz"):
+    """Euler angles -> (w,x,y,z); 'sxyz' (every call on the OSC path) by the closed form, the other conventions of
+    transforms3d.euler by composing the three elementary rotations."""
+    if axes != "sxyz":
+        q = np.array([1.0, 0.0, 0.0, 0.0])
+        for axis, slot in _axes_sequence(axes):
+            q = np.array(qmult(_axis_quat(axis, (ai, aj, ak)[slot]), q))      # later rotations about fixed axes multiply from the left
+        return q
     ai, aj, ak = ai / 2.0, aj / 2.0, ak / 2.0
     ci, si = math.cos(ai), math.sin(ai)
     cj, sj = math.cos(aj), math.sin(aj)
@@ -78,8 +105,10 @@ def euler2quat(ai, aj, ak):
     return np.array([cj * cc + sj * ss, cj * sc - sj * cs, cj * ss + sj * cc, cj * cs - sj * sc])
 
 
-def euler2mat(ai, aj, ak):
-    """'sxyz' Euler angles -> rotation matrix (transforms3d.euler.euler2mat): Rz(ak) Ry(aj) Rx(ai)."""
+def euler2mat(ai, aj, ak, axes="sxyz"):
+    """Euler angles -> rotation matrix (transforms3d.euler.euler2mat); 'sxyz': Rz(ak) Ry(aj) Rx(ai)."""
+    if axes != "sxyz":
+        return quat2mat(euler2quat(ai, aj, ak, axes))
     si, sj, sk = math.sin(ai), math.sin(aj), math.sin(ak)
     ci, cj, ck = math.cos(ai), math.cos(aj), math.cos(ak)
     cc, cs, sc, ss = ci * ck, ci * sk, si * ck, si * sk

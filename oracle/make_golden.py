@@ -422,6 +422,165 @@ def make_insertion_golden(name, seed, active_arm="right", objects="nist_action_o
     print(f"{name:28s} {len(seq)} actions ({meta['n_wp']} WP), {len(rec['ctrl'])} ticks -> {os.path.getsize(path) // 1024} KiB")
 
 
+G_TELEOP = [("base", "osc2"), ("ur5right", "osc2"), ("ur5left", "osc2")]      # both teleoperation demos: osc2 everywhere
+
+
+class _StopLoop(Exception):
+    pass
+
+
+def _load_reference_example(fname, stubs):
+    """Import one of the reference's example scripts with stand-ins for the hardware modules it pulls in."""
+    import importlib.util
+    import types
+    for name, attrs in stubs.items():
+        m = types.ModuleType(name)
+        for k2, v in attrs.items():
+            setattr(m, k2, v)
+        sys.modules[name] = m
+    spec = importlib.util.spec_from_file_location("ref_" + fname[:-3], "/root/reference/irl_control/examples/" + fname)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def make_teleop_golden(name, kind, seed, ticks, rate=0.08, button_every=4):
+    """Per-tick goldens of the two teleoperation callers (SURVEY.md section 8b lists both among the consumers of
+    OSC.generate): the REFERENCE's own loop bodies -- SpaceMouseDemo.run_demo (examples/space_mouse_example.py:106-165) with
+    the reference's own SpaceMouse integrator on a scripted `pyspacemouse`, PSMoveExample.run and its button poll
+    (examples/ps_move_example.py:60-180) on scripted MoveState records -- on a FakeSim with ToyDynamics whose goals follow
+    the mocap bodies the loops move.  The objects are created without their constructors (MuJoCo, a viewer, the
+    controllers' drivers); the viewer's render() is the tick hook.  space_mouse: the wall-clock `sleep_for` thread is a tick
+    budget, as for the GRIP actions.  ps_move: `run` never returns -- the hook ends it after `ticks`; its 10 Hz button
+    thread runs its own loop body, one pass every `button_every` ticks, handed over through two semaphores where it sleeps."""
+    import threading as real_threading
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import teleop_loops as tl
+    from mujoco_py.mjviewer import MjViewer
+    rng = np.random.default_rng(seed)
+    cfg = load_cfg("default_xyz_abg.yaml")
+    dyn = fakesim.ToyDynamics(rate=rate)
+    mocaps = tl.SPACE_MOUSE_MOCAPS if kind == "space_mouse" else tl.PS_MOVE_MOCAPS
+    sim = fakesim.randomize(fakesim.FakeSim(dynamics=dyn, mocap_names=mocaps), rng)
+    robot, osc = build_reference(cfg, sim, G_TELEOP, True, True, False)
+    ee = {"ur5right": "ur_EE_ur5right", "ur5left": "ur_EE_ur5left"}
+    hands = dict(zip(("ur5right", "ur5left"), mocaps[-2:]))
+    rec = dict(ctrl=[])
+    if kind == "space_mouse":
+        dyn.goal_provider = lambda: ({ee[n]: sim.data.get_body_xpos(h).copy() for n, h in hands.items()},
+                                     {ee[n]: sim.data.get_body_xquat(h).copy() for n, h in hands.items()})
+        mod = _load_reference_example("space_mouse_example.py",
+                                      {"pyspacemouse": dict(open=lambda: True, read=tl.space_mouse_stream(seed, ticks))})
+        demo = mod.SpaceMouseDemo.__new__(mod.SpaceMouseDemo)
+        demo.sim, demo.model, demo.robot, demo.controller = sim, sim.model, robot, osc
+        demo.viewer = MjViewer(sim)
+        demo.timer_running = False
+        budget = dict(left=0)
+
+        class TickBudgetThread:
+            def __init__(self, target=None, args=()):
+                pass
+
+            def start(self):
+                budget["left"] = ticks
+                demo.timer_running = True
+
+            def join(self):
+                pass
+        mod.threading = type("threading_stub", (), {"Thread": TickBudgetThread})
+
+        def on_render():
+            rec["ctrl"].append(np.array(sim.data.ctrl))
+            budget["left"] -= 1
+            if budget["left"] <= 0:
+                demo.timer_running = False
+        demo.viewer.on_render = on_render
+        demo.run_demo(demo_duration=ticks)
+    else:
+        dyn.goal_provider = lambda: ({ee[n]: sim.data.get_body_xpos(h).copy() for n, h in hands.items()}, {})
+        mod = _load_reference_example("ps_move_example.py", {"psmove": dict(count_connected=lambda: 0)})
+        RefMoveName = mod.MoveName
+        from irl_control.input_devices.ps_move import MoveState as RefMoveState
+        script = tl.ps_move_script(seed, ticks + 1)
+        by_ref = {RefMoveName.RIGHT: tl.MoveName.RIGHT, RefMoveName.LEFT: tl.MoveName.LEFT}
+        demo = mod.PSMoveExample.__new__(mod.PSMoveExample)
+        demo.sim, demo.model, demo.robot, demo.controller = sim, sim.model, robot, osc
+        demo.viewer = MjViewer(sim)
+        demo.move_states = {n: RefMoveState() for n in RefMoveName}
+        demo.grip_pos = dict([(n, 0.0) for n in RefMoveName])
+
+        def apply_row(t):
+            for rn, n in by_ref.items():
+                for k2, v in script[t][n].items():
+                    demo.move_states[rn].set(k2, v)
+        apply_row(0)
+        go, done, state = real_threading.Semaphore(0), real_threading.Semaphore(0), dict(stop=False, tick=0)
+
+        class ButtonThread:                                  # stands in for threading.Thread(target=self.update_move_button_states)
+            def __init__(self, target=None, args=()):
+                def body():
+                    go.acquire()                             # no pass before the loop asks for one
+                    if not state["stop"]:
+                        target(*args)
+                self._t = real_threading.Thread(target=body, daemon=True)
+
+            def start(self):
+                self._t.start()
+
+        def sleep_stub(_seconds):                            # the poll's time.sleep: one pass is over, wait to be asked again
+            done.release()
+            go.acquire()
+            if state["stop"]:
+                raise SystemExit
+        mod.threading = type("threading_stub", (), {"Thread": ButtonThread})
+        mod.time = type("time_stub", (), {"sleep": staticmethod(sleep_stub)})
+
+        def on_render():
+            rec["ctrl"].append(np.array(sim.data.ctrl))
+            t = state["tick"]
+            if (t + 1) % button_every == 0:
+                go.release()
+                done.acquire()
+            state["tick"] = t + 1
+            if t + 1 >= ticks:
+                raise _StopLoop
+            apply_row(t + 1)
+        demo.viewer.on_render = on_render
+        try:
+            demo.run()
+        except _StopLoop:
+            pass
+        state["stop"] = True
+        go.release()
+    # cross-check of the headless counterpart's LOGIC: examples/teleop_loops.py driven with the reference's classes on the same
+    # set-up must reproduce the reference's own loop bit for bit (the GPU tests then swap in the HIP path)
+    dyn2 = fakesim.ToyDynamics(rate=rate)
+    sim2 = fakesim.randomize(fakesim.FakeSim(dynamics=dyn2, mocap_names=mocaps), np.random.default_rng(seed))
+    robot2, osc2 = build_reference(load_cfg("default_xyz_abg.yaml"), sim2, G_TELEOP, True, True, False)
+    if kind == "space_mouse":
+        dyn2.goal_provider = lambda: ({ee[n]: sim2.data.get_body_xpos(h).copy() for n, h in hands.items()},
+                                      {ee[n]: sim2.data.get_body_xquat(h).copy() for n, h in hands.items()})
+        from irl_control_amd.input_devices import SpaceMouse
+        mine = tl.space_mouse_loop(robot2, osc2, RefTarget, sim2, SpaceMouse([0.0, 0.5, 0.5, 0.0, 0.0, 0.0],
+                                                                             reader=tl.space_mouse_stream(seed, ticks)), ticks)
+    else:
+        dyn2.goal_provider = lambda: ({ee[n]: sim2.data.get_body_xpos(h).copy() for n, h in hands.items()}, {})
+        from irl_control_amd.input_devices import MoveState
+        ms = {n: MoveState() for n in tl.MoveName}
+        script2 = tl.ps_move_script(seed, ticks + 1)
+        tl.apply_script_row(ms, script2[0])
+        mine = tl.ps_move_loop(robot2, osc2, RefTarget, RefDeviceState, sim2, ms, ticks,
+                               advance=lambda t: tl.apply_script_row(ms, script2[t + 1]), button_every=button_every)
+    _d = np.abs(mine["ctrl"] - np.asarray(rec["ctrl"]))
+    print("   self-check:", _d.max(), "first tick differing:", int(np.argmax(_d.max(axis=1) > 0)), "cols", np.nonzero(_d.max(axis=0) > 0)[0])
+    assert np.array_equal(mine["ctrl"], np.asarray(rec["ctrl"])), "examples/teleop_loops.py does not reproduce the reference's loop"
+    meta = dict(kind=kind, seed=seed, ticks=ticks, rate=rate, button_every=button_every, mocaps=list(mocaps))
+    arrays = dict(ctrl=np.asarray(rec["ctrl"]), layout_json=np.array(json.dumps(meta)))
+    path = os.path.join(OUT_DIR, f"{name}.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name:28s} {len(rec['ctrl'])} ticks of the reference's {kind} loop -> {os.path.getsize(path) // 1024} KiB")
+
+
 RLB = ("ur5right", "ur5left", "base")
 BRL = ("base", "ur5right", "ur5left")
 G_GAIN = [("base", "osc0"), ("ur5right", "osc2"), ("ur5left", "osc2")]
@@ -438,6 +597,7 @@ if __name__ == "__main__":
             return lambda name, *a, **k: fn(name, *a, **k) if name in _only else None
         make_case, make_e2e_case, make_loop_case = _filtered(make_case), _filtered(make_e2e_case), _filtered(make_loop_case)
         make_insertion_golden, make_mutation_case = _filtered(make_insertion_golden), _filtered(make_mutation_case)
+        make_teleop_golden = _filtered(make_teleop_golden)
     # gain_test layout (examples/gain_test.py:27-36,124-128): arms xyz only, k = 7
     make_case("k7_gain_test", S + 1, 32, "default_xyz.yaml", RLB, G_GAIN, all_actuated=True)
     make_case("k7_real_actuators", S + 2, 8, "default_xyz.yaml", RLB, G_GAIN)
@@ -473,3 +633,7 @@ if __name__ == "__main__":
     # insertion_task.py:294), and the GRIP actions of the insertion sequence on a stated tick budget
     make_mutation_case("e2e_live_mutations", S + 23, 6, "default_xyz_abg.yaml", RLB, G_GAIN)
     make_insertion_golden("loop_insertion_full", 0, with_grip=True, tick_seconds=0.04)
+    # the two teleoperation callers of OSC.generate (examples/space_mouse_example.py, examples/ps_move_example.py): the
+    # reference's own loop bodies on scripted input streams
+    make_teleop_golden("loop_space_mouse", "space_mouse", 5, 200)
+    make_teleop_golden("loop_ps_move", "ps_move", 6, 200)

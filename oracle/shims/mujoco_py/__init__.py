@@ -18,3 +18,8 @@ def load_model_from_path(path):
 class MjSim:
     def __init__(self, *a, **k):
         raise RuntimeError("mujoco_py stub: no MuJoCo here; inject a FakeSim instead")
+
+
+class GlfwContext:                       # examples/space_mouse_example.py:1 imports it (never constructed on the headless path)
+    def __init__(self, *a, **k):
+        raise RuntimeError("mujoco_py stub: no OpenGL context here")

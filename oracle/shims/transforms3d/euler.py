@@ -8,13 +8,11 @@ def _only_sxyz(axes):
 
 
 def euler2quat(ai, aj, ak, axes="sxyz"):
-    _only_sxyz(axes)
-    return _t.euler2quat(ai, aj, ak)
+    return _t.euler2quat(ai, aj, ak, axes)
 
 
 def euler2mat(ai, aj, ak, axes="sxyz"):
-    _only_sxyz(axes)
-    return _t.euler2mat(ai, aj, ak)
+    return _t.euler2mat(ai, aj, ak, axes)
 
 
 def quat2euler(q, axes="sxyz"):

@@ -884,6 +884,27 @@ def test_admit_test_loop_matches_reference_tick_by_tick():
     assert jump_in > 2 * jump_before
 
 
+@pytest.mark.parametrize("demo", ["space_mouse", "ps_move"])
+def test_teleoperation_loops_match_the_reference_tick_by_tick(demo):
+    """The two teleoperation callers of OSC.generate (examples/space_mouse_example.py:141-143,
+    examples/ps_move_example.py:154-159), headless on scripted input streams: the goldens are what the REFERENCE's own loop
+    bodies (SpaceMouseDemo.run_demo with the reference's SpaceMouse integrator; PSMoveExample.run with its button poll) wrote
+    into sim.data.ctrl tick by tick; here the same streams go through examples/teleop_loops.py and OSC.generate on the HIP
+    path.  ps_move: the triggers switch `ctrlr_dof_abg` of live devices (orientation error off, rows kept), released arms
+    hold their own position, the gripper position actuators (ctrl 7 / 14) follow circle / triangle."""
+    g, meta = _load_loop_golden("loop_" + demo)
+    mod = _load_example("teleop_headless")
+    rec = mod.run(demo=demo, ticks=meta["ticks"], seed=meta["seed"], rate=meta["rate"], button_every=meta["button_every"], verbose=False)
+    assert rec["ctrl"].shape == g["ctrl"].shape
+    err = np.abs(rec["ctrl"] - g["ctrl"]).max(axis=1) / np.abs(g["ctrl"]).max(axis=1)
+    assert err.max() <= TOL64, (int(np.argmax(err)), float(err.max()))
+    if demo == "ps_move":
+        eng = rec["engaged"]
+        assert (np.diff(eng.astype(int), axis=0) != 0).sum() >= 4              # both arms engaged and released several times
+        assert np.array_equal(rec["ctrl"][:, [7, 14]], g["ctrl"][:, [7, 14]])  # gripper set-points: caller-side logic, exact
+        assert g["ctrl"][:, 7].max() >= 0.3
+
+
 # ------------------------------------------------------------------------------------------------
 # Rigid-body front end (SURVEY.md section 8 row f1): records from (qpos, qvel) on the GPU
 # ------------------------------------------------------------------------------------------------

@@ -50,3 +50,21 @@ def test_qmult_is_hamilton_product():
     ours = np.array(tf.qmult(a, b)) / (np.linalg.norm(a) * np.linalg.norm(b))
     ref = r.as_quat(scalar_first=True)
     assert min(np.abs(ours - ref).max(), np.abs(ours + ref).max()) < 1e-14
+
+
+def test_euler_axes_conventions_vs_scipy():
+    """euler2quat / euler2mat for the other conventions of transforms3d.euler ('rxyz' is what examples/space_mouse_example.py:59,121
+    asks for): static = extrinsic (SciPy lower case), rotating = intrinsic (SciPy upper case)."""
+    from scipy.spatial.transform import Rotation
+    from irl_control_amd import transforms as t
+    rng = np.random.default_rng(11)
+    for axes in ("sxyz", "rxyz", "szyx", "rzyx", "szxz", "rxzx", "syxz", "ryzx"):
+        for _ in range(50):
+            a = rng.uniform(-3, 3, 3)
+            R = Rotation.from_euler(axes[1:] if axes[0] == "s" else axes[1:].upper(), a).as_matrix()
+            assert np.abs(t.quat2mat(t.euler2quat(*a, axes=axes)) - R).max() < 1e-14
+            assert np.abs(t.euler2mat(*a, axes=axes) - R).max() < 1e-14
+    assert np.array_equal(t.euler2quat(0.3, -0.2, 0.1), t.euler2quat(0.3, -0.2, 0.1, axes="sxyz"))
+    import pytest
+    with pytest.raises(ValueError):
+        t.euler2quat(0, 0, 0, axes="sxxz")
