@@ -551,22 +551,37 @@ def main():
             import shutil
             import tempfile
             base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
-            d = tempfile.mkdtemp(prefix="irlosc_mint_", dir=base)
-            try:
-                cmd = [sys.executable, os.path.abspath(__file__), "--mint-physical", d, "--batch", str(B), "--layout", args.layout,
-                       "--dtype", args.dtype, "--slots", "1"]
-                env = dict(os.environ)
-                env["IRLOSC_BENCH_DEVICE"] = str(local_rank)
-                subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL)
-                arr0 = {f[:-4]: np.load(os.path.join(d, f)) for f in sorted(os.listdir(d)) if f.endswith(".npy")}
-            finally:
-                shutil.rmtree(d, ignore_errors=True)
+            arr0, mint_error = None, None
+            for where in (base, None):                   # /dev/shm first (0.5 GB of records), then the default temporary directory
+                d = tempfile.mkdtemp(prefix="irlosc_mint_", dir=where)
+                try:
+                    if os.environ.get("IRLOSC_BENCH_FAIL_MINT"):          # test hook: the hand-over fails, the line must still come out
+                        raise OSError("IRLOSC_BENCH_FAIL_MINT is set")
+                    cmd = [sys.executable, os.path.abspath(__file__), "--mint-physical", d, "--batch", str(B), "--layout", args.layout,
+                           "--dtype", args.dtype, "--slots", "1"]
+                    env = dict(os.environ)
+                    env["IRLOSC_BENCH_DEVICE"] = str(local_rank)
+                    subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL)
+                    arr0 = {f[:-4]: np.load(os.path.join(d, f)) for f in sorted(os.listdir(d)) if f.endswith(".npy")}
+                    break
+                except (OSError, subprocess.CalledProcessError) as e:      # the baseline must never break the bench line
+                    mint_error = str(e)
+                finally:
+                    shutil.rmtree(d, ignore_errors=True)
+                if where is None:
+                    break
             lay0 = synth.make_layout(args.layout)
             _, gains0, _ = synth.make_batch(args.layout, 2, seed=1, dtype=MODES[args.dtype][0])
-            minted_crc = sharding.checksum_u64(arr0["M"])
+            if arr0 is not None:
+                minted_crc = sharding.checksum_u64(arr0["M"])
         else:
             lay0, gains0, arr0 = make_slot(args.dtype, 0)
-        cb, ref, ref_idx = cpu_baseline(lay0, gains0, arr0)
+        if arr0 is None:         # no physical slot for the CPU legs: time the oracle on the synthetic batch (same arithmetic per step)
+            lay0, gains0, arr0 = make_slot(args.dtype, 0)
+            cb, _, _ = cpu_baseline(lay0, gains0, arr0)
+            cb["sample"] += f"; SYNTHETIC records (slot 0 of the physical workload could not be handed to the CPU legs: {mint_error})"
+        else:
+            cb, ref, ref_idx = cpu_baseline(lay0, gains0, arr0)
         if not args.no_from_q and args.layout in ("k13", "k7"):
             from irl_control_amd.rigid_body import RigidBodyModel
             model = RigidBodyModel.load("dual_ur5")
@@ -610,6 +625,11 @@ def main():
                         "truncated_frac": float(((fl & 8) != 0).mean()), "nonfinite_frac": float(((fl & 64) != 0).mean())}
         if cb is not None:
             out["cpu_baseline"] = cb
+            if ref is None:      # (fallback above) the oracle in this process on the first instances of the GPU's own slot 0
+                n = min(NSEC, B)
+                ref = np.full((u.shape[0], u.shape[1]), np.nan)
+                ref[:n] = oracle_reference(lay_, gains, arr, 0, n)
+                ref_idx = range(n)
             out["parity_sample"] = parity_sample(arr, u, ref, ref_idx)
     runs = [(m, args.workload) for m in others]
     if others and args.workload == "physical":
