@@ -158,10 +158,10 @@ __device__ __forceinline__ void ldl16(double (&A)[K], const int l, const double 
     static_for<0, K>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         double d = bc_nop<j>(A[j]) + sigma;
-        const bool npd = !(d > 0.0);
+        const bool npd = !(d > 0.0);                   // also catches NaN
         pd = pd && !npd;
-        const double dfix = (d == d && d != 0.0) ? fabs(d) : 1.0;
-        d = npd ? dfix : d;
+        d = npd ? 1.0 : d;      // the verdict is in: what a non-positive pivot leaves behind is never used (the caller refactors
+                                // with a shift or only asked for `pd`); 1 keeps the rest of the recursion finite
         det *= d;
         const double invd = rcp_refined(d);
         const double f = A[j] * invd;
