@@ -20,11 +20,17 @@
 //           t = A^-1 w by W and one back substitution, all on bcast-FMAs                          (osc.py:51-55)
 //   u_i  = u0_i + bias_i - kvn * mdq_i - sum_r bcast(t_r) * J[r][i]                               (osc.py:174-200)
 //
-// J is read once, coalesced, and parked in LDS (10 KB per wave): column j of it in the right-hand-side layout is one
+// Tree form (TOPO = a compiled tree shape; records verified to carry its zeros, or written by the fused walk): M = L^T L with the
+// columns taken from the leaves up -- the recursion for hinge j then only involves the hinges of j's own subtree, there is no
+// fill-in, and the rows of Y under no end effector are identically zero: 258 column terms instead of 795, 169 products for A
+// instead of 325.  Everything else is the same code.
+//
+// J is read once, coalesced, and parked in LDS (11 KB per wave): column j of it in the right-hand-side layout is one
 // conflict-free ds_read per iteration, and the rows come back in the joint layout for J^T t.  Nothing else uses LDS
-// beyond a 1 KB exchange area, there is no inter-wave communication and no ring: occupancy is bounded by registers.
-// Instances whose k x k solve is not certifiably the reference's inverse branch are appended to a worklist and
-// recomputed by the generic kernel (cyclic Jacobi), exactly like the tail of the fp32 group path.
+// beyond a 1 KB exchange area, there is no inter-wave communication and no ring: occupancy is bounded by registers --
+// three waves per SIMD (<= 168 registers, no scratch; see IRLOSC_R16_WAVES below).
+// Instances whose k x k solve is not certifiably the reference's inverse branch go through the in-wave eigen stage
+// (eigen16); the few it gives up on are appended to a worklist and recomputed by the generic kernel (cyclic Jacobi).
 //
 // Hazard discipline: the hardware does NOT interlock "VALU writes a VGPR -> DPP reads it" (2 wait states; measured:
 // tools/probe/dpp64.hip) and the compiler cannot see into inline asm, so (1) every DPP instruction is volatile asm
