@@ -2,7 +2,9 @@
 # usage (on the GPU box, from the repo root): bash tools/gpu_profile.sh <tag> <kernel-substring> <hbm_traffic.json key> [bench flags]
 # kernel trace + stats, then the two PMC passes for HBM traffic (separate runs, counters only: MI355X_MICROARCH.md, HBM).
 # Everything lands under gpurun_out/ ; copy the summaries to keep into profiles/.
-tag=${1:-rXX}; kern=${2:-osc_row16}; key=${3:-osc_row16_f64_n25_k13}
+tag=${1:-rXX}; kern=${2:-25, false, irlosc::TopoDualUr5}; key=${3:-osc_row16_f64_n25_k13+tree}
+# (defaults: the tree form of the fp64 row16 kernel, what `python bench.py` runs; for `--workload synthetic` pass "25, false, void" and
+#  osc_row16_f64_n25_k13)
 shift; shift; shift
 export TMPDIR=/tmp
 B="python bench.py --steps 64 --warmup 8 --preroll 96 --no-cpu-baseline --no-secondary --no-from-q $*"
