@@ -60,12 +60,6 @@
 #ifndef IRLOSC_R16_TREE_BUDGET          // doubles per lane in flight ahead of the tree form's recursion (dense records)
 #define IRLOSC_R16_TREE_BUDGET (2 * IRLOSC_R16_PF)
 #endif
-#ifndef IRLOSC_EIG_MAXIT
-#define IRLOSC_EIG_MAXIT 12
-#endif
-#ifndef IRLOSC_EIG_EXTRA
-#define IRLOSC_EIG_EXTRA 2
-#endif
 
 namespace irlosc {
 namespace r16 {
@@ -271,7 +265,7 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
         double x = lq < K ? 0.3 + 0.1 * (double)(((lq + 3 * slot) * 5) % 7) - 0.05 * (double)slot : 0.0;
         double lam = 0.0, lam_prev = -1.0;
         bool fin = !active;
-        for (int it = 0; it < IRLOSC_EIG_MAXIT; ++it) {
+        for (int it = 0; it < 12; ++it) {
             double xn = x;
 #pragma unroll
             for (int s0 = 0; s0 < NV - 1; ++s0) {
@@ -292,7 +286,7 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
         // amplified by 1 / lambda_cut: two more steps (each gains at least the factor 4 of the net, typically far more) for
         // every instance, whenever its loop froze (tools/parity_sweep.py --stress --layout k7: errors of 1.2e-5 .. 1.6e-5).
 #pragma unroll
-        for (int ex = 0; ex < IRLOSC_EIG_EXTRA; ++ex) {
+        for (int ex = 0; ex < 2; ++ex) {
             double xn = x;
 #pragma unroll
             for (int s0 = 0; s0 < NV - 1; ++s0) {
@@ -329,11 +323,7 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
     giveup = giveup || (m == NV);               // the net is full: there may be more under it (-> Jacobi)
     // Rayleigh-Ritz on the span of the candidates whenever an instance has more than one: H = V^T A V (4 x 4, the
     // unused vectors are zero), cyclic Jacobi on H with the rotations applied to V.  Rare, wave-uniform branch.
-#ifdef IRLOSC_EIG_NORR
-    if (false) {
-#else
     if (__any(m >= 2)) {
-#endif
         double av[NV], h[NV][NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) av[i] = matvec16<K>(v[i], Ac);
@@ -392,11 +382,7 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
         const bool below = has[i] && th[i] <= 1e-5 * lo;
         const bool ask = has[i] && !below && th[i] <= 1e-5 * hi;
         bool cut = below;
-#ifdef IRLOSC_EIG_NOASK
-        if (false) {
-#else
         if (__any(ask)) {
-#endif
             double A2[K], Ft[K], Gt[K], invt = 0.0, dett = 1.0;
             bool pdt = true;
 #pragma unroll
