@@ -389,6 +389,7 @@ def main():
     ap.add_argument("--layout", default="k13")
     ap.add_argument("--kernel", type=int, default=-1, help="override: 0 auto, 1 generic, 2 group, 3 row16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="length of each of the two CPU timing windows (one core, all cores)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other arithmetic / storage variants")
     ap.add_argument("--no-from-q", action="store_true", help="skip the joint-coordinates path (front end + step)")
     ap.add_argument("--workload", default="physical", choices=["physical", "synthetic"],
@@ -578,10 +579,10 @@ def main():
             lay0, gains0, arr0 = make_slot(args.dtype, 0)
         if arr0 is None:         # no physical slot for the CPU legs: time the oracle on the synthetic batch (same arithmetic per step)
             lay0, gains0, arr0 = make_slot(args.dtype, 0)
-            cb, _, _ = cpu_baseline(lay0, gains0, arr0)
+            cb, _, _ = cpu_baseline(lay0, gains0, arr0, args.cpu_seconds, args.cpu_seconds)
             cb["sample"] += f"; SYNTHETIC records (slot 0 of the physical workload could not be handed to the CPU legs: {mint_error})"
         else:
-            cb, ref, ref_idx = cpu_baseline(lay0, gains0, arr0)
+            cb, ref, ref_idx = cpu_baseline(lay0, gains0, arr0, args.cpu_seconds, args.cpu_seconds)
         if not args.no_from_q and args.layout in ("k13", "k7"):
             from irl_control_amd.rigid_body import RigidBodyModel
             model = RigidBodyModel.load("dual_ur5")

@@ -790,6 +790,33 @@ def test_bench_two_ranks_self_launched_and_under_a_launcher():
         assert "RCCL" in line["config"]["sharding"] or "files" in line["config"]["sharding"]
 
 
+@pytest.mark.parametrize("fail_hand_over", [False, True])
+def test_bench_line_with_the_cpu_legs_on_the_physical_workload(fail_hand_over):
+    """The default workload's records come out of the GPU, the CPU legs fork before the bench process touches HIP: a child
+    process computes slot 0 and hands it over (the parent checks the CRC against its own slot 0).  The line carries the CPU
+    baseline and a parity sample of the tree-form kernel against the oracle on those records.  With the hand-over failing
+    (IRLOSC_BENCH_FAIL_MINT) the line still comes out: CPU timing on synthetic records, said so, parity in-process."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    if fail_hand_over:
+        env["IRLOSC_BENCH_FAIL_MINT"] = "1"
+    cmd = [sys.executable, "bench.py", "--steps", "16", "--warmup", "8", "--preroll", "0", "--batch", "4096", "--cpu-seconds", "0.5",
+           "--no-secondary", "--no-from-q"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["records_from"] == "physical" and line["config"]["kernel"].endswith("+tree")
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port"
+    assert ("SYNTHETIC records" in line["cpu_baseline"]["sample"]) == fail_hand_over
+    ps = line["parity_sample"]
+    assert ps["n"] >= 512 and ps["n_over_tol_in_parity_domain"] == 0 and ps["max_rel_err"] <= TOL64
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+
+
 @pytest.mark.parametrize("lost", [1, 2, 3, 5])
 def test_row16_rank_deficient_jacobians(lost):
     """Exactly singular task Jacobians (duplicated rows: `lost` zero eigenvalues of J M^-1 J^T): the plain
