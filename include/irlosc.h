@@ -39,6 +39,9 @@
  *     IRLOSC_ERR_ARG when an instance has max |M - M^T| > 1e-6 max |M| and the context runs a throughput kernel.  Records
  *     assembled on the device (irlosc_upload_raw / irlosc_assemble_device / irlosc_frontend) are symmetric by
  *     construction; for irlosc_step_device it stays the caller's contract;
+ *   - (not a contract, an observation the library makes for itself) records of a real robot carry the zeros of its kinematic
+ *     tree -- robot.py:68-72 / device.py:115-133 hand over what mj_fullM / mj_jacBody wrote -- and uploads are probed for
+ *     them: see irlosc_slot_structure;
  *   - device pointers handed to irlosc_step_device / irlosc_assemble_device are 16-byte aligned;
  *   - a context is driven from ONE stream at a time: its train tables, worklists and pending stage-2 work are ordered
  *     by stream order only, so a caller stream passed to the *_device entry points must not run concurrently with the
