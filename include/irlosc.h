@@ -146,6 +146,10 @@ int irlosc_upload(irlosc_ctx* ctx, int32_t slot, int32_t B, const void* M, const
  * qualifies.  A train of irlosc_step_resident uses the form when every slot in it qualifies.  Results differ from the
  * dense recursion at rounding level only.  IRLOSC_TREE=0 in the environment turns the form off. */
 int irlosc_slot_structure(const irlosc_ctx* ctx, int32_t slot);
+/* The same look at records that are already in `slot` (first B instances), for the one path that cannot take it by itself:
+ * irlosc_assemble_device on a caller's stream.  Synchronous on the context's stream -- the caller synchronises its own stream
+ * first.  Returns 1 / 0 like irlosc_slot_structure (and updates that verdict), or a negative irlosc_status. */
+int irlosc_probe_structure(irlosc_ctx* ctx, int32_t slot, int32_t B);
 /* Host -> device copy of the targets for slot `slot`.  tgt_vel may be NULL (all zero). */
 int irlosc_set_targets(irlosc_ctx* ctx, int32_t slot, int32_t B, const void* tgt_pose,
                        const void* tgt_vel);

@@ -23,7 +23,7 @@ EXPORTS = ["irlosc_abi_version", "irlosc_device_count", "irlosc_create", "irlosc
            "irlosc_tick", "irlosc_comm_unique_id", "irlosc_comm_create", "irlosc_comm_destroy",
            "irlosc_comm_last_error", "irlosc_bench_allreduce", "irlosc_comm_allgather_u64", "irlosc_set_model",
            "irlosc_upload_q", "irlosc_frontend", "irlosc_step_resident_from_q", "irlosc_download_records",
-           "irlosc_step_from_q", "irlosc_from_q_name", "irlosc_slot_structure"]
+           "irlosc_step_from_q", "irlosc_from_q_name", "irlosc_slot_structure", "irlosc_probe_structure"]
 COMM_ID_BYTES = 128
 
 
@@ -104,6 +104,8 @@ def load():
     lib.irlosc_from_q_name.restype = C.c_char_p
     lib.irlosc_slot_structure.argtypes = [vp, C.c_int32]
     lib.irlosc_slot_structure.restype = C.c_int
+    lib.irlosc_probe_structure.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.irlosc_probe_structure.restype = C.c_int
     lib.irlosc_tick.argtypes = [vp, i32] + [vp] * 10
     lib.irlosc_comm_unique_id.argtypes = [vp]
     lib.irlosc_comm_create.argtypes = [i32, i32, i32, vp, C.POINTER(vp)]

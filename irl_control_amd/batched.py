@@ -199,6 +199,14 @@ class BatchedOSC:
         factors M in the tree-structured form (irlosc_slot_structure, include/irlosc.h)."""
         return bool(self.lib.irlosc_slot_structure(self._h, slot))
 
+    def probe_structure(self, slot: int = 0, B: Optional[int] = None) -> bool:
+        """Look at the records already in `slot` (irlosc_probe_structure): what assemble_device on a caller's stream cannot
+        do for itself.  -> the slot's verdict, as slot_structure() reports it from then on."""
+        rc = self.lib.irlosc_probe_structure(self._h, slot, self._B[slot] if B is None else B)
+        if rc < 0:
+            self._chk(rc)
+        return bool(rc)
+
     @property
     def from_q_name(self) -> str:
         """What step_from_q / step_resident_from_q launch: the fused pair (compact exchange buffer, no dense M / J) when the

@@ -450,6 +450,18 @@ static int structure_probe(irlosc_ctx* c, int slot, int B) {
     return IRLOSC_OK;
 }
 
+extern "C" int irlosc_probe_structure(irlosc_ctx* c, int32_t slot, int32_t B) {
+    if (!c) return IRLOSC_ERR_ARG;
+    int rc = check_slot(c, slot, B);
+    if (rc) return rc;
+    if (B > std::max(0, c->uploaded[slot]))
+        return fail(c, IRLOSC_ERR_STATE, "slot %d holds records of %d instances, probe asked for %d", slot, std::max(0, c->uploaded[slot]), B);
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    rc = structure_probe(c, slot, B);
+    if (rc) return rc;
+    return slot_tree(c, slot) ? 1 : 0;
+}
+
 extern "C" int irlosc_slot_structure(const irlosc_ctx* c, int32_t slot) {
     if (!c || slot < 0 || slot >= c->cfg.n_slots) return 0;
     return slot_tree(c, slot) ? 1 : 0;

@@ -1468,3 +1468,52 @@ def test_trains_mixing_tree_and_dense_slots_fall_back_to_the_dense_recursion():
     u_last0, _ = osc.download(B)
     osc.close()
     assert rel_err(u_last0, u0_tree.astype(np.float64)).max() <= 1e-8
+
+
+def test_raw_state_paths_qualify_for_the_tree_form():
+    """Raw simulator arrays of physical states (what mj_fullM / mj_jacBody leave) through the two assembly paths: the
+    host-staged irlosc_upload_raw probes by itself; irlosc_assemble_device on device-resident arrays cannot (caller's stream)
+    and gets its verdict from irlosc_probe_structure.  Either way the step equals the one on the plainly uploaded records."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    B = 320
+    lay, gains, g, rec, u_rec, fl_rec = _physical_records("k13", B, np.float64, seed=53)
+    nv, ns = 25, 18
+    d = _lib.RawDesc()
+    d.nv, d.n_sensor = nv, ns
+    for p_ in range(32):
+        d.joint_ids[p_] = p_ if p_ < 25 else 0
+        d.dq_src[p_] = p_ if p_ < 25 else -1
+    for i in range(4):
+        d.ft_force0[i], d.ft_torque0[i] = -1, -1
+    # records -> raw: k13 stacks ur5right (6 rows), ur5left (6 rows), base (yaw row = third rotational row)
+    jacp, jacr = np.zeros((B, 3, 3, nv)), np.zeros((B, 3, 3, nv))
+    jacp[:, 0], jacr[:, 0] = rec["J"][:, 0:3], rec["J"][:, 3:6]
+    jacp[:, 1], jacr[:, 1] = rec["J"][:, 6:9], rec["J"][:, 9:12]
+    jacr[:, 2, 2] = rec["J"][:, 12]
+    arr = dict(qM=rec["M"], qvel=rec["dq"], qfrc_bias=rec["bias"], jacp=jacp, jacr=jacr, ee_xpos=np.ascontiguousarray(rec["ee_pose"][:, :, :3]),
+               ee_xquat=np.ascontiguousarray(rec["ee_pose"][:, :, 3:]), site_xmat=np.tile(np.eye(3).reshape(9), (B, 3, 1)),
+               sensordata=np.zeros((B, ns)))
+    osc = BatchedOSC(lay, B, dtype=np.float64, kernel=_lib.KERNEL_ROW16)
+    osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+    osc.upload_raw(d, **arr)
+    osc.set_targets(g["tgt_pose"])
+    assert osc.slot_structure(0)                              # probed by the upload itself
+    u_raw, fl_raw = osc.step(return_flags=True)
+    assert np.array_equal(u_raw, u_rec) and np.array_equal(fl_raw, fl_rec)
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in arr.items()}
+    torch.cuda.synchronize()
+    pp = lambda t: C.c_void_p(t.data_ptr())
+    rc = osc.lib.irlosc_assemble_device(osc._h, 0, B, C.byref(d), pp(dev["qM"]), pp(dev["qvel"]), pp(dev["qfrc_bias"]),
+                                        pp(dev["jacp"]), pp(dev["jacr"]), pp(dev["ee_xpos"]), pp(dev["ee_xquat"]),
+                                        pp(dev["site_xmat"]), pp(dev["sensordata"]), None)
+    assert rc == 0, osc.lib.irlosc_last_error(osc._h)
+    assert not osc.slot_structure(0)                          # nobody has looked yet: dense recursion
+    u_dense = osc.step()
+    assert rel_err(u_dense, u_rec.astype(np.float64)).max() <= 1e-8
+    assert osc.probe_structure(0) and osc.slot_structure(0)
+    u_dev, fl_dev = osc.step(return_flags=True)
+    assert np.array_equal(u_dev, u_rec) and np.array_equal(fl_dev, fl_rec)
+    with pytest.raises(_lib.IrloscError):
+        osc.probe_structure(0, B + 1)
+    osc.close()
