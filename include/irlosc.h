@@ -142,9 +142,10 @@ int irlosc_upload(irlosc_ctx* ctx, int32_t slot, int32_t B, const void* M, const
  * verdict is taken when the records arrive: irlosc_upload / irlosc_upload_raw look at every instance (one pass on the device:
  * M[i][j] exactly 0 unless hinge i is above hinge j or j above i; columns of J exactly 0 for hinges that move no end-effector
  * candidate -- what mj_fullM / mj_jacBody leave, robot.py:68-72, device.py:115-133), batches of 64 instances and more only;
- * irlosc_frontend's lane kernel writes such records by construction; irlosc_assemble_device (caller's stream) never
- * qualifies.  A train of irlosc_step_resident uses the form when every slot in it qualifies.  Results differ from the
- * dense recursion at rounding level only.  IRLOSC_TREE=0 in the environment turns the form off. */
+ * irlosc_frontend's lane kernel writes such records by construction; irlosc_assemble_device (caller's stream) does not
+ * qualify until irlosc_probe_structure has looked.  A train of irlosc_step_resident uses the form when every slot in it
+ * qualifies.  Results differ from the dense recursion at rounding level only.  IRLOSC_TREE=0 in the environment turns the
+ * form off. */
 int irlosc_slot_structure(const irlosc_ctx* ctx, int32_t slot);
 /* The same look at records that are already in `slot` (first B instances), for the one path that cannot take it by itself:
  * irlosc_assemble_device on a caller's stream.  Synchronous on the context's stream -- the caller synchronises its own stream
