@@ -31,6 +31,12 @@ environment -- bench.py starts its N workers itself.  No PyTorch here: the barri
 time and the all-gather of per-rank output checksums are RCCL calls behind the C ABI (irlosc_bench_allreduce,
 irlosc_comm_allgather_u64), and the device synchronisation is hipDeviceSynchronize (irlosc_device_sync).
 Rank 0 prints ONE JSON line.
+
+--require-rccl: exit non-zero unless the barrier / reduction of an N > 1 run went through RCCL on every rank (by default a rank
+that cannot bring RCCL up makes ALL ranks fall back to files together, and the line says so in config.sharding /
+config.rccl_ranks = 0).  --slices S: the rank's batch is the concatenation of S independently seeded sub-batches ("virtual ranks"
+rank * S + j), and the line carries one output checksum per sub-batch (slice_checksums): an 8-rank run and a 1-rank
+`--slices 8` run of the same total batch must agree slice by slice -- sharding changes no bit.
 """
 import argparse
 import json
@@ -58,7 +64,7 @@ FLOPS_FRONT_END = 20.1e3                                                # FK, EE
 MODES = {   # --dtype -> (record dtype, arithmetic label, kernel id)
     "f64": (np.float64, "f64", 0),
     "mixed": (np.float32, "f64", 3),
-    "f32": (np.float32, "f32", 0),
+    "f32": (np.float32, "f32", 2),      # explicit opt-in: IRLOSC_KERNEL_GROUP
 }
 
 
@@ -304,6 +310,9 @@ def measure_from_q(BatchedOSC, synth, args, B, local_rank, state0=None, ref_u=No
         ms_total, ms_step = osc.step_resident_from_q(steps)
         osc.device_sync()
         el = time.perf_counter() - t0
+        trains = osc.time_trains(64, from_q=True) if "fused" in osc.from_q_name else None
+        for s in range(args.slots):                     # a fused step leaves no records in the slot (include/irlosc.h)
+            osc.frontend(slot=s)
         _, ms_osc = osc.step_resident(steps)
         esz = np.dtype(dt).itemsize
         flops = FLOPS_FRONT_END + FLOPS_OSC_STEP.get(args.layout, FLOPS_OSC_STEP["k13"])
@@ -316,6 +325,7 @@ def measure_from_q(BatchedOSC, synth, args, B, local_rank, state0=None, ref_u=No
                                  frac=achieved / FP64_VALU_PEAK_TFLOPS, flops_per_step_per_instance=flops,
                                  note="useful fp64 flops (FMA = 2) of front end + OSC step, DESIGN.md section 5; HBM sees "
                                       "568 B in and 200 B out per robot, so the HBM roof is not the bound of this path"),
+                   untraced=train_summary(trains, osc.steps_per_launch) if trains is not None else None,
                    note="per step: rigid-body front end (FK, EE Jacobians, CRBA, RNEA) from resident (qpos, qvel) and the OSC step on "
                         "what it leaves behind (fused path: a compact exchange buffer of the structural non-zeros, 2.5 KB per robot, "
                         "instead of 8.5 KB of dense records); nothing crosses PCIe")
@@ -346,6 +356,97 @@ def _parity_plain(u, ref, tol, note):
     err = np.max(np.abs(u[:n].astype(np.float64) - ref), axis=1) / np.max(np.abs(ref), axis=1)
     return {"n": int(n), "tolerance": tol, "median_rel_err": float(np.median(err)), "p99_rel_err": float(np.quantile(err, 0.99)),
             "max_rel_err": float(err.max()), "n_over_tol": int((err > tol).sum()), "note": note}
+
+
+def train_summary(tt, spl):
+    """irlosc_time_trains -> the three figures that reconcile a kernel trace with the driver's clock: the in-kernel duration of a
+    train (first wave's start to last wave's end, the kernel's own 100 MHz clock: what a trace reports per dispatch without the
+    tracer), the steady-state PERIOD between consecutive trains' starts (what ms_per_step x steps_per_launch measures), and the
+    HIP event pair around a train."""
+    tt = np.asarray(tt)
+    dur = tt[:, 2] - tt[:, 1]
+    per = np.diff(tt[:, 1])
+    q = lambda a, x: float(np.quantile(a, x))
+    return {"trains": int(len(tt)), "steps_per_train": int(spl),
+            "kernel_span_us": {"median": q(dur, 0.5), "p10": q(dur, 0.1), "p90": q(dur, 0.9)},
+            "period_us": {"median": q(per, 0.5), "p10": q(per, 0.1), "p90": q(per, 0.9), "mean": float(per.mean())},
+            "event_pair_us": {"median": q(tt[:, 0], 0.5) * 1e3, "mean": float(tt[:, 0].mean()) * 1e3},
+            "overlap_us_median": q(dur[:-1] - per, 0.5),
+            "note": "untraced, one run: kernel_span = last wave's end - first wave's start of a train's main kernel (s_memrealtime stamped "
+                    "in the kernel); period = start-to-start of consecutive trains; overlap = span - period (> 0: the next train's "
+                    "first waves run while this train's last waves drain -- kernels of one stream are not serialised by a barrier)"}
+
+
+def measure_end_to_end(BatchedOSC, lay, gains, arr, dt, kern, local_rank):
+    """SURVEY.md 8(d) "separately end-to-end with H2D/D2H": the boundary handing over HOST arrays every tick.  Never `value`."""
+    try:
+        B = arr["M"].shape[0]
+        esz = np.dtype(dt).itemsize
+        osc = BatchedOSC(lay, B, dtype=dt, hip_device=local_rank, kernel=kern)
+        osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+        a = (arr["M"], arr["J"], arr["dq"], arr["bias"], arr["ee_pose"], arr["tgt_pose"], arr.get("tgt_vel"), arr.get("wrench"))
+        for _ in range(2):
+            osc.generate_batched(*a)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter(); osc.generate_batched(*a); ts.append(time.perf_counter() - t0)
+        el = float(np.median(ts))
+        nbytes = sum(x.nbytes for x in a if x is not None) + B * lay.n * esz + 4 * B
+        out = {"generate_batched": {"value": B / el, "unit": "steps/s", "ms_per_tick": el * 1e3, "instances": B,
+                                    "pcie_GBps": nbytes / el / 1e9, "bytes_per_instance": nbytes // B, "kernel": osc.kernel_name,
+                                    "what": "BatchedOSC.generate_batched from pageable host arrays: irlosc_upload (records + device-side symmetry / "
+                                            "structure probes) + irlosc_set_targets + irlosc_step with the torques and flags copied back"}}
+        osc.close()
+        # B = 1: what OSC.generate costs per tick (irlosc_tick: pack, one H2D, the step, one D2H, one synchronisation)
+        one = {k: (v[:1] if isinstance(v, np.ndarray) else v) for k, v in arr.items()}
+        osc = BatchedOSC(lay, 1, dtype=dt, hip_device=local_rank, kernel=kern)
+        osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+        a1 = (one["M"], one["J"], one["dq"], one["bias"], one["ee_pose"], one["tgt_pose"], one.get("tgt_vel"), one.get("wrench"))
+        for _ in range(50):
+            osc.tick(*a1)
+        t1 = []
+        for _ in range(300):
+            t0 = time.perf_counter(); osc.tick(*a1); t1.append(time.perf_counter() - t0)
+        out["tick_b1_us"] = {"median": float(np.median(t1)) * 1e6, "p99": float(np.quantile(t1, 0.99)) * 1e6, "kernel": osc.kernel_name,
+                             "what": "irlosc_tick at B = 1 (the call under OSC.generate)"}
+        osc.close()
+        # raw simulator arrays in, state assembly on the GPU (irlosc_upload_raw), then the step: k13 only (the mapping below)
+        if lay.k == 13 and lay.ndev == 3:
+            from irl_control_amd import _lib
+            nv, ns = 25, 18
+            d = _lib.RawDesc()
+            d.nv, d.n_sensor = nv, ns
+            for p_ in range(32):
+                d.joint_ids[p_] = p_ if p_ < 25 else 0
+                d.dq_src[p_] = p_ if p_ < 25 else -1
+            for i in range(4):
+                d.ft_force0[i], d.ft_torque0[i] = -1, -1
+            jacp, jacr = np.zeros((B, 3, 3, nv), dt), np.zeros((B, 3, 3, nv), dt)
+            jacp[:, 0], jacr[:, 0] = arr["J"][:, 0:3], arr["J"][:, 3:6]
+            jacp[:, 1], jacr[:, 1] = arr["J"][:, 6:9], arr["J"][:, 9:12]
+            jacr[:, 2, 2] = arr["J"][:, 12]
+            raw = dict(qM=arr["M"], qvel=arr["dq"], qfrc_bias=arr["bias"], jacp=jacp, jacr=jacr,
+                       ee_xpos=np.ascontiguousarray(arr["ee_pose"][:, :, :3]), ee_xquat=np.ascontiguousarray(arr["ee_pose"][:, :, 3:]))
+            osc = BatchedOSC(lay, B, dtype=dt, hip_device=local_rank, kernel=kern)
+            osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+            ts = []
+            for it in range(5):
+                t0 = time.perf_counter()
+                osc.upload_raw(d, **raw)
+                osc.set_targets(arr["tgt_pose"])
+                osc.step()
+                ts.append(time.perf_counter() - t0)
+            el = float(np.median(ts[1:]))
+            rb = sum(x.nbytes for x in raw.values()) + arr["tgt_pose"].nbytes + B * lay.n * esz + 4 * B
+            out["upload_raw_step"] = {"value": B / el, "unit": "steps/s", "ms_per_tick": el * 1e3, "pcie_GBps": rb / el / 1e9,
+                                      "what": "raw simulator arrays (mj_fullM, jacp / jacr, qvel, qfrc_bias, xpos / xquat; nv = 25) from the host, "
+                                              "state assembly on the GPU (irlosc_upload_raw), targets, one step, torques back"}
+            osc.close()
+        out["note"] = ("host arrays cross PCIe every tick: the link bounds these figures, not the kernel; `value` (inputs resident in HBM) "
+                       "is the headline, and from_q (568 B per robot in) is the path that needs no dense records at all")
+        return out
+    except Exception as e:                              # never break the bench line
+        return dict(error=str(e))
 
 
 def self_launch(args_list, n):
@@ -390,11 +491,16 @@ def main():
     ap.add_argument("--kernel", type=int, default=-1, help="override: 0 auto, 1 generic, 2 group, 3 row16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="length of each of the two CPU timing windows (one core, all cores)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the other arithmetic / storage variants")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other storage variant (mixed) and the synthetic-records run")
+    ap.add_argument("--with-f32", action="store_true", help="also run the fp32-arithmetic group kernel as a secondary (explicit opt-in kernel: does NOT meet 1e-5)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the H2D/D2H-inclusive legs (generate_batched from host arrays, tick at B = 1, upload_raw)")
+    ap.add_argument("--require-rccl", action="store_true", help="N > 1: exit non-zero unless every rank's barrier / reduction went through RCCL")
+    ap.add_argument("--slices", type=int, default=1, help="sub-batches ('virtual ranks') per rank, one output checksum each")
     ap.add_argument("--no-from-q", action="store_true", help="skip the joint-coordinates path (front end + step)")
     ap.add_argument("--workload", default="physical", choices=["physical", "synthetic"],
                     help="physical: records of random joint states from the front end (tree zeros); synthetic: random dense SPD M")
     ap.add_argument("--mint-physical", default=None, help=argparse.SUPPRESS)   # internal: write slot 0 of the physical workload to this directory
+    ap.add_argument("--as-rank", type=int, default=-1, help=argparse.SUPPRESS)  # internal: seed the data like this rank (the minting child of rank 0)
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -402,29 +508,41 @@ def main():
 
     from irl_control_amd import BatchedOSC, sharding, synth
     rank, world, local_rank = sharding.env_world()
+    if args.as_rank >= 0:
+        rank = args.as_rank
     if "IRLOSC_BENCH_DEVICE" in os.environ:                  # test hook: several ranks on ONE GPU (then RCCL refuses the duplicate
         local_rank = int(os.environ["IRLOSC_BENCH_DEVICE"])  # device and the file-based reduction is what gets exercised)
     if world != args.gpus:
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     B = args.total_batch // world if args.total_batch else args.batch
+    S = max(1, args.slices)
+    if B % S:
+        sys.exit(f"--slices {S} does not divide the {B} instances of a rank")
+    Bs = B // S
     comm, comm_note = None, "single process"
-    if world > 1:
-        comm, comm_note = sharding.make_comm(rank, world, local_rank)
+
+    def vrank(j):                        # "virtual rank" of sub-batch j of this rank: what seeds its data
+        return rank * S + j
 
     def make_slot(mode, s):
-        return synth.make_batch(args.layout, B, seed=20241008 + 1000 * 2 + 17 * s + 101 * rank, dtype=MODES[mode][0])
+        parts = [synth.make_batch(args.layout, Bs, seed=20241008 + 1000 * 2 + 17 * s + 101 * vrank(j), dtype=MODES[mode][0]) for j in range(S)]
+        lay_, gains_ = parts[0][0], parts[0][1]
+        arr_ = {k: np.concatenate([p_[2][k] for p_ in parts], axis=0) for k in parts[0][2]} if S > 1 else parts[0][2]
+        return lay_, gains_, arr_
 
     def fill_physical(osc, lay, dt, s, model):
         """Slot s of the physical workload: random joint states -> front end (records stay in HBM) -> targets around the end
         effectors it found (-> wrench for the admittance layout, which only arrives with an upload of records).  Returns
         slot 0's records as host arrays (what the oracle legs are run on), None for the other slots."""
-        rng = np.random.default_rng(20241008 + 1000 * 2 + 17 * s + 101 * rank + 500000)
-        qpos, qvel = model.random_state(rng, B)
+        rngs = [np.random.default_rng(20241008 + 1000 * 2 + 17 * s + 101 * vrank(j) + 500000) for j in range(S)]
+        st = [model.random_state(r_, Bs) for r_ in rngs]
+        qpos, qvel = np.concatenate([x_[0] for x_ in st]), np.concatenate([x_[1] for x_ in st])
         osc.upload_q(qpos, qvel, slot=s)
         osc.frontend(slot=s)
         ee = osc.download_records(s, keys=("ee_pose",))["ee_pose"]
-        tgt = synth.targets_near(ee.astype(np.float64), rng).astype(dt)
-        wrench = rng.normal(0.0, 5.0, size=(B, lay.ndev, 6)).astype(dt) if lay.admittance else None
+        tgt = np.concatenate([synth.targets_near(ee[j * Bs:(j + 1) * Bs].astype(np.float64), rngs[j]) for j in range(S)]).astype(dt)
+        wrench = (np.concatenate([rngs[j].normal(0.0, 5.0, size=(Bs, lay.ndev, 6)) for j in range(S)]).astype(dt)
+                  if lay.admittance else None)
         rec = None
         if wrench is not None or s == 0:
             rec = osc.download_records(s)
@@ -519,32 +637,46 @@ def main():
                 "; tree-structured factorisation M = L^T L on the dense records (their zero pattern verified at upload / by construction)"
                 if tree else "")
         prof = measured_profile(kname)
+        same = prof.get("instances", B) == B and prof.get("steps_per_launch", spl) == spl
+        # `traffic` is a PMC figure: it cannot be taken in an untraced run, so the line carries the one of the committed passes
+        # (profiles/hbm_traffic.json) and says so under committed_profile; everything else in `roofline` is measured in THIS run
         roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=achieved / HBM_PEAK_GBS,
-                    traffic=prof.get("traffic_bytes_per_launch") if prof.get("instances", B) == B else None,
+                    traffic=prof.get("traffic_bytes_per_launch") if same else None,
+                    traffic_source="committed_profile (PMC passes need a tracer; not measured in this run)" if same and prof.get("traffic_bytes_per_launch") else None,
                     kernel=kname + note, kernel_ms=ms_dom, steps_per_launch=spl, step_ms_events=ms_kernel,
                     whole_step_achieved=bytes_step / (ms_kernel * 1e-3) / 1e9,
                     algorithmic_bytes_per_launch=bytes_launch,
                     algorithmic_bytes_per_step_per_instance=bytes_step // B)
-        if prof.get("rocprof_avg_us") and prof.get("steps_per_launch") == spl and prof.get("instances") == B:
-            # the committed kernel trace of the same command (profiles/): tracing serialises dispatches and adds its own
-            # overhead, so this is the conservative figure next to the live one (profiles/README.md has the timestamps)
-            roof["rocprof_kernel_ms"] = prof["rocprof_avg_us"] * 1e-3
-            roof["frac_rocprof"] = bytes_launch / (prof["rocprof_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+        if "row16" in kname:
+            # untraced evidence of the same run: per-train event pairs + the wall clock stamped inside the kernel
+            ntr = 256 if steps >= 1000 else 32
+            roof["untraced"] = train_summary(osc.time_trains(ntr), spl)
+            roof["untraced"]["frac_from_period"] = bytes_launch / (roof["untraced"]["period_us"]["median"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            roof["untraced"]["frac_from_kernel_span"] = bytes_launch / (roof["untraced"]["kernel_span_us"]["median"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+        if prof.get("rocprof_avg_us") and same:
+            # the COMMITTED rocprofv3 passes of this command (profiles/; not measured now): kernel trace average and PMC traffic
+            roof["committed_profile"] = {
+                "file": "profiles/hbm_traffic.json", "entry": kname,
+                "rocprof_avg_us": prof["rocprof_avg_us"], "traffic_bytes_per_launch": prof.get("traffic_bytes_per_launch"),
+                "frac_rocprof": bytes_launch / (prof["rocprof_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "note": "a kernel trace serialises dispatches: its per-dispatch average corresponds to untraced.kernel_span_us, not to "
+                        "ms_per_step x steps_per_launch (= untraced.period_us); profiles/README.md"}
         res = dict(value=rate, ms_per_step=elapsed / steps * 1e3, kernel=kname, mode=mode, arith=arith,
                    records="float64" if esz == 8 else "float32", layout=lay, roofline=roof, workload=workload)
         osc.step(slot=0)
         u, fl = osc.download(B)
         res["checksum"] = sharding.checksum_u64(u)
+        res["slice_checksums"] = [sharding.checksum_u64(u[j * Bs:(j + 1) * Bs]) for j in range(S)]
         osc.close()
         return res, (lay, gains, slot0, u, fl)
 
     # CPU legs first: their worker processes are forked before this process has initialised the HIP runtime
     cb = ref = ref_idx = fq_state = fq_ref = None
-    others = [m for m in ("f64", "mixed", "f32") if m != args.dtype] if (world == 1 and not args.no_secondary) else []
+    others = [m for m in (("f64", "mixed") + (("f32",) if args.with_f32 else ())) if m != args.dtype] if (world == 1 and not args.no_secondary) else []
     NSEC = 4096                       # instances of slot 0 the secondary modes are checked on (oracle in this process)
     minted_crc = None
-    if world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:          # N > 1 too: rank 0's host cores, rank 0's shard (the other ranks wait in make_comm)
         if args.workload == "physical":
             # The records of the physical workload come from the GPU front end, and the CPU legs fork their workers before
             # THIS process touches the HIP runtime: a child process computes slot 0 (same seeds, same kernel: the same bits,
@@ -559,8 +691,9 @@ def main():
                     if os.environ.get("IRLOSC_BENCH_FAIL_MINT"):          # test hook: the hand-over fails, the line must still come out
                         raise OSError("IRLOSC_BENCH_FAIL_MINT is set")
                     cmd = [sys.executable, os.path.abspath(__file__), "--mint-physical", d, "--batch", str(B), "--layout", args.layout,
-                           "--dtype", args.dtype, "--slots", "1"]
-                    env = dict(os.environ)
+                           "--dtype", args.dtype, "--slots", "1", "--slices", str(S), "--as-rank", str(rank)]
+                    env = {k_: v_ for k_, v_ in os.environ.items()
+                           if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "IRLOSC_RDV_TAG")}
                     env["IRLOSC_BENCH_DEVICE"] = str(local_rank)
                     subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL)
                     arr0 = {f[:-4]: np.load(os.path.join(d, f)) for f in sorted(os.listdir(d)) if f.endswith(".npy")}
@@ -583,7 +716,7 @@ def main():
             cb["sample"] += f"; SYNTHETIC records (slot 0 of the physical workload could not be handed to the CPU legs: {mint_error})"
         else:
             cb, ref, ref_idx = cpu_baseline(lay0, gains0, arr0, args.cpu_seconds, args.cpu_seconds)
-        if not args.no_from_q and args.layout in ("k13", "k7"):
+        if world == 1 and not args.no_from_q and args.layout in ("k13", "k7"):
             from irl_control_amd.rigid_body import RigidBodyModel
             model = RigidBodyModel.load("dual_ur5")
             fq_state = model.random_state(np.random.default_rng(20241008 + 77), B)
@@ -591,6 +724,13 @@ def main():
             fq_ref = from_q_reference(lay0, gq, fq_state[0], fq_state[1], aq["tgt_pose"], 4096, effective_cores()[0])
             del aq
         del arr0
+    if world > 1:        # behind the CPU legs: RCCL initialises the HIP runtime, and the CPU workers are forked before that
+        comm, comm_note = sharding.make_comm(rank, world, local_rank, init_timeout_s=900.0)
+        if args.require_rccl and not isinstance(comm, sharding.RcclComm):
+            if rank == 0:
+                print(f"bench.py: --require-rccl, but the ranks fell back: {comm_note}", file=sys.stderr, flush=True)
+            comm.close()
+            sys.exit(3)
     primary, chk = measure(args.dtype, args.steps, args.warmup, preroll=args.preroll, workload=args.workload)
     if minted_crc is not None and sharding.checksum_u64(chk[2]["M"]) != minted_crc:
         raise RuntimeError("slot 0 of the physical workload differs between the minting process and this one")
@@ -600,7 +740,9 @@ def main():
         "metric": "OSC control steps/sec", "value": primary["value"], "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": primary["ms_per_step"],
         "higher_is_better": True, "scaling": "strong" if args.total_batch else "weak", "vs_baseline": None,
-        "dtype": primary["arith"], "data": "synthetic",
+        "dtype": primary["arith"],
+        "data": "synthetic (" + ("records of uniformly random joint states from the rigid-body front end" if args.workload == "physical"
+                                 else "random dense SPD M, SURVEY.md 8d") + "; no dataset, no checkpoint)",
         "config": {"workload": f"{B} Dual-UR5 instances per GPU ({baseline_config_of(args.layout, B, world, args.dtype)}), "
                                + ("records of uniformly random joint states (SURVEY.md 8d: true CRBA on random qpos) computed once by "
                                   "the rigid-body front end before the timed region, targets scattered around the end effectors, "
@@ -614,12 +756,17 @@ def main():
                    "kernel": primary["kernel"], "records_from": args.workload, "preroll_steps": args.preroll,
                    "steps_per_launch": primary["roofline"]["steps_per_launch"],
                    "sharding": f"{world} x independent shards, no data-path collective; barrier and final sum(steps) / "
-                               f"max(elapsed) reduction: {comm_note}"},
+                               f"max(elapsed) reduction: {comm_note}",
+                   "rccl_ranks": (world if isinstance(comm, sharding.RcclComm) else 0) if world > 1 else None,
+                   "slices_per_rank": S},
         "roofline": primary["roofline"],
     }
     # per-rank checksum of one step's outputs on slot 0 (rank r's data depend on r only, so its checksum must be the
     # same in the 1-, 2-, 4- and 8-GPU runs: sharding changes no bit)
     out["rank_checksums"] = [f"{v:016x}" for v in (comm.allgather_u64(primary["checksum"]) if comm else [primary["checksum"]])]
+    # slice_checksums[r][j] = sub-batch j ("virtual rank" r * S + j) of rank r: equal across every way of cutting the same total batch
+    cols = [(comm.allgather_u64(c_) if comm else [c_]) for c_ in primary["slice_checksums"]]
+    out["slice_checksums"] = [[f"{cols[j][r]:016x}" for j in range(S)] for r in range(world)]
     if rank == 0:
         lay_, gains, arr, u, fl = chk
         out["flags"] = {"eigen_path_frac": float(((fl & 4) != 0).mean()), "pinv_branch_frac": float(((fl & 2) != 0).mean()),
@@ -659,8 +806,17 @@ def main():
                           "north_star's 1e-5 (n_over_tol says by how much); " if f32 else "")
                          + "GPU vs float64 oracle on the same (record-dtype-rounded) records; parity domain per SURVEY.md 8c")
             out["secondary"].append(entry)
+    for e_ in out.get("secondary", []):       # rounds 1-3 quoted this workload as the headline: kept at top level under its own name
+        if e_.get("records_from") == "synthetic" and e_.get("mode") == args.dtype and "value" in e_:
+            out["synthetic_dense_records"] = {"metric": "OSC control steps/sec on synthetic dense records (random SPD M without the tree's zeros)",
+                                              "value": e_["value"], "ms_per_step": e_["ms_per_step"], "kernel": e_["kernel"],
+                                              "roofline_frac": e_["roofline"]["frac"]}
     if world == 1 and not args.no_from_q:
         out["from_q"] = measure_from_q(BatchedOSC, synth, args, B, local_rank, fq_state, fq_ref)
+    if world == 1 and rank == 0 and not args.no_end_to_end:
+        lay_, gains_, arr_ = chk[0], chk[1], chk[2]
+        out["end_to_end"] = measure_end_to_end(BatchedOSC, lay_, gains_, arr_, MODES[args.dtype][0],
+                                               args.kernel if args.kernel >= 0 else MODES[args.dtype][2], local_rank)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if comm:

@@ -36,7 +36,9 @@
  * Contracts the kernels rely on (not checked on the device):
  *   - M is symmetric: the throughput kernels read row j of M as its column j (the generic kernel uses M as given, like
  *     osc.py:49,151).  Records that come from the HOST are probed on the device: irlosc_upload and irlosc_tick return
- *     IRLOSC_ERR_ARG when an instance has max |M - M^T| > 1e-6 max |M| and the context runs a throughput kernel.  Records
+ *     IRLOSC_ERR_ARG when an instance has max |M - M^T| > 1e-6 max |M| (over its FINITE entries: a robot whose M holds
+ *     NaN / Inf is not refused -- it is reported per instance through IRLOSC_FLAG_NONFINITE / M_NOT_PD and the other robots
+ *     of the batch get their torques) and the context runs a throughput kernel.  Records
  *     assembled on the device (irlosc_upload_raw / irlosc_assemble_device / irlosc_frontend) are symmetric by
  *     construction; for irlosc_step_device it stays the caller's contract;
  *   - (not a contract, an observation the library makes for itself) records of a real robot carry the zeros of its kinematic
@@ -93,10 +95,13 @@ typedef enum {
 #define IRLOSC_FLAG_NONFINITE    64u   /* output contains NaN/Inf */
 
 /* kernel selection (cfg.kernel) */
-#define IRLOSC_KERNEL_AUTO    0
+#define IRLOSC_KERNEL_AUTO    0   /* fp64 ARITHMETIC always (the reference's, osc.py:49-55; meets 1e-5): row16 where the shape
+                                     has an instantiation -- on float64 records and on float32 records alike -- else generic */
 #define IRLOSC_KERNEL_GENERIC 1   /* one wavefront per instance, LDS tiles, any n<=32, k<=16 */
-#define IRLOSC_KERNEL_GROUP   2   /* fp32: 4 lanes per instance, register-resident factors (n=25 shapes) */
-#define IRLOSC_KERNEL_ROW16   3   /* fp64: 16 lanes (one DPP row) per instance, broadcast-FMA formulation (n=25 shapes) */
+#define IRLOSC_KERNEL_GROUP   2   /* EXPLICIT OPT-IN ONLY, never picked by AUTO: fp32 records AND fp32 arithmetic, 4 lanes per
+                                     instance (n=25 shapes).  Error ~ eps32 * cond(J M^-1 J^T): does NOT meet the 1e-5 bar */
+#define IRLOSC_KERNEL_ROW16   3   /* fp64 arithmetic: 16 lanes (one DPP row) per instance, broadcast-FMA formulation
+                                     (n=25; (k, ndev) = (13,3), (12,2), (7,3), (6,2)); float32 records = the "mixed" path */
 
 typedef struct irlosc_cfg {
     int32_t hip_device;                      /* HIP device ordinal */
@@ -172,6 +177,18 @@ int irlosc_step_resident(irlosc_ctx* ctx, int32_t first_slot, int32_t B, int32_t
  * the fused launch (stage 1 of irlosc_steps_per_launch() chained steps + the riding stage 2 of the previous
  * launch's steps); generic path: the generic kernel.  Outputs are complete, as after irlosc_step_resident. */
 int irlosc_time_dominant_kernel(irlosc_ctx* ctx, int32_t slot, int32_t B, int32_t iters, float* ms_avg);
+/* Roofline evidence WITHOUT a tracer ("Timing method"; row16 kernel only).  `ntrains` (<= 4096) consecutive
+ * trains of irlosc_steps_per_launch() steps, issued exactly as irlosc_step_resident issues them (slots rotating from first_slot),
+ * after one untimed train.  Every train gets (a) its own HIP event pair on the library's stream and (b) the wall clock
+ * (s_memrealtime, 100 MHz) stamped by its main kernel itself: the start of its first wave and the end of its last wave.
+ *   out[3 i + 0]  event pair of train i in milliseconds (main kernel + give-up pass; from_q: walk + OSC kernel + give-up pass)
+ *   out[3 i + 1]  start of train i's first wave, microseconds after the first wave of train 0
+ *   out[3 i + 2]  end of train i's last wave, same origin
+ * => in-kernel duration of train i = out[3 i + 2] - out[3 i + 1] (what a kernel trace reports per dispatch, minus the
+ * tracer's own serialisation); steady-state period = out[3 (i + 1) + 1] - out[3 i + 1] (what irlosc_step_resident's wall
+ * time divided by the number of trains measures).  from_q != 0: trains of irlosc_step_resident_from_q (the stamps are the OSC
+ * kernel's; the walk in front of it is inside the period and the event pair). */
+int irlosc_time_trains(irlosc_ctx* ctx, int32_t first_slot, int32_t B, int32_t ntrains, int32_t from_q, double* out);
 /* Steps chained in one launch by irlosc_step_resident / irlosc_time_dominant_kernel (1 on the generic path):
  * the algorithmic bytes of one dominant launch = this many steps' worth. */
 int irlosc_steps_per_launch(const irlosc_ctx* ctx);
@@ -273,9 +290,13 @@ int irlosc_download_records(irlosc_ctx* ctx, int32_t slot, int32_t B, void* M, v
  * With the compiled Dual-UR5 tree shape and the fp64 row16 kernel this is the FUSED path: the lane-per-robot walk leaves only
  * the structural non-zeros of M and J, the bias forces and the EE poses in a compact exchange buffer (2.4 KB per robot,
  * written once, coalesced) and the OSC kernel gathers its operands from there -- the dense records of the slot are neither
- * written nor read (robots the in-kernel eigen stage hands to the generic kernel get theirs from the wave-per-robot front end;
- * their entries of the slot's records are overwritten).  Other models / kernels: irlosc_frontend + irlosc_step.
- * set_model allocates one exchange buffer per step of a train for it: 8 x ceil(max_batch / 64) x 318 x 512 bytes. */
+ * written nor read -- except that robots the in-kernel eigen stage hands to the generic kernel get theirs from the
+ * wave-per-robot front end, into the slot.  AFTER A FUSED STEP THE SLOT THEREFORE HOLDS NO RECORDS: irlosc_step,
+ * irlosc_step_resident and irlosc_download_records on it fail with IRLOSC_ERR_STATE until irlosc_frontend / irlosc_upload* fills
+ * it again (its joint coordinates and targets stay).  Other models / kernels: irlosc_frontend + irlosc_step (records left behind).
+ * The exchange buffers (ceil(max_batch / 64) x 318 x 512 bytes each) are allocated by the first fused step: one for this call,
+ * one per step of a train (8) for irlosc_step_resident_from_q; if that allocation fails the context drops to the path through
+ * dense records. */
 int irlosc_step_from_q(irlosc_ctx* ctx, int32_t slot, int32_t B, void* u_host, uint32_t* flags_host);
 /* What irlosc_step_from_q / irlosc_step_resident_from_q launch ("" before irlosc_set_model). */
 const char* irlosc_from_q_name(const irlosc_ctx* ctx);

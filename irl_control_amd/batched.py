@@ -32,6 +32,11 @@ class BatchedOSC:
                                    f"{self.lib.irlosc_last_error(None).decode()}")
         self._h = h
         self._B = [0] * self.n_slots
+        if kernel == _lib.KERNEL_AUTO and self.max_batch >= 1024 and "generic" in self.kernel_name:
+            import warnings
+            warnings.warn(f"layout (n={layout.n}, k={layout.k}, ndev={layout.ndev}) has no throughput instantiation: "
+                          f"{self.kernel_name} (one wavefront per instance, ~25x slower than osc_row16 at this batch size); "
+                          "row16 shapes: n=25 with (k, ndev) in {(13,3), (12,2), (7,3), (6,2)}", RuntimeWarning, stacklevel=2)
 
     # -- plumbing ---------------------------------------------------------------------------------
     def _chk(self, rc):
@@ -146,6 +151,14 @@ class BatchedOSC:
         a = C.c_float()
         self._chk(self.lib.irlosc_time_dominant_kernel(self._h, slot, B, iters, C.byref(a)))
         return a.value
+
+    def time_trains(self, ntrains: int, first_slot: int = 0, B: Optional[int] = None, from_q: bool = False) -> np.ndarray:
+        """Untraced timing of `ntrains` consecutive trains (irlosc_time_trains): -> [ntrains, 3] = (HIP event pair of the train in
+        ms, start of its first wave, end of its last wave in microseconds of the kernels' own 100 MHz clock since train 0)."""
+        B = self._B[first_slot] if B is None else B
+        out = np.zeros((int(ntrains), 3), dtype=np.float64)
+        self._chk(self.lib.irlosc_time_trains(self._h, first_slot, B, int(ntrains), 1 if from_q else 0, _lib.ptr(out)))
+        return out
 
     @property
     def steps_per_launch(self) -> int:

@@ -79,7 +79,10 @@ __global__ __launch_bounds__(64) void osc_assemble_kernel(const RawDesc d, const
 
 // Symmetry probe for irlosc_upload / irlosc_tick on the throughput paths (which read row j of M as its column j): counts the
 // instances with max |M - M^T| > 1e-6 max |M| in out[0] and remembers the first one as out[1] = max(INT_MAX - b), so that
-// both words start from zero (one memset).  One 64-thread block per instance, grid-strided; one pass over M (0.16 ms per
+// both words start from zero (one memset).  Only pairs of FINITE entries are judged: a robot whose M holds NaN / Inf (a
+// diverged simulation) is not "asymmetric" -- it goes through to the kernel, which reports it per instance
+// (IRLOSC_FLAG_NONFINITE / M_NOT_PD) while the other robots of the batch get their torques, like the reference, which
+// simply propagates the NaN of that robot.  One 64-thread block per instance, grid-strided; one pass over M (0.16 ms per
 // 65 536 instances, against ~10 ms of PCIe for the same records).
 template <typename T>
 __global__ __launch_bounds__(64) void osc_symmetry_kernel(const T* __restrict__ M, const int n, const int B, int32_t* __restrict__ out) {
@@ -90,12 +93,14 @@ __global__ __launch_bounds__(64) void osc_symmetry_kernel(const T* __restrict__ 
         for (int e = lane; e < n * n; e += 64) {
             const int i = e / n, j = e - i * n;
             const double v = (double)Mb[e], w = (double)Mb[j * n + i];
-            asym = fmax(asym, fabs(v - w));
-            scale = fmax(scale, fabs(v));
+            if (t_finite(v) && t_finite(w)) {
+                asym = fmax(asym, fabs(v - w));
+                scale = fmax(scale, fabs(v));
+            }
         }
         asym = wave_max(asym);
         scale = wave_max(scale);
-        if (lane == 0 && !(asym <= 1e-6 * fmax(scale, 1e-300))) {       // also catches NaN
+        if (lane == 0 && asym > 1e-6 * fmax(scale, 1e-300)) {
             atomicAdd(&out[0], 1);
             atomicMax(&out[1], 0x7fffffff - b);
         }

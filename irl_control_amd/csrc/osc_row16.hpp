@@ -550,6 +550,9 @@ struct Row16Extra {
     const double* qvel;        // [B][n]
     const FeCompactTables* tables;
     int32_t xcd_map;           // 1: the XCD-aware block -> robots map of the FROMQ kernel (0: identity, A/B measurements)
+    // irlosc_time_trains: {min over waves of the start, max over waves of the end} of the 100 MHz wall clock (s_memrealtime),
+    // one pair per TRAIN (every step of a train points at the same pair); nullptr = no stamps
+    unsigned long long* span;
 };
 
 // One launch = a TRAIN of up to R16_TRAIN steps (blockIdx.y = step): consecutive steps of irlosc_step_resident are
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
     uint32_t flags = 0;
     // IRLOSC_PHASE_TIMING=1 debug runs: cycle stamps per phase and the wall clock of the wave (p.dbg != nullptr)
     unsigned long long ts[8];
-    const unsigned long long rt0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long rt0 = (p.dbg || x.span) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #define IRLOSC_TS(i) ts[i] = p.dbg ? __builtin_readcyclecounter() : 0ull
     IRLOSC_TS(0);
 
@@ -1118,6 +1121,10 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
         }
     }
     IRLOSC_TS(7);
+    if (x.span && lane == 0) {       // first wave's start / last wave's end of the train, untraced (irlosc_time_trains)
+        atomicMin(x.span, rt0);
+        atomicMax(x.span + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    }
     if (p.dbg && lane == 0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) p.dbg[(size_t)blockIdx.x * 10 + i] = ts[i];      // (the last step of a train wins)
@@ -1144,7 +1151,7 @@ __global__ __launch_bounds__(64) void osc_generic_worklist_kernel(const Row16Tra
 
 inline bool row16_kernel_supports(int dtype, int n, int k, int ndev) {
     (void)dtype;     // fp64 records, or fp32 records with fp64 arithmetic (mixed path)
-    return n == 25 && ((k == 13 && ndev == 3) || (k == 12 && ndev == 2) || (k == 7 && ndev == 3));
+    return n == 25 && ((k == 13 && ndev == 3) || (k == 12 && ndev == 2) || (k == 7 && ndev == 3) || (k == 6 && ndev == 2));
 }
 
 }  // namespace irlosc

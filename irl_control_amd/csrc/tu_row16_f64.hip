@@ -18,12 +18,14 @@ int launch_row16(const Row16Train<TIN>& tr, int nsteps, bool tree, hipStream_t s
         if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25, false, TopoDualUr5>), grid, dim3(64), 0, st, tr);
         else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<12, 2, TIN, 25, false, TopoDualUr5>), grid, dim3(64), 0, st, tr);
         else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<7, 3, TIN, 25, false, TopoDualUr5>), grid, dim3(64), 0, st, tr);
+        else if (p.k == 6 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<6, 2, TIN, 25, false, TopoDualUr5>), grid, dim3(64), 0, st, tr);
         else return (int)hipErrorNotSupported;
         return (int)hipGetLastError();
     }
     if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25>), grid, dim3(64), 0, st, tr);
     else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<12, 2, TIN, 25>), grid, dim3(64), 0, st, tr);
     else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<7, 3, TIN, 25>), grid, dim3(64), 0, st, tr);
+    else if (p.k == 6 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<6, 2, TIN, 25>), grid, dim3(64), 0, st, tr);
     else return (int)hipErrorNotSupported;
     return (int)hipGetLastError();
 }
@@ -40,6 +42,7 @@ int launch_row16_fromq(const Row16Train<TIN>& tr, int nsteps, hipStream_t st) {
     if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25, true, TopoDualUr5>), grid, dim3(64), 0, st, tr);
     else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<12, 2, TIN, 25, true, TopoDualUr5>), grid, dim3(64), 0, st, tr);
     else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<7, 3, TIN, 25, true, TopoDualUr5>), grid, dim3(64), 0, st, tr);
+    else if (p.k == 6 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<6, 2, TIN, 25, true, TopoDualUr5>), grid, dim3(64), 0, st, tr);
     else return (int)hipErrorNotSupported;
     return (int)hipGetLastError();
 }

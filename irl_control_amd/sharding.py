@@ -92,7 +92,7 @@ def exchange_bytes(rank: int, payload: Optional[bytes], nbytes: int, path: str, 
 class RcclComm:
     """RCCL communicator of one process-per-GPU job, through libirlosc (no torch)."""
 
-    def __init__(self, rank: int, world: int, hip_device: int, tag: Optional[str] = None):
+    def __init__(self, rank: int, world: int, hip_device: int, tag: Optional[str] = None, rdv_timeout_s: float = 120.0):
         self.lib = _lib.load()
         self.rank, self.world = rank, world
         path = rendezvous_path(tag)
@@ -103,7 +103,7 @@ class RcclComm:
             if rc != 0:
                 raise _lib.IrloscError(f"irlosc_comm_unique_id failed ({rc}): {self.lib.irlosc_comm_last_error(None).decode()}")
             uid = bytes(buf)
-        uid = exchange_bytes(rank, uid, _lib.COMM_ID_BYTES, path)
+        uid = exchange_bytes(rank, uid, _lib.COMM_ID_BYTES, path, timeout_s=rdv_timeout_s)
         h = C.c_void_p()
         idbuf = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(uid)
         rc = self.lib.irlosc_comm_create(hip_device, rank, world, idbuf, C.byref(h))
@@ -214,7 +214,7 @@ def make_comm(rank: int, world: int, hip_device: int, tag: Optional[str] = None,
 
     def init():
         try:
-            box["comm"] = RcclComm(rank, world, hip_device, tag)
+            box["comm"] = RcclComm(rank, world, hip_device, tag, rdv_timeout_s=init_timeout_s)
         except Exception as e:                                   # noqa: BLE001 - reported in the bench line
             box["err"] = str(e)
     th = threading.Thread(target=init, daemon=True)

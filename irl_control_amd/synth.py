@@ -16,6 +16,8 @@ LAYOUTS = {
                      [BASE_J, RIGHT_J, LEFT_J], [0, 1, 7], dict(branch_b=True)),
     "k7": (["ur5right", "ur5left", "base"], [XYZ + [False] * 3, XYZ + [False] * 3, [False] * 3 + YAW],
            [RIGHT_J, LEFT_J, BASE_J], [1, 4, 0], dict()),
+    # two arms, positions only, no base target: robot_configs/default_xyz.yaml:15-16,24-25 driven with the two arm targets
+    "k6": (["ur5right", "ur5left"], [XYZ + [False] * 3, XYZ + [False] * 3], [RIGHT_J, LEFT_J], [1, 4], dict()),
     "k12_admit": (["ur5right", "ur5left"], [XYZ + ABG, XYZ + ABG], [RIGHT_J, LEFT_J], [1, 7],
                   dict(admittance=True)),
 }

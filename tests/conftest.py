@@ -124,3 +124,44 @@ def golden_expected_u(g):
 @pytest.fixture(scope="session")
 def goldens():
     return {n: load_golden(n) for n in golden_names()}
+
+
+class HipBuffers:
+    """Device buffers for the tests that hand DEVICE pointers to the C ABI (irlosc_step_device / irlosc_assemble_device), straight
+    from libamdhip64 through ctypes: hipMalloc / hipMemcpy / hipFree -- no framework in between, so these tests cannot silently
+    vanish on a box without one."""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipFree.argtypes = [C.c_void_p]
+        self._ptrs = []
+
+    def _chk(self, rc, what):
+        assert rc == 0, f"{what} failed with hipError {rc}"
+
+    def alloc(self, nbytes):
+        p = self.C.c_void_p()
+        self._chk(self.hip.hipMalloc(self.C.byref(p), max(int(nbytes), 16)), "hipMalloc")
+        self._ptrs.append(p)
+        return p
+
+    def to_device(self, a):
+        a = np.ascontiguousarray(a)
+        p = self.alloc(a.nbytes)
+        self._chk(self.hip.hipMemcpy(p, a.ctypes.data_as(self.C.c_void_p), a.nbytes, 1), "hipMemcpy H2D")      # hipMemcpyHostToDevice
+        return p
+
+    def to_host(self, p, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        self._chk(self.hip.hipDeviceSynchronize(), "hipDeviceSynchronize")
+        self._chk(self.hip.hipMemcpy(out.ctypes.data_as(self.C.c_void_p), p, out.nbytes, 2), "hipMemcpy D2H")   # hipMemcpyDeviceToHost
+        return out
+
+    def free(self):
+        for p in self._ptrs:
+            self.hip.hipFree(p)
+        self._ptrs = []

@@ -169,3 +169,50 @@ def test_compiled_topology_header_matches_the_model_table():
         os.chdir(cwd)
     with open(os.path.join(root, "irl_control_amd", "csrc", "topo_dual_ur5.hpp")) as f:
         assert f.read() == buf.getvalue()
+
+
+MJ_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mj_dual_ur5.npz")
+
+
+def load_mujoco_fixture():
+    """tests/golden/mj_dual_ur5.npz (oracle/make_mujoco_golden.py, official `mujoco` bindings) or a SKIP that says why."""
+    if not os.path.exists(MJ_FIXTURE):
+        pytest.skip("PARITY WITH MUJOCO UNPINNED: tests/golden/mj_dual_ur5.npz absent -- MuJoCo is in neither the build image nor the "
+                    "GPU box; mint it with `python oracle/make_mujoco_golden.py <scenes/gain_test_scene.xml>` where `mujoco` is installed")
+    return np.load(MJ_FIXTURE)
+
+
+def test_against_mujoco_fixture():
+    """Row f1 pinned to what the reference reads from MuJoCo (robot.py:69 mj_fullM, device.py:125-128 jacp / jacr, osc.py:191
+    qfrc_bias, device.py:97-99 xpos / xquat): the rigid-body oracle -- and with it tools/parse_mjcf.py's reading of the MJCF
+    (frame composition, inertiafromgeom for the mesh-only base links, armature, defaults) -- on MuJoCo's own states."""
+    z = load_mujoco_fixture()
+    m = rb.Model(os.path.join(MODELS, "dual_ur5.json"))
+    assert [str(n) for n in z["joint_names"]] == m.raw["joint_names"]
+    assert np.allclose(z["gravity"], m.gravity)
+    dof, qadr = z["dofadr"], z["qposadr"]
+    ee = [m.body_id(str(n)) for n in z["ee_bodies"]]
+    worst = {}
+    for i in range(z["qpos"].shape[0]):
+        q, qd = z["qpos"][i][qadr], z["qvel"][i][dof]
+        M, bias, kin = rb.dynamics(m, q, qd)
+        got = {"fullM": M, "qfrc_bias": bias}
+        want = {"fullM": z["fullM"][i][np.ix_(dof, dof)], "qfrc_bias": z["qfrc_bias"][i][dof]}
+        for e, b in enumerate(ee):
+            jp, jr = rb.body_jacobian(m, kin, b)
+            got[f"jacp{e}"], want[f"jacp{e}"] = jp, z["jacp"][i, e][:, dof]
+            got[f"jacr{e}"], want[f"jacr{e}"] = jr, z["jacr"][i, e][:, dof]
+            got[f"xpos{e}"], want[f"xpos{e}"] = kin["xpos"][b], z["xpos"][i, e]
+            sgn = np.sign(kin["xquat"][b] @ z["xquat"][i, e])                # q and -q are the same rotation
+            got[f"xquat{e}"], want[f"xquat{e}"] = sgn * kin["xquat"][b], z["xquat"][i, e]
+        for s_, nm in enumerate(z["ft_sites"]):
+            site = m.site(str(nm))
+            R = kin["xmat"][site["body"]] @ rb.quat2mat(np.array(site["quat"]))
+            got[f"site{s_}"], want[f"site{s_}"] = R.reshape(9), z["site_xmat"][i, s_]
+        for k in got:
+            err = np.abs(got[k] - want[k]).max() / max(np.abs(want[k]).max(), 1e-12)
+            worst[k] = max(worst.get(k, 0.0), err)
+    print("oracle/rigid_body.py vs mujoco", str(z["mujoco_version"]), {k: f"{v:.1e}" for k, v in worst.items()})
+    # kinematics and Jacobians are exact formulas; M and bias carry MuJoCo's own mesh-inertia rule for the two base links
+    for k, v in worst.items():
+        assert v <= (1e-9 if k.startswith(("jac", "xpos", "xquat", "site")) else 1e-6), (k, v)
