@@ -102,7 +102,9 @@ constexpr int FE_TRAIN = 8;
 // Entry indices of the COMPACT EXCHANGE BUFFER the lane-per-robot walk leaves for the fp64 OSC kernel (osc_row16.hpp,
 // FROMQ): per walk wave a block [entry][64 robots] of doubles holding only the structural non-zeros -- M[i][j] for i at
 // or above j, the Jacobian columns and the pose of the end-effector bodies, the bias forces -- plus one entry of zeros that
-// every structural zero points at.  Built on the host from the compiled tree shape (tu_frontend_lane_f64.hip).
+// every structural zero points at -- and IRLOSC_MAX_K entries the walk leaves alone: the rows of the gained task-space error,
+// written by the task pass between the walk and the OSC kernel (osc_row16.hpp: osc_task_rows_fromq_kernel).  Built on the host
+// from the compiled tree shape (tu_frontend_lane_f64.hip).
 struct FeCompactTables {
     // BYTE offsets of the entries inside a walk wave's block (entry index x 512), 16-byte aligned arrays: the OSC kernel
     // copies them into LDS with a handful of 16-byte loads per lane
@@ -111,7 +113,19 @@ struct FeCompactTables {
     uint16_t eetab[IRLOSC_MAX_DEV][8];                 // entry indices: [device d][0..6] = x y z qw qx qy qz of its end effector
     uint16_t btab[32];                                 // [joint i]: bias force
     uint16_t zero, n_entries;
+    // The same tables for the LDS TILE of the OSC kernel (osc_row16.hpp, FROMQ): a workgroup of four waves stages the entries of
+    // its 16 robots as tile[entry][17] doubles (16 robots + one pad: conflict-free), and these are BYTE offsets of the entry's
+    // row in that tile, entry x FE_TILE_ROW_BYTES (< 65 536).  One block of 16-byte aligned uint16, copied to LDS in one go.
+    alignas(16) uint16_t t_m[32 * 32];                 // [column j * 32 + row i]
+    uint16_t t_j[IRLOSC_MAX_K * 32];                   // [task row r * 32 + joint i]
+    uint16_t t_ee[IRLOSC_MAX_DEV * 8];                 // [device d * 8 + component]
+    uint16_t t_b[32];                                  // [joint i]
+    uint16_t t_e[IRLOSC_MAX_K];                        // [task row r]: the gained task error the task pass leaves (rows >= k: zeros)
+    uint16_t e0;                                       // entry index of task row 0 (rows follow each other)
 };
+constexpr int FE_TILE_ROW = 17;                        // doubles per entry row of the tile
+constexpr int FE_TILE_ROW_BYTES = FE_TILE_ROW * 8;
+constexpr int FE_TILE_TAB_WORDS = 32 * 32 + IRLOSC_MAX_K * 32 + IRLOSC_MAX_DEV * 8 + 32 + IRLOSC_MAX_K;      // uint16 words of t_m .. t_e
 
 // Parameters of one launch of the compact lane kernel (osc_frontend_lane.hpp): step i reads (qpos[i], qvel[i]) of B robots and
 // fills the exchange buffer side[i].

@@ -438,6 +438,45 @@ __device__ __forceinline__ void apply_gains6_fast(const double* __restrict__ g, 
     }
 }
 
+// Orientation part of calc_error (osc.py:113-117): the entries of R = quat2mat(qconjugate(qmult(normalized(q_tgt), qconjugate(q_ee))))
+// that mat2euler('sxyz') reads, with cy and the gimbal-lock verdict -- same formulas as task_error6 (osc_common.hpp), divisions and
+// square roots on the refined hardware seeds.  The three angles are atan2(ay, ax) of TaskRot::angle_args.
+struct TaskRot {
+    double r00, r10, r20, r21, r22, r11, r12, cy;
+    bool gimbal;
+    __device__ __forceinline__ void angle_args(const int a, double& ay, double& ax) const {
+        ay = 0.0; ax = 1.0;                        // atan2(0, 1) = 0: an idle lane, and az at gimbal lock
+        if (a == 0) { ay = gimbal ? -r12 : r21; ax = gimbal ? r11 : r22; }
+        else if (a == 1) { ay = -r20; ax = cy; }
+        else if (a == 2 && !gimbal) { ay = r10; ax = r00; }
+    }
+};
+__device__ __forceinline__ TaskRot task_rot(const double (&ee)[7], const double (&tg)[7]) {
+    const double tw = tg[3], tx = tg[4], ty = tg[5], tz = tg[6];
+    const double rnrm = rsq_refined(tw * tw + tx * tx + ty * ty + tz * tz);
+    const double w1 = tw * rnrm, x1 = tx * rnrm, y1 = ty * rnrm, z1 = tz * rnrm;
+    const double w2 = ee[3], x2 = -ee[4], y2 = -ee[5], z2 = -ee[6];
+    const double rw = w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2;
+    const double rx = w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2;
+    const double ry = w1 * y2 + y1 * w2 + z1 * x2 - x1 * z2;
+    const double rz = w1 * z2 + z1 * w2 + x1 * y2 - y1 * x2;
+    const double w = rw, xq = -rx, yq = -ry, zq = -rz;
+    const double Nq = w * w + xq * xq + yq * yq + zq * zq;
+    TaskRot R{1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 0.0, false};
+    if (!(Nq < 2.220446049250313e-16)) {
+        const double s = 2.0 * rcp_refined(Nq);
+        const double X = xq * s, Y = yq * s, Z = zq * s;
+        const double wX = w * X, wY = w * Y, wZ = w * Z;
+        const double xX = xq * X, xY = xq * Y, xZ = xq * Z;
+        const double yY = yq * Y, yZ = yq * Z, zZ = zq * Z;
+        R.r00 = 1.0 - (yY + zZ); R.r10 = xY + wZ; R.r20 = xZ - wY; R.r21 = yZ + wX;
+        R.r22 = 1.0 - (xX + yY); R.r11 = 1.0 - (xX + zZ); R.r12 = yZ - wX;
+    }
+    R.cy = sqrt_fast(R.r00 * R.r00 + R.r10 * R.r10);
+    R.gimbal = !(R.cy > 4.0 * 2.220446049250313e-16);
+    return R;
+}
+
 // Compile-time shape queries for the tree-structured factorisation (hinge numbering = MuJoCo's depth-first order)
 template <class TOPO>
 constexpr int tree_subtree_size(int j) {
@@ -551,7 +590,8 @@ struct Row16Extra {
     const FeCompactTables* tables;
     int32_t xcd_map;           // 1: the XCD-aware block -> robots map of the FROMQ kernel (0: identity, A/B measurements)
     // irlosc_time_trains: {min over waves of the start, max over waves of the end} of the 100 MHz wall clock (s_memrealtime),
-    // one pair per TRAIN (every step of a train points at the same pair); nullptr = no stamps
+    // R16_SPAN_SLOTS pairs per TRAIN (every step of a train points at the same block; a wave uses pair blockIdx.x % slots: 131 072
+    // waves hammering ONE address serialise in the L2 -- measured: a train took 3.07 ms instead of 0.85); nullptr = no stamps
     unsigned long long* span;
 };
 
@@ -560,6 +600,7 @@ struct Row16Extra {
 // launch gap, the ramp-up and the tail between them (a step's last waves - those with eigen-stage instances - finish
 // while the next step's first waves already run).  A train of one step is the plain single-step launch.
 constexpr int R16_TRAIN = 8;
+constexpr int R16_SPAN_SLOTS = 256;      // stamp pairs per train (irlosc_time_trains), a power of two
 template <typename TIN>
 struct Row16Train {
     KParams<TIN> p[R16_TRAIN];
@@ -613,72 +654,82 @@ __device__ __forceinline__ void tree_chains(double& m0, double& m1, double& tj, 
 }
 
 template <int K, int NDEV, typename TIN, int N, bool FROMQ = false, class TOPO = void>
-__global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const Row16Train<TIN> tr) {
+__global__ __launch_bounds__(FROMQ ? 256 : 64, IRLOSC_R16_WAVES) void osc_row16_kernel(const Row16Train<TIN> tr) {
     using namespace r16;
     constexpr bool TREE = !std::is_void_v<TOPO>;      // the records carry the zero pattern of this tree (fused path: by
                                                       // construction; dense records: verified when they were uploaded)
+    static_assert(!FROMQ || TREE, "the fused path exists for a compiled tree shape");
+    // Dense records: one wave per block (4 instances).  FROMQ: FOUR waves per block = 16 robots = one 128-byte line of every
+    // entry of the walk's exchange block [entry][64 robots]; the block stages those lines in LDS once (r16 tile, below).
+    constexpr int NW = FROMQ ? 4 : 1;
     const KParams<TIN>& p = tr.p[blockIdx.y];
     const Row16Extra& x = tr.x[blockIdx.y];
     using TM = std::conditional_t<FROMQ, double, TIN>;      // type the M / J / dq / bias operands arrive in
     static_assert(N > 16 && N <= 32 && K >= 1 && K <= 16 && NDEV >= 1 && NDEV <= 4, "shape");
     constexpr int N1 = N - 16;                 // real rows in slot 1
     constexpr int PF = IRLOSC_R16_PF;          // rows of M in flight ahead of the column being eliminated
-    __shared__ double Jl[4 * (K + 1) * N + 16];   // [q][r][i]; row K of each instance is zeros (lanes >= K read it)
-    __shared__ double Wl[4][16];               // task vector, written by the device lanes
-    __shared__ double Dxl[4][16];              // dx for the target-velocity branch
-    __shared__ double Kvl[4][4];
-    __shared__ int Brl[4][4];
-
-    __shared__ __align__(16) uint32_t Mt[FROMQ ? N * 32 : 4];      // FROMQ: byte offset of the entry of M[j][i] at [j * 32 + i],
-    __shared__ __align__(16) uint32_t Jt[FROMQ ? K * 32 : 4];      // of J[r][i] at [r * 32 + i]
-    const int lane = threadIdx.x, q = lane >> 4, l = lane & 15;
-    int blk = blockIdx.x;
-    if constexpr (FROMQ) {      // block x + 8 (s + 16 t) -> walk wave 8 t + x, robots 4 s .. 4 s + 3 of it
-        if (x.xcd_map) {
-            const int r = blk & 127;
-            blk = ((blk >> 7) * 8 + (r & 7)) * 16 + (r >> 3);
-        }
-    }
-    const int b = blk * 4 + q;
+    __shared__ double Jl[FROMQ ? 2 : 4 * (K + 1) * N + 16];   // dense records: [q][r][i]; row K of each instance is zeros (lanes >= K read it)
+    __shared__ double Wl_[NW][4][16];          // task vector, written by the device lanes
+    __shared__ double Dxl_[NW][4][16];         // dx for the target-velocity branch
+    __shared__ double Kvl_[NW][4][4];
+    __shared__ int Brl_[NW][4][4];
+    // FROMQ: the block's tile of the exchange buffer, tile[entry][16 robots + 1 pad] (43 KB: three blocks = twelve waves per
+    // CU), and the entry tables as byte offsets into it (FeCompactTables::t_m .. t_b, one contiguous block of uint16)
+    constexpr int TILE_E = [] { if constexpr (FROMQ) return FeTopo<TOPO>::task_index(0) + K; else return 1; }();     // rows staged
+    constexpr int BLK_E = [] { if constexpr (FROMQ) return FeTopo<TOPO>::n_compact(); else return 1; }();            // rows of a walk block
+    __shared__ double Tile[FROMQ ? TILE_E * FE_TILE_ROW : 2];
+    __shared__ __align__(16) uint16_t Tab[FROMQ ? FE_TILE_TAB_WORDS : 8];
+    const uint16_t* const Tm = Tab;                                 // [j * 32 + i]: M[i][j]
+    const uint16_t* const Tj = Tab + 32 * 32;                       // [r * 32 + i]: J[r][i]
+    const uint16_t* const Tee = Tab + 32 * 32 + IRLOSC_MAX_K * 32;  // [d * 8 + c]
+    const uint16_t* const Tb = Tee + IRLOSC_MAX_DEV * 8;            // [i]
+    const uint16_t* const Te = Tb + 32;                             // [r]: gained task error, row r
+    const int wv = FROMQ ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;      // wave of the block (scalar)
+    const int lane = threadIdx.x & 63, q = lane >> 4, l = lane & 15;
+    double (&Wl)[4][16] = Wl_[wv];
+    double (&Dxl)[4][16] = Dxl_[wv];
+    double (&Kvl)[4][4] = Kvl_[wv];
+    int (&Brl)[4][4] = Brl_[wv];
+    const int blk = blockIdx.x;
+    const int b = blk * (4 * NW) + (int)(threadIdx.x >> 4);
     const bool live = b < p.B;
     const int bc = live ? b : p.B - 1;
     const bool v1 = l < N1;
     const TIN* __restrict__ zeros = reinterpret_cast<const TIN*>(x.zeros);
     const TIN* __restrict__ m0p = FROMQ ? zeros : p.M + (size_t)bc * (N * N) + l;
     const TIN* __restrict__ m1p = (!FROMQ && v1) ? p.M + (size_t)bc * (N * N) + 16 + l : zeros;
-    // FROMQ: the four robots of a block sit in ONE walk wave's exchange block (uniform base, scalar registers); a robot's
-    // column is (b % 64) * 8 bytes into an entry and entry e starts e * 512 bytes into the block: 32-bit lane offsets
-    const char* sbase = nullptr;
-    unsigned lane_off = 0;
+    // FROMQ: the 16 robots of a block sit in ONE walk wave's exchange block (block x -> walk wave x / 4, robots 16 (x % 4) ..):
+    // all four waves pull the block's 128-byte lines -- entry e, 16 robots -- into the tile, every line exactly once, perfectly
+    // coalesced (a wave load = 4 whole lines); the main loop then gathers out of LDS.  (Round 3 gathered from L2 in the main
+    // loop: a row of M was 16 different lines of which 32 bytes each were used, 1 165 us per train against 968 for dense records.)
+    const unsigned rob8 = (threadIdx.x >> 4) * 8u;                  // this lane's robot: byte offset inside a tile row
+    auto tile_at = [&](const unsigned row_off) -> double {          // row_off = entry x FE_TILE_ROW_BYTES (from the tables)
+        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(Tile) + (row_off + rob8));
+    };
     if constexpr (FROMQ) {
-        // the entry tables into LDS: all 16-byte loads of the wave issued before the first one is waited for (copied word
-        // by word in a loop, every round trip to L2 was paid in turn: 8 us of a wave's 22 us of residency)
         const FeCompactTables* __restrict__ tb = x.tables;
-        constexpr int MQ = N * 8, JQ = K * 8;                    // 16-byte pieces of the two tables
-        const uint4* __restrict__ msrc = reinterpret_cast<const uint4*>(tb->mt_off);
-        const uint4* __restrict__ jsrc = reinterpret_cast<const uint4*>(tb->jt_off);
-        uint4 mv[(MQ + 63) / 64], jv[(JQ + 63) / 64];
+        const double* __restrict__ src = x.side + ((size_t)(blk >> 2) * BLK_E) * 64 + (blk & 3) * 16;
+        constexpr int NT = (TILE_E * 16 + 255) / 256;               // 8-byte pieces per thread
+        constexpr int TQ = (FE_TILE_TAB_WORDS * 2 + 15) / 16;       // 16-byte pieces of the tables (<= 256)
+        static_assert(TQ <= 256, "one table piece per thread");
+        double tv[NT];
+        const int tid = threadIdx.x;
+        const uint4 tq = reinterpret_cast<const uint4*>(tb->t_m)[min(tid, TQ - 1)];
 #pragma unroll
-        for (int i = 0; i < (MQ + 63) / 64; ++i) mv[i] = msrc[min(lane + 64 * i, MQ - 1)];
+        for (int i = 0; i < NT; ++i) {                               // all loads in flight before the first is waited for
+            const int idx = min(tid + 256 * i, TILE_E * 16 - 1);
+            tv[i] = src[(idx >> 4) * 64 + (idx & 15)];
+        }
+        if (tid < TQ) reinterpret_cast<uint4*>(Tab)[tid] = tq;
 #pragma unroll
-        for (int i = 0; i < (JQ + 63) / 64; ++i) jv[i] = jsrc[min(lane + 64 * i, JQ - 1)];
-#pragma unroll
-        for (int i = 0; i < (MQ + 63) / 64; ++i) if (lane + 64 * i < MQ) reinterpret_cast<uint4*>(Mt)[lane + 64 * i] = mv[i];
-#pragma unroll
-        for (int i = 0; i < (JQ + 63) / 64; ++i) if (lane + 64 * i < JQ) reinterpret_cast<uint4*>(Jt)[lane + 64 * i] = jv[i];
-        const int wv = __builtin_amdgcn_readfirstlane(bc >> 6);
-        sbase = reinterpret_cast<const char*>(x.side + (size_t)wv * tb->n_entries * 64);
-        lane_off = (unsigned)(bc & 63) * 8u;
+        for (int i = 0; i < NT; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < TILE_E * 16) Tile[(idx >> 4) * FE_TILE_ROW + (idx & 15)] = tv[i];
+        }
+        __syncthreads();
     }
-    auto side_at = [&](const unsigned byte_off) -> double { return *reinterpret_cast<const double*>(sbase + (byte_off + lane_off)); };
-    auto side_ld = [&](const unsigned entry) -> double { return side_at(entry << 9); };
-    // (Two thirds of M's and J's entries are structural zeros, all naming the one entry of zeros.  Masking those lanes out of
-    // the loads was tried: 1 586 instead of 1 476 us per train of 8 -- the exec-mask bookkeeping costs more issue slots than
-    // the lines it saves; the loads stay unconditional.)
-    unsigned zb = 0;
-    if constexpr (FROMQ) zb = x.tables->zero;
 
-    double* Jq = Jl + q * ((K + 1) * N);
+    double* Jq = Jl + (FROMQ ? 0 : q * ((K + 1) * N));      // (dense records only)
     uint32_t flags = 0;
     // IRLOSC_PHASE_TIMING=1 debug runs: cycle stamps per phase and the wall clock of the wave (p.dbg != nullptr)
     unsigned long long ts[8];
@@ -698,18 +749,17 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
     {
         const TIN* __restrict__ tgp = p.tgt + ((size_t)bc * NDEV + dd) * 7;
         const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * NDEV * IRLOSC_GAIN_WORDS : 0) + dd * IRLOSC_GAIN_WORDS;
-        if constexpr (FROMQ) {
-#pragma unroll
-            for (int i = 0; i < 7; ++i) ee_in[i] = side_ld(x.tables->eetab[dd][i]);
+        if constexpr (FROMQ) {      // part 1 of the task signal was computed by the task pass: only the velocity gain is needed here
+            g_in[1] = gp[1];
         } else {
             const TIN* __restrict__ eep = p.ee + ((size_t)bc * NDEV + dd) * 7;
 #pragma unroll
             for (int i = 0; i < 7; ++i) ee_in[i] = eep[i];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) tg_in[i] = tgp[i];
+#pragma unroll
+            for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) g_in[i] = gp[i];
         }
-#pragma unroll
-        for (int i = 0; i < 7; ++i) tg_in[i] = tgp[i];
-#pragma unroll
-        for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) g_in[i] = gp[i];
         const TIN* __restrict__ tvp = has_tv ? p.tvel + ((size_t)bc * NDEV + dd) * 6 : zeros;      // all six together: as a
 #pragma unroll                                                                                      // short-circuit chain each
         for (int i = 0; i < 6; ++i) tv_in[i] = tvp[i];                                              // waited for the one before
@@ -720,19 +770,17 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
     TM jl0[K], jl1[K];
     TM dq0_in, dq1_in;
     const bool use_g = (p.cfgflags & IRLOSC_USE_G) != 0;
-    unsigned mo0 = 0, mo1 = 0;      // FROMQ: entries of the next row of M to be requested (table reads run one column ahead)
+    unsigned mo0 = 0, mo1 = 0;      // FROMQ: tile rows of the next row of M to be read (the table reads run one column ahead)
+    constexpr int PFQ = 2;          // FROMQ: rows of M in flight ahead of the column being eliminated (LDS latency, not HBM's)
     if constexpr (FROMQ) {
-        lds_sync();                 // the entry tables are in LDS
-        static_for<0, PF>([&](auto jc) {      // TREE: the recursion runs from the last column down
-            constexpr int j = TREE ? N - 1 - decltype(jc)::value : decltype(jc)::value;
-            pm0[j] = side_at(Mt[j * 32 + l]);
-            if constexpr (!tree_row_slot1_zero<TOPO>(j)) pm1[j] = side_at(Mt[j * 32 + 16 + l]);
+        static_for<0, PFQ>([&](auto jc) {      // the recursion runs from the last column down
+            constexpr int j = N - 1 - decltype(jc)::value;
+            pm0[j] = tile_at(Tm[j * 32 + l]);
+            if constexpr (!tree_row_slot1_zero<TOPO>(j)) pm1[j] = tile_at(Tm[j * 32 + 16 + l]);
         });
-        constexpr int jn = TREE ? N - 1 - PF : PF;
-        mo0 = Mt[jn * 32 + l];
-        if constexpr (!tree_row_slot1_zero<TOPO>(jn)) mo1 = Mt[jn * 32 + 16 + l];
-#pragma unroll
-        for (int r = 0; r < K; ++r) { jl0[r] = side_at(Jt[r * 32 + l]); jl1[r] = side_at(Jt[r * 32 + 16 + l]); }
+        constexpr int jn = N - 1 - PFQ;
+        mo0 = Tm[jn * 32 + l];
+        if constexpr (!tree_row_slot1_zero<TOPO>(jn)) mo1 = Tm[jn * 32 + 16 + l];
         dq0_in = x.qvel[(size_t)bc * N + l];
         dq1_in = v1 ? x.qvel[(size_t)bc * N + 16 + l] : 0.0;
     } else {
@@ -762,13 +810,7 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
     // id -- are fetched / recomputed WHERE they are used (cached lines, a handful of instructions) instead of riding through
     // the whole kernel in vector registers: `late()` makes the lane id opaque so that the compiler cannot share the early copy.
     auto late_lane = [&]() { int t2 = threadIdx.x; asm volatile("" : "+v"(t2)); return t2; };
-    auto late_bc = [&](const int lane2) {
-        int blk2 = blockIdx.x;
-        if constexpr (FROMQ) {
-            if (x.xcd_map) { const int r = blk2 & 127; blk2 = ((blk2 >> 7) * 8 + (r & 7)) * 16 + (r >> 3); }
-        }
-        return blk2 * 4 + (lane2 >> 4);
-    };
+    auto late_bc = [&](const int tid2) { return (int)blockIdx.x * (4 * NW) + (tid2 >> 4); };
     auto load_kvn = [&]() -> double {
         if (!(p.cfgflags & IRLOSC_NULLSPACE)) return 0.0;
         const int b2 = late_bc(late_lane());
@@ -777,7 +819,25 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
     const bool has_wr = (p.cfgflags & IRLOSC_ADMITTANCE) && p.wrench != nullptr;
     const DevMeta dm = p.dev[dd];
     bool own_brB = false;
-    {
+    if constexpr (FROMQ) {
+        // Part 1 arrives as k rows of the tile (osc_task_rows_fromq_kernel, one lane per robot, ran between the walk and this
+        // kernel): lane l takes row l (rows >= k: the entry of zeros); the device lanes only leave the velocity gain and the
+        // damping-branch verdict of their device (osc.py:173).  405 of the ~2 650 VALU instructions of a wave went into sixteen
+        // lanes per robot each running the pipeline for one Euler angle; with the operands in LDS this kernel is issue-bound.
+        bool all_nonzero = has_tv;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) all_nonzero = all_nonzero & ((double)tv_in[i] != 0.0);
+        own_brB = all_nonzero && dv < NDEV;          // np.all(target_vel) == 0 quirk, osc.py:173
+        Wl[q][l] = tile_at(Te[l]);
+        if (ang_id == 0 && dv < NDEV) {
+            Kvl[q][dv] = (double)g_in[1];
+            Brl[q][dv] = all_nonzero ? 0 : 1;
+        }
+        if (own_brB) {
+            flags |= IRLOSC_FLAG_VEL_BRANCH_B;
+            if (dm.jidx0 + dm.rows > K) flags |= IRLOSC_FLAG_BAD_JIDX;
+        }
+    } else {
         const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * NDEV * IRLOSC_GAIN_WORDS : 0) + dd * IRLOSC_GAIN_WORDS;
         double ee[7], tg[7], g[IRLOSC_GAIN_WORDS];
 #pragma unroll
@@ -787,33 +847,10 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
         double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if (dm.calc & 1u) { e[0] = ee[0] - tg[0]; e[1] = ee[1] - tg[1]; e[2] = ee[2] - tg[2]; }
         if (dm.calc & 2u) {
-            // transforms3d calls of osc.py:115-117, same formulas as task_error6 (osc_common.hpp)
-            const double tw = tg[3], tx = tg[4], ty = tg[5], tz = tg[6];
-            const double rnrm = rsq_refined(tw * tw + tx * tx + ty * ty + tz * tz);
-            const double w1 = tw * rnrm, x1 = tx * rnrm, y1 = ty * rnrm, z1 = tz * rnrm;
-            const double w2 = ee[3], x2 = -ee[4], y2 = -ee[5], z2 = -ee[6];
-            const double rw = w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2;
-            const double rx = w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2;
-            const double ry = w1 * y2 + y1 * w2 + z1 * x2 - x1 * z2;
-            const double rz = w1 * z2 + z1 * w2 + x1 * y2 - y1 * x2;
-            const double w = rw, xq = -rx, yq = -ry, zq = -rz;
-            const double Nq = w * w + xq * xq + yq * yq + zq * zq;
-            double r00 = 1.0, r10 = 0.0, r20 = 0.0, r21 = 0.0, r22 = 1.0, r11 = 1.0, r12 = 0.0;
-            if (!(Nq < 2.220446049250313e-16)) {
-                const double s = 2.0 * rcp_refined(Nq);
-                const double X = xq * s, Y = yq * s, Z = zq * s;
-                const double wX = w * X, wY = w * Y, wZ = w * Z;
-                const double xX = xq * X, xY = xq * Y, xZ = xq * Z;
-                const double yY = yq * Y, yZ = yq * Z, zZ = zq * Z;
-                r00 = 1.0 - (yY + zZ); r10 = xY + wZ; r20 = xZ - wY; r21 = yZ + wX;
-                r22 = 1.0 - (xX + yY); r11 = 1.0 - (xX + zZ); r12 = yZ - wX;
-            }
-            const double cy = sqrt_fast(r00 * r00 + r10 * r10);
-            const bool gimbal = !(cy > 4.0 * 2.220446049250313e-16);
-            double ay = 0.0, ax = 1.0;             // atan2(0, 1) = 0: the idle lane and the gimbal-lock az
-            if (ang_id == 0) { ay = gimbal ? -r12 : r21; ax = gimbal ? r11 : r22; }
-            else if (ang_id == 1) { ay = -r20; ax = cy; }
-            else if (ang_id == 2 && !gimbal) { ay = r10; ax = r00; }
+            // transforms3d calls of osc.py:115-117
+            const TaskRot R = task_rot(ee, tg);
+            double ay, ax;
+            R.angle_args(ang_id, ay, ax);
             const double ang = atan2(ay, ax);
             e[3] = quad_bcast(ang, 0);
             e[4] = quad_bcast(ang, 1);
@@ -838,14 +875,16 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
         }
     }
     IRLOSC_TS(1);
-    // J into LDS (its loads have been in flight since the top of the kernel)
+    // J into LDS (its loads have been in flight since the top of the kernel); FROMQ: J already sits in the tile
+    if constexpr (!FROMQ) {
 #pragma unroll
-    for (int r = 0; r < K; ++r) Jq[r * N + l] = (double)jl0[r];
-    Jq[K * N + l] = 0.0;
-    if (v1) {
+        for (int r = 0; r < K; ++r) Jq[r * N + l] = (double)jl0[r];
+        Jq[K * N + l] = 0.0;
+        if (v1) {
 #pragma unroll
-        for (int r = 0; r < K; ++r) Jq[r * N + 16 + l] = (double)jl1[r];
-        Jq[K * N + 16 + l] = 0.0;
+            for (int r = 0; r < K; ++r) Jq[r * N + 16 + l] = (double)jl1[r];
+            Jq[K * N + 16 + l] = 0.0;
+        }
     }
     const double dq0 = (double)dq0_in, dq1 = (double)dq1_in;
     lds_sync();
@@ -857,12 +896,17 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
     double mdq0 = 0.0, mdq1 = 0.0, dx = 0.0;
     unsigned long long npd_mask = 0;      // lanes that saw a non-positive pivot of M (scalar registers: see pinned_ballot)
     const double* trow = Jq + (l < K ? l : K) * N;
+    // column j of J in the right-hand-side layout: J[r][j] for lane r (rows K .. 15 of the tile table name the entry of zeros)
+    auto jcol = [&](const int j) -> double {
+        if constexpr (FROMQ) return tile_at(Tj[l * 32 + j]);
+        else return trow[j];
+    };
     if constexpr (TREE) {
         // M = L^T L, columns N - 1 .. 0; R0[c] = L[c][l], R1[c] = L[c][16 + l] (the lane's two COLUMNS of L)
         using TI = FeTopo<TOPO>;
         static_assert(TOPO::NJ == N, "tree shape and kernel shape");
         double R0[N], R1[N];
-        double tnext = trow[N - 1];
+        double tnext = jcol(N - 1);
         static_for_down<0, N>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int sj = j >> 4, gj = j & 15;
@@ -871,12 +915,12 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
             constexpr bool EEJ = tree_moves_ee<TOPO>(j);            // otherwise column j of J and row j of Y are zero
             constexpr bool S1Z = tree_slot1_zero<TOPO>(j);          // no slot-1 half: m1 = 0, nothing loaded for it
             if constexpr (FROMQ) {
-                if constexpr (j - PF >= 0) {
-                    pm0[j - PF] = side_at(mo0);
-                    if constexpr (!tree_slot1_zero<TOPO>(j - PF)) pm1[j - PF] = side_at(mo1);
-                    if constexpr (j - PF - 1 >= 0) {
-                        mo0 = Mt[(j - PF - 1) * 32 + l];
-                        if constexpr (!tree_slot1_zero<TOPO>(j - PF - 1)) mo1 = Mt[(j - PF - 1) * 32 + 16 + l];
+                if constexpr (j - PFQ >= 0) {
+                    pm0[j - PFQ] = tile_at(mo0);
+                    if constexpr (!tree_slot1_zero<TOPO>(j - PFQ)) pm1[j - PFQ] = tile_at(mo1);
+                    if constexpr (j - PFQ - 1 >= 0) {
+                        mo0 = Tm[(j - PFQ - 1) * 32 + l];
+                        if constexpr (!tree_slot1_zero<TOPO>(j - PFQ - 1)) mo1 = Tm[(j - PFQ - 1) * 32 + 16 + l];
                     }
                 }
             }
@@ -891,7 +935,7 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
                 });
             }
             double tj = EEJ ? tnext : 0.0;
-            if constexpr (j > 0) { if constexpr (tree_moves_ee<TOPO>(j - 1)) tnext = trow[j - 1]; }
+            if constexpr (j > 0) { if constexpr (tree_moves_ee<TOPO>(j - 1)) tnext = jcol(j - 1); }
             const double dqs = sj ? dq1 : dq0;
             __builtin_amdgcn_sched_barrier(0);
             fmac_bc_nop<gj>(mdq0, dqs, m0);
@@ -913,14 +957,7 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
     static_for<0, N>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int sj = j >> 4, gj = j & 15;
-        if constexpr (j + PF < N) {
-            if constexpr (FROMQ) {
-                pm0[j + PF] = side_at(mo0); pm1[j + PF] = side_at(mo1);
-                if constexpr (j + PF + 1 < N) { mo0 = Mt[(j + PF + 1) * 32 + l]; mo1 = Mt[(j + PF + 1) * 32 + 16 + l]; }
-            } else {
-                pm0[j + PF] = m0p[(j + PF) * N]; pm1[j + PF] = m1p[(j + PF) * N];
-            }
-        }
+        if constexpr (j + PF < N) { pm0[j + PF] = m0p[(j + PF) * N]; pm1[j + PF] = m1p[(j + PF) * N]; }
         double m0 = (double)pm0[j], m1 = (double)pm1[j];
         double tj = tnext;
         if constexpr (j + 1 < N) tnext = trow[j + 1];
@@ -1066,21 +1103,30 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
     const bool live2 = b2 < p.B;
     const int bc2 = live2 ? b2 : p.B - 1;
     TM bias0_in, bias1_in;                 // requested here, consumed behind the J^T t products
+    // (FROMQ: the tile addresses of this phase are rebuilt from the late copy of the thread id, like everything else down here)
+    const unsigned rob2 = (unsigned)(lane2 >> 4) * 8u;
+    auto tile2 = [&](const unsigned row_off) -> double {
+        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(Tile) + (row_off + rob2));
+    };
     if constexpr (FROMQ) {
-        const unsigned lo2 = (unsigned)(bc2 & 63) * 8u;
-        bias0_in = *reinterpret_cast<const double*>(sbase + (((unsigned)(use_g ? x.tables->btab[l2] : zb) << 9) + lo2));
-        bias1_in = *reinterpret_cast<const double*>(sbase + (((unsigned)(use_g ? x.tables->btab[16 + l2] : zb) << 9) + lo2));
+        bias0_in = use_g ? tile2(Tb[l2]) : 0.0;
+        bias1_in = use_g ? tile2(Tb[16 + l2]) : 0.0;      // joints >= N: the entry of zeros
     } else {
         bias0_in = (use_g ? p.bias + (size_t)bc2 * N + l2 : zeros)[0];
         bias1_in = (use_g && l2 < N1 ? p.bias + (size_t)bc2 * N + 16 + l2 : zeros)[0];
     }
     const double kvn = load_kvn();
-    mdq0 = Dxl[lane2 >> 4][l2];
-    mdq1 = Wl[lane2 >> 4][l2];
+    // (the LDS rows of this wave, addressed from the late thread id: the early base addresses would ride through the eigen stage)
+    const int wv2 = FROMQ ? (lane2 >> 6) : 0, q2 = (lane2 >> 4) & 3;
+    mdq0 = Dxl_[wv2][q2][l2];
+    mdq1 = Wl_[wv2][q2][l2];
     {
         double jr0[K], jr1[K];
 #pragma unroll
-        for (int r = 0; r < K; ++r) { jr0[r] = Jq[r * N + l]; jr1[r] = Jq[r * N + 16 + l]; }   // padding lanes: junk, never stored
+        for (int r = 0; r < K; ++r) {
+            if constexpr (FROMQ) { jr0[r] = tile2(Tj[r * 32 + l2]); jr1[r] = tile2(Tj[r * 32 + 16 + l2]); }      // joints >= N: zeros
+            else { jr0[r] = Jq[r * N + l]; jr1[r] = Jq[r * N + 16 + l]; }   // padding lanes: junk, never stored
+        }
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, K>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
@@ -1092,8 +1138,8 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
     double u0 = 0.0, u1 = 0.0;
 #pragma unroll
     for (int d2 = 0; d2 < NDEV; ++d2) {       // branch A damping, osc.py:174 (assignment, device order)
-        const bool brA = Brl[q][d2] != 0;
-        const double kvd = Kvl[q][d2];
+        const bool brA = Brl_[wv2][q2][d2] != 0;
+        const double kvd = Kvl_[wv2][q2][d2];
         const uint32_t jm = p.dev[d2].joint_mask;
         if (brA && ((jm >> l) & 1u)) u0 = -kvd * mdq0;
         if (brA && ((jm >> ((16 + l) & 31)) & 1u)) u1 = -kvd * mdq1;
@@ -1122,14 +1168,16 @@ __global__ __launch_bounds__(64, IRLOSC_R16_WAVES) void osc_row16_kernel(const R
     }
     IRLOSC_TS(7);
     if (x.span && lane == 0) {       // first wave's start / last wave's end of the train, untraced (irlosc_time_trains)
-        atomicMin(x.span, rt0);
-        atomicMax(x.span + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        unsigned long long* sp = x.span + 2 * (blockIdx.x & (R16_SPAN_SLOTS - 1));
+        atomicMin(sp, rt0);
+        atomicMax(sp + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
     if (p.dbg && lane == 0) {
+        const size_t wid = (size_t)blockIdx.x * NW + wv;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) p.dbg[(size_t)blockIdx.x * 10 + i] = ts[i];      // (the last step of a train wins)
-        p.dbg[(size_t)blockIdx.x * 10 + 8] = rt0;
-        p.dbg[(size_t)blockIdx.x * 10 + 9] = __builtin_amdgcn_s_memrealtime();
+        for (int i = 0; i < 8; ++i) p.dbg[wid * 10 + i] = ts[i];      // (the last step of a train wins)
+        p.dbg[wid * 10 + 8] = rt0;
+        p.dbg[wid * 10 + 9] = __builtin_amdgcn_s_memrealtime();
     }
 #undef IRLOSC_TS
 }
@@ -1147,6 +1195,74 @@ __global__ __launch_bounds__(64) void osc_generic_worklist_kernel(const Row16Tra
     // them, whatever the train's length: a shorter train must not inherit what a longer one counted.)
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < R16_TRAIN && reset) reset[threadIdx.x] = 0;
     for (int it = blockIdx.x; it < n; it += gridDim.x) generic_instance<T>(p, list[it], smem);
+}
+
+// FROMQ: part 1 of the task-space signal (calc_error, velocity limit, gains, stiffness: osc.py:101-118,70-99,160-168) as a PASS OF ITS
+// OWN between the walk and the OSC kernel -- ONE LANE PER ROBOT, block x = walk wave x (its 64 robots), blockIdx.y = step.  Reads
+// the end-effector poses the walk parked (coalesced: [entry][64 robots]), the targets and gains, and leaves the k gained error rows
+// as k more entries of the exchange block (FeTopo::task_index), which the OSC kernel's tile picks up like everything else.  Same
+// formulas as the in-kernel form of the dense-record path (task_rot, apply_gains6_fast).  ~1 200 instructions per wave of 64
+// robots against ~400 per wave of FOUR robots in the OSC kernel.
+template <int K, int NDEV, typename TIN, class TOPO>
+__global__ __launch_bounds__(64) void osc_task_rows_fromq_kernel(const Row16Train<TIN> tr) {
+    using namespace r16;
+    const KParams<TIN>& p = tr.p[blockIdx.y];
+    const Row16Extra& x = tr.x[blockIdx.y];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x * 64 + lane;
+    const int bc = b < p.B ? b : p.B - 1;        // idle lanes of a ragged last block: the walk left the last robot's data in their columns
+    const FeCompactTables* __restrict__ tb = x.tables;
+    constexpr int BLK_E = FeTopo<TOPO>::n_compact();      // (through a constexpr VARIABLE: called inside a runtime expression, the
+                                                          // constexpr function is evaluated at run time -- loops over the tree, 2.4 ms)
+    double* __restrict__ col = const_cast<double*>(x.side) + (size_t)blockIdx.x * BLK_E * 64 + lane;
+    // The targets of the block's 64 robots are 64 x NDEV x 7 consecutive words: wave loads, all in flight together, transposed
+    // through LDS (read straight per lane -- 168-byte strides, 64 lines per load instruction -- this pass took 2.07 ms per train
+    // of 8: the texture addresser handles a line per cycle).
+    constexpr int TW = NDEV * 7;                   // odd: conflict-free reads with the robot as the slow index
+    __shared__ double tgs[64 * TW];
+    {
+        const size_t g0 = (size_t)blockIdx.x * 64 * TW, glast = (size_t)p.B * TW - 1;
+        TIN tv[TW];
+#pragma unroll
+        for (int i = 0; i < TW; ++i) { const size_t g = g0 + lane + 64 * i; tv[i] = p.tgt[g < glast ? g : glast]; }
+#pragma unroll
+        for (int i = 0; i < TW; ++i) tgs[lane + 64 * i] = (double)tv[i];
+        lds_sync();
+    }
+    const unsigned e0 = tb->e0;                    // (a value, not `tb->e0` at every store: the stores might alias the table for all the compiler knows)
+    uint16_t eet[NDEV][7];                         // entry indices of the poses: requested together, ahead of the poses
+#pragma unroll
+    for (int d = 0; d < NDEV; ++d)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) eet[d][i] = tb->eetab[d][i];
+    static_for<0, NDEV>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        const DevMeta dm = p.dev[d];
+        const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * NDEV * IRLOSC_GAIN_WORDS : 0) + d * IRLOSC_GAIN_WORDS;
+        double ee[7], tg[7], g[IRLOSC_GAIN_WORDS];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) ee[i] = col[(size_t)eet[d][i] * 64];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) tg[i] = tgs[lane * TW + d * 7 + i];
+#pragma unroll
+        for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) g[i] = (double)gp[i];
+        double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (dm.calc & 1u) { e[0] = ee[0] - tg[0]; e[1] = ee[1] - tg[1]; e[2] = ee[2] - tg[2]; }
+        if (dm.calc & 2u) {
+            const TaskRot R = task_rot(ee, tg);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                double ay, ax;
+                R.angle_args(a, ay, ax);
+                e[3 + a] = atan2(ay, ax);
+            }
+        }
+        apply_gains6_fast(g, e);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            if (dm.dofmask & (1u << i)) { col[(size_t)(e0 + dm.row0 + cnt) * 64] = e[i]; ++cnt; }
+    });
 }
 
 inline bool row16_kernel_supports(int dtype, int n, int k, int ndev) {

@@ -30,18 +30,23 @@ int launch_row16(const Row16Train<TIN>& tr, int nsteps, bool tree, hipStream_t s
 }
 
 // The same train on the fused path: operands from the compact exchange buffers (tr.x[i].side / qvel / tables), the
-// factorisation in the tree-structured form of the compiled Dual-UR5 shape.  The grid
-// covers whole groups of 8 walk waves (128 blocks) so that the XCD-aware block map of the kernel stays a bijection.
+// factorisation in the tree-structured form of the compiled Dual-UR5 shape.  Blocks of FOUR waves (256 threads): block x takes
+// robots 16 (x % 4) .. of walk wave x / 4, i.e. one 128-byte line of every entry of that wave's exchange block.
 template <typename TIN>
 int launch_row16_fromq(const Row16Train<TIN>& tr, int nsteps, hipStream_t st) {
     const KParams<TIN>& p = tr.p[0];
     if (p.B <= 0 || nsteps <= 0) return 0;
     const int waves = (p.B + 63) / 64;
-    const dim3 grid(((waves + 7) / 8) * 128, nsteps);
-    if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25, true, TopoDualUr5>), grid, dim3(64), 0, st, tr);
-    else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<12, 2, TIN, 25, true, TopoDualUr5>), grid, dim3(64), 0, st, tr);
-    else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<7, 3, TIN, 25, true, TopoDualUr5>), grid, dim3(64), 0, st, tr);
-    else if (p.k == 6 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<6, 2, TIN, 25, true, TopoDualUr5>), grid, dim3(64), 0, st, tr);
+    const dim3 grid(waves * 4, nsteps), tgrid(waves, nsteps);      // the task pass first: one lane per robot, block = walk wave
+    if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<13, 3, TIN, TopoDualUr5>), tgrid, dim3(64), 0, st, tr);
+    else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<12, 2, TIN, TopoDualUr5>), tgrid, dim3(64), 0, st, tr);
+    else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<7, 3, TIN, TopoDualUr5>), tgrid, dim3(64), 0, st, tr);
+    else if (p.k == 6 && p.ndev == 2) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<6, 2, TIN, TopoDualUr5>), tgrid, dim3(64), 0, st, tr);
+    else return (int)hipErrorNotSupported;
+    if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25, true, TopoDualUr5>), grid, dim3(256), 0, st, tr);
+    else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<12, 2, TIN, 25, true, TopoDualUr5>), grid, dim3(256), 0, st, tr);
+    else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<7, 3, TIN, 25, true, TopoDualUr5>), grid, dim3(256), 0, st, tr);
+    else if (p.k == 6 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<6, 2, TIN, 25, true, TopoDualUr5>), grid, dim3(256), 0, st, tr);
     else return (int)hipErrorNotSupported;
     return (int)hipGetLastError();
 }

@@ -284,7 +284,9 @@ def test_row16_tree_full_size(cfg, dtype):
     f64 = dtype == np.float64
     u0, fl0 = osc.step(return_flags=True)
     assert not np.any(fl0 & (_lib.FLAG_NONFINITE | _lib.FLAG_M_NOT_PD)) and np.all(np.isfinite(u0))
-    assert 0.05 < (fl0 & _lib.FLAG_EIGEN_PATH != 0).mean() < 0.5 and (fl0 & _lib.FLAG_TRUNCATED != 0).mean() > 0.03
+    k13 = lay.k == 13            # (without the base's yaw row far fewer task spaces degenerate: 2 % instead of 15 % reach the eigen stage)
+    assert (0.05 if k13 else 0.01) < ((fl0 & _lib.FLAG_EIGEN_PATH) != 0).mean() < 0.5
+    assert ((fl0 & _lib.FLAG_TRUNCATED) != 0).mean() > (0.03 if k13 else 0.005)
     up = lambda **kw: osc.upload(*[kw.get(k, rec[k]) for k in ("M", "J", "dq", "bias", "ee_pose")], kw.get("wrench", rec.get("wrench")))
     scale = np.maximum(np.abs(u0).max(axis=1, keepdims=True).astype(np.float64), 1.0)
     rnd = 1e-12 if f64 else 3e-7                       # rounding of the sums (float32 records: u is stored as float32)
@@ -334,7 +336,7 @@ def test_row16_tree_full_size(cfg, dtype):
     n_eig = int(((fs & _lib.FLAG_EIGEN_PATH) != 0).sum())
     print(f"{kname}+tree, {B} physical records: oracle on {len(idx)} instances ({n_eig} through the eigen stage, "
           f"{int(trunc.sum())} truncating, {int((~dom).sum())} outside the parity domain): max rel err in the domain {err[dom].max():.2e}")
-    assert len(idx) >= 8192 and dom.mean() > 0.97 and n_eig >= 800 and trunc.sum() >= 400
+    assert len(idx) >= 8192 and dom.mean() > 0.97 and n_eig >= (800 if k13 else 100) and trunc.sum() >= (400 if k13 else 30)
     assert err[dom].max() <= TOL64, float(err[dom].max())
     assert np.array_equal((fs[dom] & _lib.FLAG_PINV_BRANCH) != 0, pinv[dom])
     assert np.array_equal((fs[dom] & _lib.FLAG_TRUNCATED) != 0, trunc[dom])
@@ -1651,7 +1653,7 @@ def test_k6_two_arms_xyz_runs_on_the_row16_kernel():
                                     np.asarray(g["tgt_pose"][:512], dtype=np.float64), None)
     dom = np.array([in_parity_domain(*osc_oracle.task_inertia(r["J"][b], r["M"][b])[2:]) for b in range(512)])
     assert rel_err(u_t, ref)[dom].max() <= TOL64
-    lay, gains, g, model, osc, states = _from_q_setup("k6", 512, np.float64, seed=63)
+    lay, gains, g, model, osc, states = _from_q_setup("k6", 512, np.float64, seed=63, singular_every=7)     # the states of _physical_records
     assert "fused" in osc.from_q_name
     assert rel_err(osc.step_q(), u_fe.astype(np.float64)).max() <= 1e-8
     osc.close()
