@@ -304,7 +304,7 @@ def measure_from_q(BatchedOSC, synth, args, B, local_rank, state0=None, ref_u=No
             osc.frontend(slot=s)
             osc.set_targets(arr["tgt_pose"], arr.get("tgt_vel"), slot=s)
         steps = max(64, min(256, args.steps // 32 * 8))          # whole trains of 8, enough of them for a steady state
-        osc.step_resident_from_q(24)
+        osc.step_resident_from_q(max(24, min(args.preroll, 400)))      # untimed: the clocks settle (as in measure())
         osc.device_sync()
         t0 = time.perf_counter()
         ms_total, ms_step = osc.step_resident_from_q(steps)

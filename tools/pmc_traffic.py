@@ -24,10 +24,12 @@ def trace_avg(db, sub):
     con = sqlite3.connect(db)
     cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
     name_c = "name" if "name" in cols else "kernel_name"
-    d = [(e - s) / 1e3 for s, e in con.execute(f"select start, end from kernels where {name_c} like ?", (f"%{sub}%",))]
+    d = [(e - s) / 1e3 for s, e in con.execute(f"select start, end from kernels where {name_c} like ? order by start", (f"%{sub}%",))]
     med = sorted(d)[len(d) // 2]
     full = [v for v in d if v >= 0.5 * med]           # full trains only (a bench run also issues a few shorter launches; relative
                                                       # to the median: one slow outlier must not define what "full" means)
+    full = full[-128:]                                # in time order, the steady state: the first launches after the idle set-up run at
+                                                      # unsettled clocks (round 3's profiles of a 168-step command averaged mostly those)
     return sum(full) / len(full), len(full)
 
 

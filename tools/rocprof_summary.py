@@ -42,6 +42,13 @@ def main(path):
         for (nm, gx), (n, tot) in sorted(by.items(), key=lambda kv: -kv[1][1]):
             if nm == dom:
                 print(f"#   grid={str(gx):>16s} calls={n:5d} avg_us={tot / n:10.2f}")
+        # in time order: the first launches after the idle set-up run at unsettled clocks (the power management needs ~50 ms of
+        # load), so the steady state is what the LAST dispatches show -- and what a long untraced run measures
+        seq = sorted(((r[ix["start"]], (r[ix["end"]] - r[ix["start"]]) / 1e3) for r in rows if r[ix[name_c]] == dom), key=lambda t: t[0])
+        full = [d for _, d in seq if d >= 0.5 * sorted(d2 for _, d2 in seq)[len(seq) // 2]]
+        for lab, part in (("first 32", full[:32]), ("last 128", full[-128:]), ("last 32", full[-32:])):
+            if part:
+                print(f"#   dominant kernel, full-size launches in time order, {lab:>8s}: n={len(part):4d} avg_us={sum(part) / len(part):10.2f}")
 
 
 if __name__ == "__main__":
