@@ -58,7 +58,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 lanes x 2 flop (FMA) x 2.4 GHz: v_fma_f64 issues at the full VALU rate
-# Useful fp64 flops of one control step from joint coordinates (FMA = 2; DESIGN.md section 5 derives both figures):
+# Useful fp64 flops of one control step from joint coordinates (FMA = 2; profiles/NOTES.md section 4.6 derives both figures):
 FLOPS_OSC_STEP = {"k13": 23.3e3, "k12_admit": 21.6e3, "k7": 14.2e3}    # Cholesky, substitution, J M^-1 J^T, k x k, torques
 FLOPS_FRONT_END = 20.1e3                                                # FK, EE Jacobians, CRBA, RNEA of the Dual-UR5 tree (counted in the ISA)
 MODES = {   # --dtype -> (record dtype, arithmetic label, kernel id)
@@ -75,7 +75,7 @@ def algorithmic_bytes(n, k, ndev, admittance, esz):
 
 def measured_profile(kernel_name):
     """What the committed rocprofv3 passes say about the dominant kernel (profiles/hbm_traffic.json): HBM bytes per launch
-    from the PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE, DESIGN.md section 5) and the kernel trace's average
+    from the PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE, DESIGN.md section 6) and the kernel trace's average
     duration; {} when there is no entry."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
@@ -323,7 +323,7 @@ def measure_from_q(BatchedOSC, synth, args, B, local_rank, state0=None, ref_u=No
                    hbm_traffic_bytes_per_step_per_instance=_fromq_traffic(osc.from_q_name, B),
                    roofline=dict(bound="fp64_valu", achieved=achieved, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
                                  frac=achieved / FP64_VALU_PEAK_TFLOPS, flops_per_step_per_instance=flops,
-                                 note="useful fp64 flops (FMA = 2) of front end + OSC step, DESIGN.md section 5; HBM sees "
+                                 note="useful fp64 flops (FMA = 2) of front end + OSC step, profiles/NOTES.md section 4.6; HBM sees "
                                       "568 B in and 200 B out per robot, so the HBM roof is not the bound of this path"),
                    untraced=train_summary(trains, osc.steps_per_launch) if trains is not None else None,
                    note="per step: rigid-body front end (FK, EE Jacobians, CRBA, RNEA) from resident (qpos, qvel) and the OSC step on "

@@ -16,7 +16,7 @@
 // step's stage-1 tiles ride the stage-2 blocks of the corresponding step of the PREVIOUS train.  Flagged instances
 // hand A and w over in one contiguous record per instance (no worklist); each stage-2 block compacts its own
 // 384-instance span in LDS.  Instances stage 2 cannot finish (more than 3 eigenvalues under the cut) go to a small
-// give-up list handled by the generic kernel (Jacobi).  DESIGN.md section 4.2 has the numbers.
+// give-up list handled by the generic kernel (Jacobi).  profiles/NOTES.md sections 4.2 and 7 have the numbers.
 #pragma once
 #include "osc_common.hpp"
 #include "osc_generic.hpp"

@@ -1363,7 +1363,7 @@ def test_insertion_sequence_with_grip_actions_matches_reference_tick_by_tick():
 
 
 def test_tick_latency_b1_is_bounded():
-    """The B = 1 drop-in path costs one library call and one synchronisation per tick (42 us
+    """The B = 1 drop-in path costs one library call and one synchronisation per tick (50 us
     median on the row16 kernel); bound it generously so that a regression to several round trips shows."""
     import time
     lay, gains, g = synth.make_batch("k13", 16, seed=1)
