@@ -666,6 +666,7 @@ def main():
                    records="float64" if esz == 8 else "float32", layout=lay, roofline=roof, workload=workload)
         osc.step(slot=0)
         u, fl = osc.download(B)
+        res["giveups"] = int(osc.giveup_counts()[0])
         res["checksum"] = sharding.checksum_u64(u)
         res["slice_checksums"] = [sharding.checksum_u64(u[j * Bs:(j + 1) * Bs]) for j in range(S)]
         osc.close()
@@ -770,7 +771,8 @@ def main():
     if rank == 0:
         lay_, gains, arr, u, fl = chk
         out["flags"] = {"eigen_path_frac": float(((fl & 4) != 0).mean()), "pinv_branch_frac": float(((fl & 2) != 0).mean()),
-                        "truncated_frac": float(((fl & 8) != 0).mean()), "nonfinite_frac": float(((fl & 64) != 0).mean())}
+                        "truncated_frac": float(((fl & 8) != 0).mean()), "nonfinite_frac": float(((fl & 64) != 0).mean()),
+                        "giveups_to_generic_kernel": primary["giveups"]}
         if cb is not None:
             out["cpu_baseline"] = cb
             if ref is None:      # (fallback above) the oracle in this process on the first instances of the GPU's own slot 0

@@ -189,6 +189,13 @@ int irlosc_time_dominant_kernel(irlosc_ctx* ctx, int32_t slot, int32_t B, int32_
  * time divided by the number of trains measures).  from_q != 0: trains of irlosc_step_resident_from_q (the stamps are the OSC
  * kernel's; the walk in front of it is inside the period and the event pair). */
 int irlosc_time_trains(irlosc_ctx* ctx, int32_t first_slot, int32_t B, int32_t ntrains, int32_t from_q, double* out);
+/* How many instances the most recent step (out[0]) / the steps of the most recent train (out[0 .. irlosc_steps_per_launch() - 1]) handed
+ * from the row16 kernel's in-wave eigen stage to the generic kernel -- task spaces that lose MORE than three directions at once
+ * (osc.py:55 with four or more singular values under the cut).  Results are the same either way; throughput is not: the give-up
+ * pass is a serial tail of its train (one instance costs ~27 us per train, a batch dominated by them runs at 4.5e6 steps/s instead of
+ * 6e8).  Zero on physical states of the Dual-UR5 in every sweep so far; a caller whose task sets are rank-deficient by construction
+ * can watch this counter.  out[8]; all zero on the other kernels.  Synchronises the context's stream. */
+int irlosc_giveup_counts(irlosc_ctx* ctx, int32_t* out);
 /* Steps chained in one launch by irlosc_step_resident / irlosc_time_dominant_kernel (1 on the generic path):
  * the algorithmic bytes of one dominant launch = this many steps' worth. */
 int irlosc_steps_per_launch(const irlosc_ctx* ctx);

@@ -23,7 +23,7 @@ EXPORTS = ["irlosc_abi_version", "irlosc_device_count", "irlosc_create", "irlosc
            "irlosc_tick", "irlosc_comm_unique_id", "irlosc_comm_create", "irlosc_comm_destroy",
            "irlosc_comm_last_error", "irlosc_bench_allreduce", "irlosc_comm_allgather_u64", "irlosc_set_model",
            "irlosc_upload_q", "irlosc_frontend", "irlosc_step_resident_from_q", "irlosc_download_records",
-           "irlosc_step_from_q", "irlosc_from_q_name", "irlosc_slot_structure", "irlosc_probe_structure", "irlosc_time_trains"]
+           "irlosc_step_from_q", "irlosc_from_q_name", "irlosc_slot_structure", "irlosc_probe_structure", "irlosc_time_trains", "irlosc_giveup_counts"]
 COMM_ID_BYTES = 128
 
 
@@ -89,6 +89,7 @@ def load():
     lib.irlosc_time_dominant_kernel.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_float)]
     lib.irlosc_steps_per_launch.argtypes = [vp]
     lib.irlosc_time_trains.argtypes = [vp, i32, i32, i32, i32, vp]
+    lib.irlosc_giveup_counts.argtypes = [vp, vp]
     lib.irlosc_upload_raw.argtypes = [vp, i32, i32, C.POINTER(RawDesc)] + [vp] * 9
     lib.irlosc_assemble_device.argtypes = [vp, i32, i32, C.POINTER(RawDesc)] + [vp] * 10
     lib.irlosc_download.argtypes = [vp, i32, vp, vp]

@@ -1089,6 +1089,18 @@ extern "C" int irlosc_time_trains(irlosc_ctx* c, int32_t first_slot, int32_t B, 
     return IRLOSC_OK;
 }
 
+// Instances the most recent step / train handed from the row16 kernel's in-wave eigen stage to the generic kernel (the give-up
+// lists): counters of the last train, read back after a stream synchronisation.
+extern "C" int irlosc_giveup_counts(irlosc_ctx* c, int32_t* out) {
+    if (!c || !out) return IRLOSC_ERR_ARG;
+    for (int i = 0; i < R16_TRAIN; ++i) out[i] = 0;
+    if (c->kernel != IRLOSC_KERNEL_ROW16) return IRLOSC_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    HIPCHK(c, hipMemcpyAsync(out, c->dr16_count, R16_TRAIN * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return IRLOSC_OK;
+}
+
 extern "C" int irlosc_sync(irlosc_ctx* c) {
     if (!c) return IRLOSC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.hip_device));
