@@ -495,6 +495,7 @@ def main():
     ap.add_argument("--with-f32", action="store_true", help="also run the fp32-arithmetic group kernel as a secondary (explicit opt-in kernel: does NOT meet 1e-5)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the H2D/D2H-inclusive legs (generate_batched from host arrays, tick at B = 1, upload_raw)")
     ap.add_argument("--require-rccl", action="store_true", help="N > 1: exit non-zero unless every rank's barrier / reduction went through RCCL")
+    ap.add_argument("--sustained-steps", type=int, default=8000, help="steps of the long-run leg reported as `sustained` (0: skip)")
     ap.add_argument("--slices", type=int, default=1, help="sub-batches ('virtual ranks') per rank, one output checksum each")
     ap.add_argument("--no-from-q", action="store_true", help="skip the joint-coordinates path (front end + step)")
     ap.add_argument("--workload", default="physical", choices=["physical", "synthetic"],
@@ -595,7 +596,7 @@ def main():
             np.save(os.path.join(args.mint_physical, k2 + ".npy"), v)
         return
 
-    def measure(mode, steps, warmup, preroll, workload):
+    def measure(mode, steps, warmup, preroll, workload, long_leg=True):
         dt, arith, kern = MODES[mode]
         if args.kernel >= 0:
             kern = args.kernel
@@ -618,6 +619,22 @@ def main():
             comm.barrier()
         elapsed = time.perf_counter() - t0
         total_steps, elapsed, rate = sharding.reduce_throughput(B * steps, elapsed, comm)
+        # the same bracket over a LONG run (the driver's command times 20 steps = 2 ms; this is the figure that does not depend on
+        # how the first milliseconds went): not `value`, reported beside it
+        sustained = None
+        if args.sustained_steps > 0 and long_leg:
+            if comm:
+                comm.barrier()
+            osc.device_sync()
+            t1 = time.perf_counter()
+            osc.step_resident(args.sustained_steps)
+            osc.device_sync()
+            if comm:
+                comm.barrier()
+            el1 = time.perf_counter() - t1
+            _, el1, rate1 = sharding.reduce_throughput(B * args.sustained_steps, el1, comm)
+            sustained = {"steps": args.sustained_steps, "value": rate1, "unit": "steps/s", "ms_per_step": el1 / args.sustained_steps * 1e3,
+                         "seconds": el1}
         bytes_step = algorithmic_bytes(lay.n, lay.k, lay.ndev, lay.admittance, esz) * B
         spl = osc.steps_per_launch              # the throughput paths chain this many steps into one launch
         bytes_launch = bytes_step * spl
@@ -663,7 +680,7 @@ def main():
                 "note": "a kernel trace serialises dispatches: its per-dispatch average corresponds to untraced.kernel_span_us, not to "
                         "ms_per_step x steps_per_launch (= untraced.period_us); profiles/README.md"}
         res = dict(value=rate, ms_per_step=elapsed / steps * 1e3, kernel=kname, mode=mode, arith=arith,
-                   records="float64" if esz == 8 else "float32", layout=lay, roofline=roof, workload=workload)
+                   records="float64" if esz == 8 else "float32", layout=lay, roofline=roof, workload=workload, sustained=sustained)
         osc.step(slot=0)
         u, fl = osc.download(B)
         res["giveups"] = int(osc.giveup_counts()[0])
@@ -761,6 +778,7 @@ def main():
                    "rccl_ranks": (world if isinstance(comm, sharding.RcclComm) else 0) if world > 1 else None,
                    "slices_per_rank": S},
         "roofline": primary["roofline"],
+        "sustained": primary["sustained"],
     }
     # per-rank checksum of one step's outputs on slot 0 (rank r's data depend on r only, so its checksum must be the
     # same in the 1-, 2-, 4- and 8-GPU runs: sharding changes no bit)
@@ -789,7 +807,7 @@ def main():
         for other, wl in runs:
             try:
                 sec, schk = measure(other, max(24, min(200, args.steps // 4)), max(8, min(24, args.warmup // 4)),
-                                    preroll=min(args.preroll, 100), workload=wl)
+                                    preroll=min(args.preroll, 100), workload=wl, long_leg=False)
             except Exception as e:                       # e.g. a layout without a group kernel
                 out["secondary"].append({"mode": other, "records_from": wl, "error": str(e)})
                 continue

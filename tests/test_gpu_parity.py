@@ -1772,3 +1772,5 @@ def test_bench_line_end_to_end_and_untraced_roofline():
     assert e["generate_batched"]["value"] > 0 and e["generate_batched"]["pcie_GBps"] > 0.5
     assert 5 < e["tick_b1_us"]["median"] < 2000 and e["upload_raw_step"]["value"] > 0
     assert line["data"].startswith("synthetic")
+    su = line["sustained"]
+    assert su["steps"] == 8000 and su["value"] > 0 and 0.5 < su["value"] / line["value"] < 2.0
