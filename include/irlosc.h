@@ -148,8 +148,8 @@ int irlosc_upload(irlosc_ctx* ctx, int32_t slot, int32_t B, const void* M, const
  * M[i][j] exactly 0 unless hinge i is above hinge j or j above i; columns of J exactly 0 for hinges that move no end-effector
  * candidate -- what mj_fullM / mj_jacBody leave, robot.py:68-72, device.py:115-133), batches of 64 instances and more only;
  * irlosc_frontend's lane kernel writes such records by construction; irlosc_assemble_device (caller's stream) does not
- * qualify until irlosc_probe_structure has looked.  A train of irlosc_step_resident uses the form when every slot in it
- * qualifies.  Results differ from the dense recursion at rounding level only.  IRLOSC_TREE=0 in the environment turns the
+ * qualify until irlosc_probe_structure has looked.  The form is chosen per slot: a train of irlosc_step_resident that mixes
+ * qualifying and other slots is issued as two launches.  Results differ from the dense recursion at rounding level only.  IRLOSC_TREE=0 in the environment turns the
  * form off. */
 int irlosc_slot_structure(const irlosc_ctx* ctx, int32_t slot);
 /* The same look at records that are already in `slot` (first B instances), for the one path that cannot take it by itself:
@@ -194,7 +194,8 @@ int irlosc_time_trains(irlosc_ctx* ctx, int32_t first_slot, int32_t B, int32_t n
  * (osc.py:55 with four or more singular values under the cut).  Results are the same either way; throughput is not: the give-up
  * pass is a serial tail of its train (one instance costs ~27 us per train, a batch dominated by them runs at 4.5e6 steps/s instead of
  * 6e8).  Zero on physical states of the Dual-UR5 in every sweep so far; a caller whose task sets are rank-deficient by construction
- * can watch this counter.  out[8]; all zero on the other kernels.  Synchronises the context's stream. */
+ * can watch this counter.  out[8]; all zero on the other kernels.  (A train that mixes tree-form and dense slots is two launches;
+ * the counters are those of the second.)  Synchronises the context's stream. */
 int irlosc_giveup_counts(irlosc_ctx* ctx, int32_t* out);
 /* Steps chained in one launch by irlosc_step_resident / irlosc_time_dominant_kernel (1 on the generic path):
  * the algorithmic bytes of one dominant launch = this many steps' worth. */

@@ -141,14 +141,6 @@ class BatchedOSC:
     def step_resident(self, iters: int, first_slot: int = 0, B: Optional[int] = None):
         """-> (ms_total, ms_kernel_avg): `iters` launches on resident data, HIP-event timed."""
         B = self._B[first_slot] if B is None else B
-        if iters > 1 and self.n_slots > 1 and not getattr(self, "_warned_mixed", False) and "row16" in self.kernel_name:
-            st = [self.slot_structure(s) for s in range(self.n_slots) if self._B[s]]
-            if any(st) and not all(st):
-                import warnings
-                self._warned_mixed = True
-                warnings.warn("resident slots mix records with and without the kinematic tree's zero pattern: a train uses the tree-structured "
-                              "factorisation only when EVERY slot in it qualifies (slot_structure()); this loop runs the dense recursion (~15 % slower)",
-                              RuntimeWarning, stacklevel=2)
         t, a = C.c_float(), C.c_float()
         self._chk(self.lib.irlosc_step_resident(self._h, first_slot, B, iters, C.byref(t), C.byref(a)))
         return t.value, a.value

@@ -914,30 +914,37 @@ static int resident_trains(irlosc_ctx* c, int first_slot, int B, int iters, cons
 }
 
 // `iters` steps on the row16 path, chained R16_TRAIN per launch (step i of a train writes output set i); events (if any)
-// go around the launches from number `skip` on.
+// go around the launches from number `skip` on.  One kernel per launch, so a train whose slots do not ALL qualify for the
+// tree-structured form is issued as two sub-trains -- the qualifying steps with the tree kernel, the others with the dense
+// recursion -- instead of dropping every step to the dense recursion (one more launch, only when slots are mixed).
 template <typename T>
 static int row16_resident(irlosc_ctx* c, int first_slot, int B, int iters, const std::vector<hipEvent_t>* evs, int skip) {
     int done = 0, launch_no = 0;
+    const hipEvent_t outer_b = c->tev_begin, outer_e = c->tev_end;      // irlosc_time_trains brackets a one-train call itself
     while (done < iters) {
         const int n = std::min((int)R16_TRAIN, iters - done);
-        KParams<T> ps[R16_TRAIN];
-        bool tree = true;                  // one kernel per train: the tree form only when every slot of it qualifies
+        KParams<T> ps[2][R16_TRAIN];        // [1]: steps whose slot qualifies for the tree form, [0]: the others
+        int cnt[2] = {0, 0};
         for (int i = 0; i < n; ++i) {
             const int slot = (first_slot + done + i) % c->cfg.n_slots;
             int rcf = check_slot_filled(c, slot, B);
             if (rcf) return rcf;
-            tree = tree && slot_tree(c, slot);
-            fill_params<T>(c, ps[i], B, c->dM[slot], c->dJ[slot], c->ddq[slot], c->dbias[slot], c->dee[slot], c->dtgt[slot],
+            const int kind = slot_tree(c, slot) ? 1 : 0;
+            fill_params<T>(c, ps[kind][cnt[kind]++], B, c->dM[slot], c->dJ[slot], c->ddq[slot], c->dbias[slot], c->dee[slot], c->dtgt[slot],
                            c->has_tvel[slot] ? c->dtvel[slot] : nullptr, c->has_wrench[slot] ? c->dwrench[slot] : nullptr,
                            c->du_set[i], c->dflags_set[i]);
         }
-        if (evs && launch_no >= skip && 2 * (launch_no - skip) + 1 < (int)evs->size()) {
-            c->tev_begin = (*evs)[2 * (launch_no - skip)];
-            c->tev_end = (*evs)[2 * (launch_no - skip) + 1];
+        const bool timed = evs && launch_no >= skip && 2 * (launch_no - skip) + 1 < (int)evs->size();
+        hipEvent_t eb = timed ? (*evs)[2 * (launch_no - skip)] : outer_b, ee = timed ? (*evs)[2 * (launch_no - skip) + 1] : outer_e;
+        const int first = cnt[1] ? 1 : 0, last = cnt[0] ? 0 : 1;      // order: tree sub-train, then dense sub-train
+        for (int kind = 1; kind >= 0; --kind) {
+            if (!cnt[kind]) continue;
+            c->tev_begin = kind == first ? eb : nullptr;              // the event pair brackets the whole train
+            c->tev_end = kind == last ? ee : nullptr;
+            int rc = row16_train<T>(c, ps[kind], cnt[kind], kind == 1, c->stream);
+            c->tev_begin = c->tev_end = nullptr;
+            if (rc) return rc;
         }
-        int rc = row16_train<T>(c, ps, n, tree, c->stream);
-        c->tev_begin = c->tev_end = nullptr;
-        if (rc) return rc;
         c->cur = n - 1;
         done += n;
         ++launch_no;

@@ -57,6 +57,15 @@
 #ifndef IRLOSC_R16_PF
 #define IRLOSC_R16_PF 4
 #endif
+#ifndef IRLOSC_EIG_MAXIT       // eigen16: inverse iterations per candidate at most / at least (it >= FLOOR before "settled" counts) / polishing steps
+#define IRLOSC_EIG_MAXIT 12
+#endif
+#ifndef IRLOSC_EIG_FLOOR
+#define IRLOSC_EIG_FLOOR 3
+#endif
+#ifndef IRLOSC_EIG_EXTRA
+#define IRLOSC_EIG_EXTRA 2
+#endif
 #ifndef IRLOSC_R16_TREE_BUDGET          // doubles per lane in flight ahead of the tree form's recursion (dense records)
 #define IRLOSC_R16_TREE_BUDGET (2 * IRLOSC_R16_PF)
 #endif
@@ -265,7 +274,7 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
         double x = lq < K ? 0.3 + 0.1 * (double)(((lq + 3 * slot) * 5) % 7) - 0.05 * (double)slot : 0.0;
         double lam = 0.0, lam_prev = -1.0;
         bool fin = !active;
-        for (int it = 0; it < 12; ++it) {
+        for (int it = 0; it < IRLOSC_EIG_MAXIT; ++it) {
             double xn = x;
 #pragma unroll
             for (int s0 = 0; s0 < NV - 1; ++s0) {
@@ -279,14 +288,14 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
             x = fin ? x : xn * rn;
             lam = fin ? lam : lamn;
             lam_prev = lam;
-            fin = fin || (it >= 3 && settled);
+            fin = fin || (it >= IRLOSC_EIG_FLOOR && settled);
             if (!__any(!fin)) break;
         }
         // The eigenvalue is settled to 1e-10, which leaves the VECTOR at ~1e-5 -- and what leaks past the projector is
         // amplified by 1 / lambda_cut: two more steps (each gains at least the factor 4 of the net, typically far more) for
         // every instance, whenever its loop froze (tools/parity_sweep.py --stress --layout k7: errors of 1.2e-5 .. 1.6e-5).
 #pragma unroll
-        for (int ex = 0; ex < 2; ++ex) {
+        for (int ex = 0; ex < IRLOSC_EIG_EXTRA; ++ex) {
             double xn = x;
 #pragma unroll
             for (int s0 = 0; s0 < NV - 1; ++s0) {

@@ -1503,10 +1503,11 @@ def test_structure_probe_refuses_what_does_not_carry_the_tree_zeros():
     assert not st_x
 
 
-def test_trains_mixing_tree_and_dense_slots_fall_back_to_the_dense_recursion():
-    """One launch per train, one kernel per launch: a train of irlosc_step_resident uses the tree form only when every slot
-    in it qualifies.  Two slots, one of them with synthetic dense records: every slot's result equals its own single step
-    bit for bit (tree slot: its dense-recursion result)."""
+def test_trains_mixing_tree_and_dense_slots_keep_each_slots_own_form():
+    """One kernel per launch: a train of irlosc_step_resident whose slots do not all qualify for the tree form is issued as two
+    sub-trains (tree kernel for the qualifying steps, dense recursion for the others) -- round 3 dropped the whole train to the
+    dense recursion.  Two slots, one of them with synthetic dense records: every slot's result equals its own single step bit
+    for bit, whatever the train."""
     B = 512
     lay, gains, g, rec, _, _ = _physical_records("k13", B, np.float64, seed=47)
     _, _, a = synth.make_batch("k13", B, seed=9, dtype=np.float64)
@@ -1517,16 +1518,13 @@ def test_trains_mixing_tree_and_dense_slots_fall_back_to_the_dense_recursion():
     osc.set_targets(g["tgt_pose"][:B], slot=0)
     osc.set_targets(a["tgt_pose"], slot=1)
     assert osc.slot_structure(0) and not osc.slot_structure(1)
-    u0_tree = osc.step(slot=0)
-    u1 = osc.step(slot=1)
-    with pytest.warns(RuntimeWarning, match="mix records with and without"):
-        osc.step_resident(2, first_slot=0)                  # train {0, 1}: dense recursion for both; last step = slot 1
-    u_last, _ = osc.download(B)
-    assert np.array_equal(u_last, u1)
-    osc.step_resident(3, first_slot=0)                      # train {0, 1, 0}: last step = slot 0 through the dense recursion
-    u_last0, _ = osc.download(B)
+    u0_tree, f0 = osc.step(slot=0, return_flags=True)
+    u1, f1 = osc.step(slot=1, return_flags=True)
+    for iters, last in ((2, 1), (3, 0), (8, 1), (13, 0)):      # trains {0,1}, {0,1,0}, a full train, a full train + a short one
+        osc.step_resident(iters, first_slot=0)
+        u_last, f_last = osc.download(B)
+        assert np.array_equal(u_last, u0_tree if last == 0 else u1) and np.array_equal(f_last, f0 if last == 0 else f1), iters
     osc.close()
-    assert rel_err(u_last0, u0_tree.astype(np.float64)).max() <= 1e-8
 
 
 def test_raw_state_paths_qualify_for_the_tree_form():
@@ -1774,3 +1772,42 @@ def test_bench_line_end_to_end_and_untraced_roofline():
     assert line["data"].startswith("synthetic")
     su = line["sustained"]
     assert su["steps"] == 8000 and su["value"] > 0 and 0.5 < su["value"] / line["value"] < 2.0
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fused_from_q_with_target_velocities_and_per_instance_gains(dtype):
+    """The round-4 fused path splits the task-space signal: part 1 (calc_error, velocity limit, gains) in the task pass, one lane
+    per robot; the damping-branch verdict, the target-velocity term (osc.py:173-181, branch B, needs dx = J dq) and the flags in the
+    OSC kernel.  Layout with the base first and non-zero target velocities on two thirds of the robots, PER-INSTANCE gains (the pass
+    reads them strided): torques and flags must equal the path through dense records (same arithmetic) -- and the oracle."""
+    from irl_control_amd.rigid_body import DUAL_UR5_EE, RigidBodyModel
+    B = 777
+    lay, gains, g = synth.make_batch("k13_branch_b", B, seed=91, dtype=dtype, per_instance_gains=True)
+    assert g["tgt_vel"] is not None and np.ndim(gains["kp"]) == 2
+    model = RigidBodyModel.load("dual_ur5")
+    qpos, qvel = model.random_state(np.random.default_rng(92), B)
+    osc = BatchedOSC(lay, B, dtype=dtype, kernel=_lib.KERNEL_ROW16)
+    osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+    osc.set_model(model, [DUAL_UR5_EE[d] for d in lay.dev_names])
+    assert "fused" in osc.from_q_name
+    osc.upload_q(qpos, qvel)
+    osc.set_targets(g["tgt_pose"], g["tgt_vel"])
+    u_f, fl_f = osc.step_q(return_flags=True)
+    osc.frontend()
+    u_d, fl_d = osc.step(return_flags=True)
+    rec = osc.download_records(0)
+    osc.close()
+    assert np.array_equal(fl_f, fl_d) and np.all(fl_f[np.arange(B) % 3 != 0] & _lib.FLAG_VEL_BRANCH_B)
+    assert not np.any(fl_f[::3] & _lib.FLAG_VEL_BRANCH_B)
+    # float32 records: the dense path rounds M / J to float32, the fused path never forms them (float64 exchange buffer) -- the
+    # difference is that rounding times the conditioning, not the kernels'
+    assert rel_err(u_f.astype(np.float64), u_d.astype(np.float64)).max() <= (1e-9 if dtype == np.float64 else 1e-4)
+    if dtype == np.float32:
+        u_f = u_d                                          # the oracle below runs on the ROUNDED records: compare like with like
+    n = 192
+    r = {k: np.asarray(v[:n], dtype=np.float64) for k, v in rec.items()}
+    gsub = {k: (np.asarray(v)[:n] if np.ndim(v) >= 1 and np.shape(v)[0] == B else v) for k, v in gains.items()}
+    ref = osc_oracle.generate_batch(lay.as_oracle_dict(), gsub, r["M"], r["J"], r["dq"], r["bias"], r["ee_pose"],
+                                    np.asarray(g["tgt_pose"][:n], dtype=np.float64), None, np.asarray(g["tgt_vel"][:n], dtype=np.float64))
+    dom = np.array([in_parity_domain(*osc_oracle.task_inertia(r["J"][b], r["M"][b])[2:]) for b in range(n)])
+    assert dom.sum() > n // 2 and rel_err(u_f[:n].astype(np.float64), ref)[dom].max() <= TOL64
