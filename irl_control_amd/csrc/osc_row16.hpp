@@ -1000,6 +1000,9 @@ __global__ __launch_bounds__(FROMQ ? 256 : 64, IRLOSC_R16_WAVES) void osc_row16_
         if constexpr (tree_row_of_y<TOPO>(i)) {               // tree: the rows of Y under no end effector are zero
             static_for<0, K>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
+                // (The task rows of one arm only see that arm's hinges and the stand: with the rows grouped by arm, 85 of these 169
+                // products are structurally non-zero.  Measured as an upper bound with the bench's row order hard-wired: +1.2 % --
+                // not worth a row permutation and a second instantiation per shape.)
                 if constexpr (i == 0 && r == 0) fmac_bc_nop<r>(A[r], T[i], T[i]);
                 else fmac_bc<r>(A[r], T[i], T[i]);
             });
@@ -1210,14 +1213,17 @@ __global__ __launch_bounds__(64) void osc_generic_worklist_kernel(const Row16Tra
 // OWN between the walk and the OSC kernel -- ONE LANE PER ROBOT, block x = walk wave x (its 64 robots), blockIdx.y = step.  Reads
 // the end-effector poses the walk parked (coalesced: [entry][64 robots]), the targets and gains, and leaves the k gained error rows
 // as k more entries of the exchange block (FeTopo::task_index), which the OSC kernel's tile picks up like everything else.  Same
-// formulas as the in-kernel form of the dense-record path (task_rot, apply_gains6_fast).  ~1 200 instructions per wave of 64
-// robots against ~400 per wave of FOUR robots in the OSC kernel.
+// formulas as the in-kernel form of the dense-record path (task_rot, apply_gains6_fast).  ~450 instructions per wave of 64
+// (robot, device) pairs against ~400 per wave of FOUR robots in the OSC kernel.
 template <int K, int NDEV, typename TIN, class TOPO>
-__global__ __launch_bounds__(64) void osc_task_rows_fromq_kernel(const Row16Train<TIN> tr) {
+__global__ __launch_bounds__(64 * NDEV) void osc_task_rows_fromq_kernel(const Row16Train<TIN> tr) {
     using namespace r16;
     const KParams<TIN>& p = tr.p[blockIdx.y];
     const Row16Extra& x = tr.x[blockIdx.y];
-    const int lane = threadIdx.x;
+    // block = the 64 robots of walk wave blockIdx.x x NDEV waves: wave d computes the rows of target device d.  (The pass moves 230 MB
+    // per train of 8 -- poses in, targets in, rows out -- and takes 60 us either way, one wave per robot or per (robot, device).)
+    const int lane = threadIdx.x & 63;
+    const int d = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int b = blockIdx.x * 64 + lane;
     const int bc = b < p.B ? b : p.B - 1;        // idle lanes of a ragged last block: the walk left the last robot's data in their columns
     const FeCompactTables* __restrict__ tb = x.tables;
@@ -1225,53 +1231,48 @@ __global__ __launch_bounds__(64) void osc_task_rows_fromq_kernel(const Row16Trai
                                                           // constexpr function is evaluated at run time -- loops over the tree, 2.4 ms)
     double* __restrict__ col = const_cast<double*>(x.side) + (size_t)blockIdx.x * BLK_E * 64 + lane;
     // The targets of the block's 64 robots are 64 x NDEV x 7 consecutive words: wave loads, all in flight together, transposed
-    // through LDS (read straight per lane -- 168-byte strides, 64 lines per load instruction -- this pass took 2.07 ms per train
-    // of 8: the texture addresser handles a line per cycle).
+    // through LDS (read straight per lane -- 168-byte strides, 64 lines per load instruction -- the texture addresser handles a
+    // line per cycle).  Wave d brings in the d-th third of them.
     constexpr int TW = NDEV * 7;                   // odd: conflict-free reads with the robot as the slow index
     __shared__ double tgs[64 * TW];
     {
-        const size_t g0 = (size_t)blockIdx.x * 64 * TW, glast = (size_t)p.B * TW - 1;
-        TIN tv[TW];
+        const size_t g0 = (size_t)blockIdx.x * 64 * TW + (size_t)d * 64 * 7, glast = (size_t)p.B * TW - 1;
+        TIN tv[7];
 #pragma unroll
-        for (int i = 0; i < TW; ++i) { const size_t g = g0 + lane + 64 * i; tv[i] = p.tgt[g < glast ? g : glast]; }
+        for (int i = 0; i < 7; ++i) { const size_t g = g0 + lane + 64 * i; tv[i] = p.tgt[g < glast ? g : glast]; }
 #pragma unroll
-        for (int i = 0; i < TW; ++i) tgs[lane + 64 * i] = (double)tv[i];
-        lds_sync();
+        for (int i = 0; i < 7; ++i) tgs[d * 64 * 7 + lane + 64 * i] = (double)tv[i];
     }
     const unsigned e0 = tb->e0;                    // (a value, not `tb->e0` at every store: the stores might alias the table for all the compiler knows)
-    uint16_t eet[NDEV][7];                         // entry indices of the poses: requested together, ahead of the poses
+    uint16_t eet[7];                               // entry indices of the pose: requested together, ahead of the pose
 #pragma unroll
-    for (int d = 0; d < NDEV; ++d)
+    for (int i = 0; i < 7; ++i) eet[i] = tb->eetab[d][i];
+    const DevMeta dm = p.dev[d];
+    const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * NDEV * IRLOSC_GAIN_WORDS : 0) + d * IRLOSC_GAIN_WORDS;
+    double ee[7], tg[7], g[IRLOSC_GAIN_WORDS];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) eet[d][i] = tb->eetab[d][i];
-    static_for<0, NDEV>([&](auto dc) {
-        constexpr int d = decltype(dc)::value;
-        const DevMeta dm = p.dev[d];
-        const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * NDEV * IRLOSC_GAIN_WORDS : 0) + d * IRLOSC_GAIN_WORDS;
-        double ee[7], tg[7], g[IRLOSC_GAIN_WORDS];
+    for (int i = 0; i < 7; ++i) ee[i] = col[(size_t)eet[i] * 64];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) ee[i] = col[(size_t)eet[d][i] * 64];
+    for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) g[i] = (double)gp[i];
+    __syncthreads();                               // the targets of all devices are in LDS
 #pragma unroll
-        for (int i = 0; i < 7; ++i) tg[i] = tgs[lane * TW + d * 7 + i];
+    for (int i = 0; i < 7; ++i) tg[i] = tgs[lane * TW + d * 7 + i];
+    double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (dm.calc & 1u) { e[0] = ee[0] - tg[0]; e[1] = ee[1] - tg[1]; e[2] = ee[2] - tg[2]; }
+    if (dm.calc & 2u) {
+        const TaskRot R = task_rot(ee, tg);
 #pragma unroll
-        for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) g[i] = (double)gp[i];
-        double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (dm.calc & 1u) { e[0] = ee[0] - tg[0]; e[1] = ee[1] - tg[1]; e[2] = ee[2] - tg[2]; }
-        if (dm.calc & 2u) {
-            const TaskRot R = task_rot(ee, tg);
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                double ay, ax;
-                R.angle_args(a, ay, ax);
-                e[3 + a] = atan2(ay, ax);
-            }
+        for (int a = 0; a < 3; ++a) {
+            double ay, ax;
+            R.angle_args(a, ay, ax);
+            e[3 + a] = atan2(ay, ax);
         }
-        apply_gains6_fast(g, e);
-        int cnt = 0;
+    }
+    apply_gains6_fast(g, e);
+    int cnt = 0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-            if (dm.dofmask & (1u << i)) { col[(size_t)(e0 + dm.row0 + cnt) * 64] = e[i]; ++cnt; }
-    });
+    for (int i = 0; i < 6; ++i)
+        if (dm.dofmask & (1u << i)) { col[(size_t)(e0 + dm.row0 + cnt) * 64] = e[i]; ++cnt; }
 }
 
 inline bool row16_kernel_supports(int dtype, int n, int k, int ndev) {

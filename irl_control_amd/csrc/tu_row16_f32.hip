@@ -38,10 +38,10 @@ int launch_row16_fromq(const Row16Train<TIN>& tr, int nsteps, hipStream_t st) {
     if (p.B <= 0 || nsteps <= 0) return 0;
     const int waves = (p.B + 63) / 64;
     const dim3 grid(waves * 4, nsteps), tgrid(waves, nsteps);      // the task pass first: one lane per robot, block = walk wave
-    if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<13, 3, TIN, TopoDualUr5>), tgrid, dim3(64), 0, st, tr);
-    else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<12, 2, TIN, TopoDualUr5>), tgrid, dim3(64), 0, st, tr);
-    else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<7, 3, TIN, TopoDualUr5>), tgrid, dim3(64), 0, st, tr);
-    else if (p.k == 6 && p.ndev == 2) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<6, 2, TIN, TopoDualUr5>), tgrid, dim3(64), 0, st, tr);
+    if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<13, 3, TIN, TopoDualUr5>), tgrid, dim3(64 * 3), 0, st, tr);
+    else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<12, 2, TIN, TopoDualUr5>), tgrid, dim3(64 * 2), 0, st, tr);
+    else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<7, 3, TIN, TopoDualUr5>), tgrid, dim3(64 * 3), 0, st, tr);
+    else if (p.k == 6 && p.ndev == 2) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<6, 2, TIN, TopoDualUr5>), tgrid, dim3(64 * 2), 0, st, tr);
     else return (int)hipErrorNotSupported;
     if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25, true, TopoDualUr5>), grid, dim3(256), 0, st, tr);
     else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<12, 2, TIN, 25, true, TopoDualUr5>), grid, dim3(256), 0, st, tr);
