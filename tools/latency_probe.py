@@ -37,4 +37,4 @@ if __name__ == "__main__":
     for B in (1, 16, 256, 4096):
         probe(B, np.float64, _lib.KERNEL_AUTO, "f64 auto (row16)")
         probe(B, np.float64, _lib.KERNEL_GENERIC, "f64 generic")
-        probe(B, np.float32, _lib.KERNEL_AUTO, "f32 auto (group)")
+        probe(B, np.float32, _lib.KERNEL_AUTO, "f32 records auto (row16 mixed)")

@@ -63,7 +63,7 @@ for sd in range(a.seeds):
     res = {}
     # the reference for float32 records is the generic kernel in float64 on the SAME (rounded) numbers
     g64 = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in g.items()}
-    for name, kern, kdt, data in (("row16", _lib.KERNEL_AUTO if a.mode == "f32" else _lib.KERNEL_ROW16, dt, g), ("generic", 1, np.float64, g64)):
+    for name, kern, kdt, data in (("row16", _lib.KERNEL_GROUP if a.mode == "f32" else _lib.KERNEL_ROW16, dt, g), ("generic", 1, np.float64, g64)):
         osc = BatchedOSC(lay, B, dtype=kdt, kernel=kern)
         osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
         # upload + step (not the one-call tick): uploaded records are probed for the kinematic tree's zero pattern, and physical
