@@ -372,9 +372,11 @@ def train_summary(tt, spl):
             "period_us": {"median": q(per, 0.5), "p10": q(per, 0.1), "p90": q(per, 0.9), "mean": float(per.mean())},
             "event_pair_us": {"median": q(tt[:, 0], 0.5) * 1e3, "mean": float(tt[:, 0].mean()) * 1e3},
             "overlap_us_median": q(dur[:-1] - per, 0.5),
+            "sclk_mhz": ({"median": q(tt[:, 3], 0.5), "p10": q(tt[:, 3], 0.1), "p90": q(tt[:, 3], 0.9)} if tt.shape[1] > 3 and tt[:, 3].max() > 0 else None),
             "note": "untraced, one run: kernel_span = last wave's end - first wave's start of a train's main kernel (s_memrealtime stamped "
                     "in the kernel); period = start-to-start of consecutive trains; overlap = span - period (> 0: the next train's "
-                    "first waves run while this train's last waves drain -- kernels of one stream are not serialised by a barrier)"}
+                    "first waves run while this train's last waves drain -- kernels of one stream are not serialised by a barrier); sclk_mhz = "
+                    "shader cycle counter against wall clock over one sample wave per train: the sustained clock under this fp64 load (peak 2 400)"}
 
 
 def measure_end_to_end(BatchedOSC, lay, gains, arr, dt, kern, local_rank):

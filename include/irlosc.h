@@ -181,11 +181,13 @@ int irlosc_time_dominant_kernel(irlosc_ctx* ctx, int32_t slot, int32_t B, int32_
  * trains of irlosc_steps_per_launch() steps, issued exactly as irlosc_step_resident issues them (slots rotating from first_slot),
  * after one untimed train.  Every train gets (a) its own HIP event pair on the library's stream and (b) the wall clock
  * (s_memrealtime, 100 MHz) stamped by its main kernel itself: the start of its first wave and the end of its last wave.
- *   out[3 i + 0]  event pair of train i in milliseconds (main kernel + give-up pass; from_q: walk + OSC kernel + give-up pass)
- *   out[3 i + 1]  start of train i's first wave, microseconds after the first wave of train 0
- *   out[3 i + 2]  end of train i's last wave, same origin
- * => in-kernel duration of train i = out[3 i + 2] - out[3 i + 1] (what a kernel trace reports per dispatch, minus the
- * tracer's own serialisation); steady-state period = out[3 (i + 1) + 1] - out[3 i + 1] (what irlosc_step_resident's wall
+ *   out[4 i + 0]  event pair of train i in milliseconds (main kernel + give-up pass; from_q: walk + OSC kernel + give-up pass)
+ *   out[4 i + 1]  start of train i's first wave, microseconds after the first wave of train 0
+ *   out[4 i + 2]  end of train i's last wave, same origin
+ *   out[4 i + 3]  shader clock in MHz during train i: cycle counter against wall clock over the life of one sample wave (the kernel is
+ *                 fp64-VALU-heavy and the part power-limited: 1.5-1.8 GHz under this load against the 2.4 GHz peak, and box to box different)
+ * => in-kernel duration of train i = out[4 i + 2] - out[4 i + 1] (what a kernel trace reports per dispatch, minus the
+ * tracer's own serialisation); steady-state period = out[4 (i + 1) + 1] - out[4 i + 1] (what irlosc_step_resident's wall
  * time divided by the number of trains measures).  from_q != 0: trains of irlosc_step_resident_from_q (the stamps are the OSC
  * kernel's; the walk in front of it is inside the period and the event pair). */
 int irlosc_time_trains(irlosc_ctx* ctx, int32_t first_slot, int32_t B, int32_t ntrains, int32_t from_q, double* out);

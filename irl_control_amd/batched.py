@@ -153,10 +153,11 @@ class BatchedOSC:
         return a.value
 
     def time_trains(self, ntrains: int, first_slot: int = 0, B: Optional[int] = None, from_q: bool = False) -> np.ndarray:
-        """Untraced timing of `ntrains` consecutive trains (irlosc_time_trains): -> [ntrains, 3] = (HIP event pair of the train in
-        ms, start of its first wave, end of its last wave in microseconds of the kernels' own 100 MHz clock since train 0)."""
+        """Untraced timing of `ntrains` consecutive trains (irlosc_time_trains): -> [ntrains, 4] = (HIP event pair of the train in
+        ms, start of its first wave, end of its last wave in microseconds of the kernels' own 100 MHz clock since train 0, shader
+        clock in MHz seen by a sample wave of the train)."""
         B = self._B[first_slot] if B is None else B
-        out = np.zeros((int(ntrains), 3), dtype=np.float64)
+        out = np.zeros((int(ntrains), 4), dtype=np.float64)
         self._chk(self.lib.irlosc_time_trains(self._h, first_slot, B, int(ntrains), 1 if from_q else 0, _lib.ptr(out)))
         return out
 

@@ -1057,18 +1057,22 @@ extern "C" int irlosc_time_trains(irlosc_ctx* c, int32_t first_slot, int32_t B, 
     if (c->dspan_cap < ntrains) {
         if (c->dspan) HIPCHK(c, hipFree(c->dspan));
         c->dspan = nullptr; c->dspan_cap = 0;
-        HIPCHK(c, hipMalloc((void**)&c->dspan, (size_t)ntrains * 2 * R16_SPAN_SLOTS * sizeof(unsigned long long)));
+        HIPCHK(c, hipMalloc((void**)&c->dspan, (size_t)ntrains * R16_SPAN_WORDS * sizeof(unsigned long long)));
         c->dspan_cap = ntrains;
     }
-    std::vector<unsigned long long> h((size_t)ntrains * 2 * R16_SPAN_SLOTS);
-    for (size_t i = 0; i < h.size(); i += 2) { h[i] = ~0ull; h[i + 1] = 0ull; }
+    std::vector<unsigned long long> h((size_t)ntrains * R16_SPAN_WORDS);
+    for (int i = 0; i < ntrains; ++i) {
+        unsigned long long* t = h.data() + (size_t)i * R16_SPAN_WORDS;
+        for (int s2 = 0; s2 < R16_SPAN_SLOTS; ++s2) { t[2 * s2] = ~0ull; t[2 * s2 + 1] = 0ull; }
+        t[2 * R16_SPAN_SLOTS] = t[2 * R16_SPAN_SLOTS + 1] = 0ull;
+    }
     HIPCHK(c, hipMemcpyAsync(c->dspan, h.data(), h.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // one untimed train first (clocks, caches, nothing rides on an idle machine), then the measured ones back to back
     for (int i = -1; i < ntrains && !rc; ++i) {
         if (i >= 0) {
             c->tev_begin = c->tev_pool[2 * i]; c->tev_end = c->tev_pool[2 * i + 1];
-            c->span_next = c->dspan + (size_t)2 * R16_SPAN_SLOTS * i;
+            c->span_next = c->dspan + (size_t)R16_SPAN_WORDS * i;
         }
         const int s0 = (first_slot + (i + 1) * spl) % c->cfg.n_slots;
         if (from_q) rc = fused_resident(c, s0, B, spl);
@@ -1082,16 +1086,18 @@ extern "C" int irlosc_time_trains(irlosc_ctx* c, int32_t first_slot, int32_t B, 
     unsigned long long t0 = 0;
     for (int i = 0; i < ntrains; ++i) {
         unsigned long long lo = ~0ull, hi = 0ull;                    // over the stamp pairs of the train
+        const unsigned long long* t = h.data() + (size_t)i * R16_SPAN_WORDS;
         for (int s2 = 0; s2 < R16_SPAN_SLOTS; ++s2) {
-            lo = std::min(lo, h[((size_t)i * R16_SPAN_SLOTS + s2) * 2]);
-            hi = std::max(hi, h[((size_t)i * R16_SPAN_SLOTS + s2) * 2 + 1]);
+            lo = std::min(lo, t[2 * s2]);
+            hi = std::max(hi, t[2 * s2 + 1]);
         }
         if (i == 0) t0 = lo;
         float ms = 0.f;
         HIPCHK(c, hipEventElapsedTime(&ms, c->tev_pool[2 * i], c->tev_pool[2 * i + 1]));
-        out[3 * i] = ms;
-        out[3 * i + 1] = (double)(lo - t0) / 100.0;                  // s_memrealtime: 100 MHz
-        out[3 * i + 2] = (double)(hi - t0) / 100.0;
+        out[4 * i] = ms;
+        out[4 * i + 1] = (double)(lo - t0) / 100.0;                  // s_memrealtime: 100 MHz
+        out[4 * i + 2] = (double)(hi - t0) / 100.0;
+        out[4 * i + 3] = t[2 * R16_SPAN_SLOTS + 1] ? (double)t[2 * R16_SPAN_SLOTS] / ((double)t[2 * R16_SPAN_SLOTS + 1] / 100.0) : 0.0;   // cycles per us = MHz
     }
     return IRLOSC_OK;
 }

@@ -609,7 +609,8 @@ struct Row16Extra {
 // launch gap, the ramp-up and the tail between them (a step's last waves - those with eigen-stage instances - finish
 // while the next step's first waves already run).  A train of one step is the plain single-step launch.
 constexpr int R16_TRAIN = 8;
-constexpr int R16_SPAN_SLOTS = 256;      // stamp pairs per train (irlosc_time_trains), a power of two
+constexpr int R16_SPAN_SLOTS = 256;      // stamp pairs per train (irlosc_time_trains), a power of two; + one pair {shader cycles, wall-clock ticks} of a sample wave
+constexpr int R16_SPAN_WORDS = 2 * R16_SPAN_SLOTS + 2;
 template <typename TIN>
 struct Row16Train {
     KParams<TIN> p[R16_TRAIN];
@@ -743,6 +744,7 @@ __global__ __launch_bounds__(FROMQ ? 256 : 64, IRLOSC_R16_WAVES) void osc_row16_
     // IRLOSC_PHASE_TIMING=1 debug runs: cycle stamps per phase and the wall clock of the wave (p.dbg != nullptr)
     unsigned long long ts[8];
     const unsigned long long rt0 = (p.dbg || x.span) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long cyc0 = x.span ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
 #define IRLOSC_TS(i) ts[i] = p.dbg ? __builtin_readcyclecounter() : 0ull
     IRLOSC_TS(0);
 
@@ -1181,8 +1183,13 @@ __global__ __launch_bounds__(FROMQ ? 256 : 64, IRLOSC_R16_WAVES) void osc_row16_
     IRLOSC_TS(7);
     if (x.span && lane == 0) {       // first wave's start / last wave's end of the train, untraced (irlosc_time_trains)
         unsigned long long* sp = x.span + 2 * (blockIdx.x & (R16_SPAN_SLOTS - 1));
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
         atomicMin(sp, rt0);
-        atomicMax(sp + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        atomicMax(sp + 1, rt1);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && wv == 0) {      // one sample wave per train: shader cycles against wall clock
+            x.span[2 * R16_SPAN_SLOTS] = (unsigned long long)__builtin_readcyclecounter() - cyc0;
+            x.span[2 * R16_SPAN_SLOTS + 1] = rt1 - rt0;
+        }
     }
     if (p.dbg && lane == 0) {
         const size_t wid = (size_t)blockIdx.x * NW + wv;

@@ -84,8 +84,8 @@ def test_cpu_legs_run_without_a_gpu():
 
 def test_train_summary_reconciles_span_period_and_events():
     """irlosc_time_trains rows -> the figures of roofline.untraced: span = end - start per train, period = start to start."""
-    tt = np.array([[1.00, 0.0, 900.0], [1.00, 850.0, 1760.0], [1.02, 1700.0, 2590.0], [0.99, 2550.0, 3445.0]])
+    tt = np.array([[1.00, 0.0, 900.0, 1600.0], [1.00, 850.0, 1760.0, 1610.0], [1.02, 1700.0, 2590.0, 1590.0], [0.99, 2550.0, 3445.0, 1600.0]])
     s = bench.train_summary(tt, 8)
     assert s["trains"] == 4 and s["steps_per_train"] == 8
     assert s["period_us"]["median"] == 850.0 and 895.0 <= s["kernel_span_us"]["median"] <= 910.0
-    assert 45.0 <= s["overlap_us_median"] <= 60.0 and 990.0 <= s["event_pair_us"]["median"] <= 1010.0
+    assert 45.0 <= s["overlap_us_median"] <= 60.0 and 990.0 <= s["event_pair_us"]["median"] <= 1010.0 and s["sclk_mhz"]["median"] == 1600.0

@@ -1700,6 +1700,7 @@ def test_time_trains_spans_and_periods_are_consistent():
     assert tt[0, 1] == 0.0 and np.all(per > 0) and np.all(span > 0)
     assert np.all(span <= tt[:, 0] * 1e3 + 20.0)              # event pair (ms) covers the kernel (+ clock granularity)
     assert np.median(per) <= np.median(span) + 100.0
+    assert np.all((tt[:, 3] > 400.0) & (tt[:, 3] < 3000.0))      # sustained shader clock in MHz, seen by a sample wave of each train
     osc.close()
 
 

@@ -80,7 +80,7 @@ out = {"what": __doc__.split("\n\n")[0], "kernel": (osc.from_q_name if a.from_q 
            "from_wall_clock": bytes_train / (wall / a.trains) / 8e12, "from_period": bytes_train / (summ["period_us"]["median"] * 1e-6) / 8e12,
            "from_kernel_span": bytes_train / (summ["kernel_span_us"]["median"] * 1e-6) / 8e12},
        "per_train": {"event_pair_us": [round(float(v) * 1e3, 2) for v in tt[:, 0]], "start_us": [round(float(v), 2) for v in tt[:, 1]],
-                     "end_us": [round(float(v), 2) for v in tt[:, 2]]}}
+                     "end_us": [round(float(v), 2) for v in tt[:, 2]], "sclk_mhz": [round(float(v), 1) for v in tt[:, 3]]}}
 osc.close()
 txt = json.dumps(out)
 if a.out:
