@@ -15,6 +15,7 @@ from oracle import osc_oracle                                # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--seeds", type=int, default=16)
+ap.add_argument("--seed0", type=int, default=0, help="first seed index (a later run continues where an earlier one stopped)")
 ap.add_argument("--batch", type=int, default=65536)
 ap.add_argument("--layout", default="k13")
 ap.add_argument("--mode", default="f64", choices=["f64", "mixed", "f32"], help="f32: the fp32 group kernel (error ~ eps32 * cond: use --tol 0.1 --band 0.05 to look for GROSS errors only)")
@@ -31,7 +32,7 @@ a = ap.parse_args()
 dt = np.float64 if a.mode == "f64" else np.float32
 B = a.batch
 tot = bad_in = bad_out = 0
-for sd in range(a.seeds):
+for sd in range(a.seed0, a.seed0 + a.seeds):
     lay, gains, g = synth.make_batch(a.layout, B, seed=777000 + 131 * sd, dtype=dt, per_instance_gains=a.per_instance_gains)
     if a.physical:
         from irl_control_amd.rigid_body import RigidBodyModel
