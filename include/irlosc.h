@@ -282,8 +282,9 @@ typedef struct irlosc_model {
     int32_t ee_body[IRLOSC_MAX_DEV];
 } irlosc_model;
 /* Validates the tree (parents precede children, one body per hinge, masses >= 0) and allocates per slot qpos / qvel of
- * max_batch robots.  A model with the compiled Dual-UR5 tree shape selects the lane-per-robot kernel, which also takes a
- * side buffer of ceil(max_batch / 64) x 266 x 512 bytes (139 MB at 65 536 robots); any other tree the generic kernel. */
+ * max_batch robots.  A model with the compiled Dual-UR5 tree shape selects the lane-per-robot kernel -- its side buffer of
+ * ceil(max_batch / 64) x 266 x 512 bytes (139 MB at 65 536 robots) is allocated by the first irlosc_frontend; if that fails the
+ * context drops to the generic kernel -- any other tree the generic kernel. */
 int irlosc_set_model(irlosc_ctx* ctx, const irlosc_model* model);
 /* Joint positions and velocities of one batch into resident slot `slot`: qpos[B][n], qvel[B][n], always double. */
 int irlosc_upload_q(irlosc_ctx* ctx, int32_t slot, int32_t B, const double* qpos, const double* qvel);

@@ -83,7 +83,6 @@ struct irlosc_ctx {
     size_t fe_xentries = 0;
     double* fe_xside[R16_TRAIN] = {};
     int fused = 0;
-    int fused_xcd_map = 1;
     int fused_train = R16_TRAIN;
     std::vector<double*> dqpos, dqvel;
     std::vector<int> has_q;
@@ -761,7 +760,7 @@ static int row16_train(irlosc_ctx* c, const KParams<T>* ps, int n, bool tree, hi
     HIPCHK(c, hipMemsetAsync(c->dr16_count, 0, R16_TRAIN * sizeof(int32_t), st));
     for (int i = 0; i < n; ++i) {
         tr.p[i] = ps[i];
-        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[i], c->dr16_count + i, nullptr, nullptr, nullptr, 0, c->span_next};
+        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[i], c->dr16_count + i, nullptr, nullptr, nullptr, c->span_next};
     }
     if (c->tev_begin) HIPCHK(c, hipEventRecord(c->tev_begin, st));
     int rc = launch_row16<T>(tr, n, tree, st);
@@ -1189,16 +1188,12 @@ extern "C" int irlosc_set_model(irlosc_ctx* c, const irlosc_model* m) {
         const char* e = getenv("IRLOSC_FRONTEND");           // "generic": force the wave-per-instance kernel (A/B measurements)
         c->fe_lane = frontend_lane_dual_ur5_matches(h) && !(e && !strcmp(e, "generic"));
     }
-    if (c->fe_lane && !c->fe_side) {
-        const size_t waves = ((size_t)c->cfg.max_batch + 63) / 64;
-        HIPCHK(c, hipMalloc((void**)&c->fe_side, waves * frontend_lane_dual_ur5_side_doubles_per_wave() * sizeof(double)));
-    }
+    // (the lane kernel's side buffer -- 139 MB at 65 536 robots -- is allocated by the first irlosc_frontend: a context that only
+    // ever takes the fused path never needs it)
     {   // The fused path needs the compiled tree shape (lane kernel) and the fp64 row16 kernel; IRLOSC_FUSED=0 forces the
         // two-kernel path through dense records (A/B measurements).
         const char* e = getenv("IRLOSC_FUSED");
         c->fused = c->fe_lane && c->kernel == IRLOSC_KERNEL_ROW16 && !(e && !strcmp(e, "0"));
-        const char* m = getenv("IRLOSC_FROMQ_MAP");        // "0": identity block map (A/B measurements)
-        c->fused_xcd_map = !(m && !strcmp(m, "0"));
         const char* t = getenv("IRLOSC_FUSED_TRAIN");      // steps per launch pair of the fused path (A/B measurements)
         if (t && atoi(t) >= 1 && atoi(t) <= R16_TRAIN) c->fused_train = atoi(t);
     }
@@ -1249,6 +1244,15 @@ static int frontend_launch(irlosc_ctx* c, int slot, int B) {
     if (!c->has_q[slot]) return fail(c, IRLOSC_ERR_STATE, "slot %d: irlosc_upload_q must precede irlosc_frontend", slot);
     if (B == 0) { c->uploaded[slot] = -1; return IRLOSC_OK; }
     if (B > c->has_q[slot]) return fail(c, IRLOSC_ERR_STATE, "slot %d holds joint coordinates of %d instances, front end asked for %d", slot, std::max(0, c->has_q[slot]), B);
+    if (c->fe_lane && !c->fe_side) {
+        const size_t waves = ((size_t)c->cfg.max_batch + 63) / 64;
+        if (hipMalloc((void**)&c->fe_side, waves * frontend_lane_dual_ur5_side_doubles_per_wave() * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            c->fe_side = nullptr;
+            c->fe_lane = 0;              // out of memory: the wave-per-robot kernel needs no side buffer
+            c->fused = 0;
+        }
+    }
     int rc;
     if (c->cfg.dtype == IRLOSC_F64) {
         const FeOut<double> o{(double*)c->dM[slot], (double*)c->dJ[slot], (double*)c->ddq[slot], (double*)c->dbias[slot], (double*)c->dee[slot]};
@@ -1345,7 +1349,7 @@ static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, hipStream_
         ft.side[i] = c->fe_xside[i];
         fill_params<T>(c, tr.p[i], B, c->dM[sl], c->dJ[sl], c->ddq[sl], c->dbias[sl], c->dee[sl], c->dtgt[sl],
                        c->has_tvel[sl] ? c->dtvel[sl] : nullptr, c->has_wrench[sl] ? c->dwrench[sl] : nullptr, c->du_set[i], c->dflags_set[i]);
-        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[i], c->dr16_count + i, c->fe_xside[i], c->dqvel[sl], c->dtables, c->fused_xcd_map, c->span_next};
+        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[i], c->dr16_count + i, c->fe_xside[i], c->dqvel[sl], c->dtables, c->span_next};
         ga.out[i] = FeOut<T>{(T*)c->dM[sl], (T*)c->dJ[sl], (T*)c->ddq[sl], (T*)c->dbias[sl], (T*)c->dee[sl]};
         ga.list[i] = c->dr16_list[i];
         ga.count[i] = c->dr16_count + i;

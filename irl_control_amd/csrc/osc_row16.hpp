@@ -597,7 +597,6 @@ struct Row16Extra {
     const double* side;        // [walk wave][entry][64 robots]
     const double* qvel;        // [B][n]
     const FeCompactTables* tables;
-    int32_t xcd_map;           // 1: the XCD-aware block -> robots map of the FROMQ kernel (0: identity, A/B measurements)
     // irlosc_time_trains: {min over waves of the start, max over waves of the end} of the 100 MHz wall clock (s_memrealtime),
     // R16_SPAN_SLOTS pairs per TRAIN (every step of a train points at the same block; a wave uses pair blockIdx.x % slots: 131 072
     // waves hammering ONE address serialise in the L2 -- measured: a train took 3.07 ms instead of 0.85); nullptr = no stamps
