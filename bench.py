@@ -60,6 +60,14 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MI
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 lanes x 2 flop (FMA) x 2.4 GHz: v_fma_f64 issues at the full VALU rate
 # Useful fp64 flops of one control step from joint coordinates (FMA = 2; profiles/NOTES.md section 4.6 derives both figures):
 FLOPS_OSC_STEP = {"k13": 23.3e3, "k12_admit": 21.6e3, "k7": 14.2e3}    # Cholesky, substitution, J M^-1 J^T, k x k, torques
+
+
+def flops_osc_step(layout_name, k):
+    """Counted figures for the three layouts of NOTES.md section 4.6; any other layout: the line through the k = 7 and k = 13 counts
+    (1.52 kflop per task row: substitution + A = Y^T Y + k x k grow with k, the Cholesky of M does not) -- labelled as such."""
+    if layout_name in FLOPS_OSC_STEP:
+        return FLOPS_OSC_STEP[layout_name], "counted (profiles/NOTES.md section 4.6)"
+    return 14.2e3 + (k - 7) * (23.3e3 - 14.2e3) / 6.0, "interpolated in k between the counted k = 7 and k = 13 figures"
 FLOPS_FRONT_END = 20.1e3                                                # FK, EE Jacobians, CRBA, RNEA of the Dual-UR5 tree (counted in the ISA)
 MODES = {   # --dtype -> (record dtype, arithmetic label, kernel id)
     "f64": (np.float64, "f64", 0),
@@ -315,14 +323,15 @@ def measure_from_q(BatchedOSC, synth, args, B, local_rank, state0=None, ref_u=No
             osc.frontend(slot=s)
         _, ms_osc = osc.step_resident(steps)
         esz = np.dtype(dt).itemsize
-        flops = FLOPS_FRONT_END + FLOPS_OSC_STEP.get(args.layout, FLOPS_OSC_STEP["k13"])
+        f_osc, f_how = flops_osc_step(args.layout, lay.k)
+        flops = FLOPS_FRONT_END + f_osc
         achieved = flops * B / (ms_step * 1e-3) / 1e12
         res = dict(value=B * steps / el, unit="steps/s", ms_per_step=el / steps * 1e3, ms_per_step_events=ms_step,
                    ms_osc_step_on_records_alone=ms_osc, kernel=osc.from_q_name,
                    input_bytes_per_step_per_instance=2 * lay.n * 8 + 7 * lay.ndev * esz,
                    hbm_traffic_bytes_per_step_per_instance=_fromq_traffic(osc.from_q_name, B),
                    roofline=dict(bound="fp64_valu", achieved=achieved, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
-                                 frac=achieved / FP64_VALU_PEAK_TFLOPS, flops_per_step_per_instance=flops,
+                                 frac=achieved / FP64_VALU_PEAK_TFLOPS, flops_per_step_per_instance=flops, flops_osc_step=f_how,
                                  note="useful fp64 flops (FMA = 2) of front end + OSC step, profiles/NOTES.md section 4.6; HBM sees "
                                       "568 B in and 200 B out per robot, so the HBM roof is not the bound of this path"),
                    untraced=train_summary(trains, osc.steps_per_launch) if trains is not None else None,
@@ -673,6 +682,11 @@ def main():
             roof["untraced"] = train_summary(osc.time_trains(ntr), spl)
             roof["untraced"]["frac_from_period"] = bytes_launch / (roof["untraced"]["period_us"]["median"] * 1e-6) / 1e9 / HBM_PEAK_GBS
             roof["untraced"]["frac_from_kernel_span"] = bytes_launch / (roof["untraced"]["kernel_span_us"]["median"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            # the same figures as FLAT scalars: the driver's record of the line keeps the scalars of `roofline` / `config` only
+            ut = roof["untraced"]
+            roof.update(untraced_kernel_span_us=ut["kernel_span_us"]["median"], untraced_period_us=ut["period_us"]["median"],
+                        untraced_trains=ut["trains"], sclk_mhz=(ut["sclk_mhz"] or {}).get("median"),
+                        frac_from_kernel_span=ut["frac_from_kernel_span"], frac_from_period=ut["frac_from_period"])
         if prof.get("rocprof_avg_us") and same:
             # the COMMITTED rocprofv3 passes of this command (profiles/; not measured now): kernel trace average and PMC traffic
             roof["committed_profile"] = {
@@ -681,6 +695,8 @@ def main():
                 "frac_rocprof": bytes_launch / (prof["rocprof_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "note": "a kernel trace serialises dispatches: its per-dispatch average corresponds to untraced.kernel_span_us, not to "
                         "ms_per_step x steps_per_launch (= untraced.period_us); profiles/README.md"}
+            roof.update(rocprof_avg_us=prof["rocprof_avg_us"], frac_rocprof=roof["committed_profile"]["frac_rocprof"],
+                        rocprof_source="profiles/hbm_traffic.json (committed kernel trace of this command on another box; not measured in this run)")
         res = dict(value=rate, ms_per_step=elapsed / steps * 1e3, kernel=kname, mode=mode, arith=arith,
                    records="float64" if esz == 8 else "float32", layout=lay, roofline=roof, workload=workload, sustained=sustained)
         osc.step(slot=0)
@@ -839,6 +855,38 @@ def main():
         lay_, gains_, arr_ = chk[0], chk[1], chk[2]
         out["end_to_end"] = measure_end_to_end(BatchedOSC, lay_, gains_, arr_, MODES[args.dtype][0],
                                                args.kernel if args.kernel >= 0 else MODES[args.dtype][2], local_rank)
+    # Flat copies of the nested results: the driver's BENCH record keeps the scalars of `config` / `roofline` / `cpu_baseline` and only the
+    # NAMES of every other top-level key.
+    cfgd = out["config"]
+    if out.get("sustained"):
+        cfgd.update(sustained_value=out["sustained"]["value"], sustained_steps=out["sustained"]["steps"],
+                    sustained_ms_per_step=out["sustained"]["ms_per_step"])
+    if out.get("parity_sample"):
+        ps = out["parity_sample"]
+        cfgd.update(parity_n_checked=ps["n"], parity_max_rel_err=ps["max_rel_err"], parity_n_over_tol=ps["n_over_tol"],
+                    parity_tolerance=ps["tolerance"])
+    if out.get("flags"):
+        cfgd.update(eigen_path_frac=out["flags"]["eigen_path_frac"], truncated_frac=out["flags"]["truncated_frac"],
+                    giveups_to_generic_kernel=out["flags"]["giveups_to_generic_kernel"])
+    fq = out.get("from_q") or {}
+    if "value" in fq:
+        cfgd.update(from_q_value=fq["value"], from_q_ms_per_step=fq.get("ms_per_step"), from_q_kernel=fq.get("kernel"),
+                    from_q_roofline_frac_fp64_valu=(fq.get("roofline") or {}).get("frac"),
+                    from_q_parity_max_rel_err=(fq.get("parity_sample") or {}).get("max_rel_err"))
+    for e_ in out.get("secondary", []):
+        if "value" in e_ and e_.get("records_from") == args.workload:
+            cfgd[f"secondary_{e_['mode']}_value"] = e_["value"]
+            cfgd[f"secondary_{e_['mode']}_roofline_frac"] = e_["roofline"]["frac"]
+            if e_.get("parity_sample"):
+                cfgd[f"secondary_{e_['mode']}_parity_n_over_tol"] = e_["parity_sample"]["n_over_tol"]
+    if out.get("synthetic_dense_records"):
+        cfgd.update(synthetic_dense_value=out["synthetic_dense_records"]["value"],
+                    synthetic_dense_roofline_frac=out["synthetic_dense_records"]["roofline_frac"])
+    e2e = out.get("end_to_end") or {}
+    if isinstance(e2e.get("generate_batched"), dict) and "value" in e2e["generate_batched"]:
+        cfgd.update(end_to_end_host_arrays_value=e2e["generate_batched"]["value"], end_to_end_pcie_GBps=e2e["generate_batched"].get("pcie_GBps"))
+    if isinstance(e2e.get("tick_b1_us"), dict):
+        cfgd["end_to_end_tick_b1_us"] = e2e["tick_b1_us"].get("median")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if comm:

@@ -65,7 +65,13 @@
 extern "C" {
 #endif
 
-#define IRLOSC_ABI_VERSION 1
+/* 2 (round 5): a fused irlosc_step_from_q invalidates the slot's dense records (IRLOSC_ERR_STATE on a later irlosc_step);
+ * IRLOSC_KERNEL_AUTO on float32 records means fp64 arithmetic (row16 "mixed"), never the fp32 group kernel; every n = 25 layout
+ * (k <= 16, ndev <= 4) has a row16-class kernel; irlosc_kernel_class / irlosc_giveup_counts / irlosc_time_trains added;
+ * only the irlosc_* symbols are exported.  _lib.py refuses a library whose version differs. */
+#define IRLOSC_ABI_VERSION 2
+/* the entry points below are the ONLY dynamic symbols of libirlosc.so (built with -fvisibility=hidden) */
+#define IRLOSC_API __attribute__((visibility("default")))
 #define IRLOSC_MAX_DEV 4
 #define IRLOSC_MAX_N 32
 #define IRLOSC_MAX_K 16
@@ -95,13 +101,14 @@ typedef enum {
 #define IRLOSC_FLAG_NONFINITE    64u   /* output contains NaN/Inf */
 
 /* kernel selection (cfg.kernel) */
-#define IRLOSC_KERNEL_AUTO    0   /* fp64 ARITHMETIC always (the reference's, osc.py:49-55; meets 1e-5): row16 where the shape
-                                     has an instantiation -- on float64 records and on float32 records alike -- else generic */
+#define IRLOSC_KERNEL_AUTO    0   /* fp64 ARITHMETIC always (the reference's, osc.py:49-55; meets 1e-5): row16 for every n = 25
+                                     layout -- on float64 records and on float32 records alike -- else generic */
 #define IRLOSC_KERNEL_GENERIC 1   /* one wavefront per instance, LDS tiles, any n<=32, k<=16 */
 #define IRLOSC_KERNEL_GROUP   2   /* EXPLICIT OPT-IN ONLY, never picked by AUTO: fp32 records AND fp32 arithmetic, 4 lanes per
                                      instance (n=25 shapes).  Error ~ eps32 * cond(J M^-1 J^T): does NOT meet the 1e-5 bar */
-#define IRLOSC_KERNEL_ROW16   3   /* fp64 arithmetic: 16 lanes (one DPP row) per instance, broadcast-FMA formulation
-                                     (n=25; (k, ndev) = (13,3), (12,2), (7,3), (6,2)); float32 records = the "mixed" path */
+#define IRLOSC_KERNEL_ROW16   3   /* fp64 arithmetic: 16 lanes (one DPP row) per instance, broadcast-FMA formulation (n = 25;
+                                     instantiations for (k, ndev) = (13,3), (12,2), (7,3), (6,2), KMAX-padded variants for every
+                                     other k <= 16, ndev <= 4: irlosc_kernel_class); float32 records = the "mixed" path */
 
 typedef struct irlosc_cfg {
     int32_t hip_device;                      /* HIP device ordinal */
@@ -122,24 +129,34 @@ typedef struct irlosc_cfg {
 
 typedef struct irlosc_ctx irlosc_ctx;
 
-int irlosc_abi_version(void);
+IRLOSC_API int irlosc_abi_version(void);
 
 /* Number of HIP devices visible, or a negative irlosc_status. */
-int irlosc_device_count(void);
+IRLOSC_API int irlosc_device_count(void);
 
-int irlosc_create(const irlosc_cfg* cfg, irlosc_ctx** out);
-void irlosc_destroy(irlosc_ctx* ctx);
-const char* irlosc_last_error(const irlosc_ctx* ctx); /* ctx may be NULL: last create() error */
-const char* irlosc_kernel_name(const irlosc_ctx* ctx); /* name of the kernel irlosc_step launches */
-const char* irlosc_frontend_name(const irlosc_ctx* ctx); /* name of the kernel irlosc_frontend launches ("" before irlosc_set_model) */
+IRLOSC_API int irlosc_create(const irlosc_cfg* cfg, irlosc_ctx** out);
+IRLOSC_API void irlosc_destroy(irlosc_ctx* ctx);
+IRLOSC_API const char* irlosc_last_error(const irlosc_ctx* ctx); /* ctx may be NULL: last create() error */
+IRLOSC_API const char* irlosc_kernel_name(const irlosc_ctx* ctx); /* name of the kernel irlosc_step launches */
+/* What irlosc_create settled on, for a C caller that asked for IRLOSC_KERNEL_AUTO and wants to know whether it got a throughput
+ * kernel: IRLOSC_CLASS_GENERIC means the one-wavefront-per-instance kernel (any n <= 32: ~25x slower per instance at large batches;
+ * AUTO only lands there when n != 25).  ROW16 = an instantiation for exactly this (k, ndev); ROW16_PADDED = the row16 kernel of the
+ * smallest tier KMAX in {4, 7, 10, 13, 16} >= k, with k and ndev as run-time arguments (same results bit for bit, a few per cent to
+ * a third slower than an exact instantiation would be; the name then ends in "_ndev<d>_pad<KMAX>"). */
+#define IRLOSC_CLASS_GENERIC      0
+#define IRLOSC_CLASS_ROW16        1
+#define IRLOSC_CLASS_ROW16_PADDED 2
+#define IRLOSC_CLASS_GROUP        3
+IRLOSC_API int irlosc_kernel_class(const irlosc_ctx* ctx);
+IRLOSC_API const char* irlosc_frontend_name(const irlosc_ctx* ctx); /* name of the kernel irlosc_frontend launches ("" before irlosc_set_model) */
 
 /* gains[nb][ndev][IRLOSC_GAIN_WORDS] and null_kv[nb] as double; nb == 1 broadcasts one gain set to
  * every instance (kept in constant/SGPR space), nb == max_batch gives per-instance gains. */
-int irlosc_set_gains(irlosc_ctx* ctx, const double* gains, const double* null_kv, int32_t nb);
+IRLOSC_API int irlosc_set_gains(irlosc_ctx* ctx, const double* gains, const double* null_kv, int32_t nb);
 
 /* Host -> device copy of one batch of robot state into resident slot `slot`.  wrench may be NULL.  On the throughput paths
  * an asymmetric M is refused (IRLOSC_ERR_ARG, the slot then holds nothing): see the contracts block above. */
-int irlosc_upload(irlosc_ctx* ctx, int32_t slot, int32_t B, const void* M, const void* J,
+IRLOSC_API int irlosc_upload(irlosc_ctx* ctx, int32_t slot, int32_t B, const void* M, const void* J,
                   const void* dq, const void* bias, const void* ee_pose, const void* wrench);
 /* 1 when the records now in `slot` carry the zero pattern of the compiled Dual-UR5 tree and the fp64 row16 kernel will
  * therefore run its factorisation in the tree-structured form (M = L^T L from the leaves up, fill-in free: Featherstone's
@@ -151,32 +168,32 @@ int irlosc_upload(irlosc_ctx* ctx, int32_t slot, int32_t B, const void* M, const
  * qualify until irlosc_probe_structure has looked.  The form is chosen per slot: a train of irlosc_step_resident that mixes
  * qualifying and other slots is issued as two launches.  Results differ from the dense recursion at rounding level only.  IRLOSC_TREE=0 in the environment turns the
  * form off. */
-int irlosc_slot_structure(const irlosc_ctx* ctx, int32_t slot);
+IRLOSC_API int irlosc_slot_structure(const irlosc_ctx* ctx, int32_t slot);
 /* The same look at records that are already in `slot` (first B instances), for the one path that cannot take it by itself:
  * irlosc_assemble_device on a caller's stream.  Synchronous on the context's stream -- the caller synchronises its own stream
  * first.  Returns 1 / 0 like irlosc_slot_structure (and updates that verdict), or a negative irlosc_status. */
-int irlosc_probe_structure(irlosc_ctx* ctx, int32_t slot, int32_t B);
+IRLOSC_API int irlosc_probe_structure(irlosc_ctx* ctx, int32_t slot, int32_t B);
 /* Host -> device copy of the targets for slot `slot`.  tgt_vel may be NULL (all zero). */
-int irlosc_set_targets(irlosc_ctx* ctx, int32_t slot, int32_t B, const void* tgt_pose,
+IRLOSC_API int irlosc_set_targets(irlosc_ctx* ctx, int32_t slot, int32_t B, const void* tgt_pose,
                        const void* tgt_vel);
 
 /* One control step over the B instances of `slot`: launch, then copy u[B][n] (and flags[B], may
  * be NULL) back to the host buffers.  u_host may be NULL to leave the result on the device. */
-int irlosc_step(irlosc_ctx* ctx, int32_t slot, int32_t B, void* u_host, uint32_t* flags_host);
+IRLOSC_API int irlosc_step(irlosc_ctx* ctx, int32_t slot, int32_t B, void* u_host, uint32_t* flags_host);
 
 /* Benchmark form: `iters` back-to-back steps on resident data, slot = (first_slot + i) % n_slots,
  * no host copies.  Consecutive steps are independent batches, so the throughput path chains several of them
  * into one launch and lets the eigen-path stage of a launch's steps ride in the next launch; everything is
  * complete when the call returns, and irlosc_download then yields the LAST step's outputs.  *ms_total receives
  * the HIP-event time of the whole region on the library's own stream; *ms_kernel_avg = *ms_total / iters. */
-int irlosc_step_resident(irlosc_ctx* ctx, int32_t first_slot, int32_t B, int32_t iters,
+IRLOSC_API int irlosc_step_resident(irlosc_ctx* ctx, int32_t first_slot, int32_t B, int32_t iters,
                          float* ms_total, float* ms_kernel_avg);
 
 /* Roofline support: mean duration of the DOMINANT kernel launch, measured live with one HIP event pair per launch
  * on the library's stream, over about `iters` (<= 256) steps run exactly like irlosc_step_resident.  Group path:
  * the fused launch (stage 1 of irlosc_steps_per_launch() chained steps + the riding stage 2 of the previous
  * launch's steps); generic path: the generic kernel.  Outputs are complete, as after irlosc_step_resident. */
-int irlosc_time_dominant_kernel(irlosc_ctx* ctx, int32_t slot, int32_t B, int32_t iters, float* ms_avg);
+IRLOSC_API int irlosc_time_dominant_kernel(irlosc_ctx* ctx, int32_t slot, int32_t B, int32_t iters, float* ms_avg);
 /* Roofline evidence WITHOUT a tracer ("Timing method"; row16 kernel only).  `ntrains` (<= 4096) consecutive
  * trains of irlosc_steps_per_launch() steps, issued exactly as irlosc_step_resident issues them (slots rotating from first_slot),
  * after one untimed train.  Every train gets (a) its own HIP event pair on the library's stream and (b) the wall clock
@@ -190,18 +207,18 @@ int irlosc_time_dominant_kernel(irlosc_ctx* ctx, int32_t slot, int32_t B, int32_
  * tracer's own serialisation); steady-state period = out[4 (i + 1) + 1] - out[4 i + 1] (what irlosc_step_resident's wall
  * time divided by the number of trains measures).  from_q != 0: trains of irlosc_step_resident_from_q (the stamps are the OSC
  * kernel's; the walk in front of it is inside the period and the event pair). */
-int irlosc_time_trains(irlosc_ctx* ctx, int32_t first_slot, int32_t B, int32_t ntrains, int32_t from_q, double* out);
+IRLOSC_API int irlosc_time_trains(irlosc_ctx* ctx, int32_t first_slot, int32_t B, int32_t ntrains, int32_t from_q, double* out);
 /* How many instances the most recent step (out[0]) / the steps of the most recent train (out[0 .. irlosc_steps_per_launch() - 1]) handed
  * from the row16 kernel's in-wave eigen stage to the generic kernel -- task spaces that lose MORE than three directions at once
  * (osc.py:55 with four or more singular values under the cut).  Results are the same either way; throughput is not: the give-up
  * pass is a serial tail of its train (one instance costs ~27 us per train, a batch dominated by them runs at 4.5e6 steps/s instead of
  * 6e8).  Zero on physical states of the Dual-UR5 in every sweep so far; a caller whose task sets are rank-deficient by construction
  * can watch this counter.  out[8]; all zero on the other kernels.  (A train that mixes tree-form and dense slots is two launches;
- * the counters are those of the second.)  Synchronises the context's stream. */
-int irlosc_giveup_counts(irlosc_ctx* ctx, int32_t* out);
+ * every step still reports at its own index of the train.)  Synchronises the context's stream. */
+IRLOSC_API int irlosc_giveup_counts(irlosc_ctx* ctx, int32_t* out);
 /* Steps chained in one launch by irlosc_step_resident / irlosc_time_dominant_kernel (1 on the generic path):
  * the algorithmic bytes of one dominant launch = this many steps' worth. */
-int irlosc_steps_per_launch(const irlosc_ctx* ctx);
+IRLOSC_API int irlosc_steps_per_launch(const irlosc_ctx* ctx);
 
 /* State assembly on the GPU (what Robot.get_all_states() / Device.get_state() do per robot on the host:
  * robot.py:44-72,125-136; device.py:115-170): one batch of RAW simulator arrays in, the resident records of slot
@@ -221,34 +238,34 @@ typedef struct irlosc_raw_desc {
     int32_t ft_force0[IRLOSC_MAX_DEV];        /* first sensordata index of the force triple, -1 = no sensor (device.py:139-170) */
     int32_t ft_torque0[IRLOSC_MAX_DEV];
 } irlosc_raw_desc;
-int irlosc_upload_raw(irlosc_ctx* ctx, int32_t slot, int32_t B, const irlosc_raw_desc* desc, const void* qM,
+IRLOSC_API int irlosc_upload_raw(irlosc_ctx* ctx, int32_t slot, int32_t B, const irlosc_raw_desc* desc, const void* qM,
                       const void* qvel, const void* qfrc_bias, const void* jacp, const void* jacr,
                       const void* ee_xpos, const void* ee_xquat, const void* site_xmat, const void* sensordata);
 
 /* Same assembly for simulators whose state already lives in HBM: every array pointer is a DEVICE pointer (layouts
  * as above), hip_stream a hipStream_t (NULL = the context's stream).  No copies; the call returns after enqueueing the
  * kernel, and steps of this context issued on the same stream see the assembled slot. */
-int irlosc_assemble_device(irlosc_ctx* ctx, int32_t slot, int32_t B, const irlosc_raw_desc* desc, const void* d_qM,
+IRLOSC_API int irlosc_assemble_device(irlosc_ctx* ctx, int32_t slot, int32_t B, const irlosc_raw_desc* desc, const void* d_qM,
                            const void* d_qvel, const void* d_qfrc_bias, const void* d_jacp, const void* d_jacr,
                            const void* d_ee_xpos, const void* d_ee_xquat, const void* d_site_xmat,
                            const void* d_sensordata, void* hip_stream);
 
-int irlosc_download(irlosc_ctx* ctx, int32_t B, void* u_host, uint32_t* flags_host);
-int irlosc_sync(irlosc_ctx* ctx);          /* waits for the context's stream */
-int irlosc_device_sync(irlosc_ctx* ctx);   /* hipDeviceSynchronize on the context's GPU (bench bracket) */
+IRLOSC_API int irlosc_download(irlosc_ctx* ctx, int32_t B, void* u_host, uint32_t* flags_host);
+IRLOSC_API int irlosc_sync(irlosc_ctx* ctx);          /* waits for the context's stream */
+IRLOSC_API int irlosc_device_sync(irlosc_ctx* ctx);   /* hipDeviceSynchronize on the context's GPU (bench bracket) */
 
 /* One control tick in ONE call (what OSC.generate does per tick for B robots, osc.py:120-210): the records are packed
  * into a pinned staging block, cross PCIe in one copy, the step runs on them in place, u[B][n] and flags[B] come back
  * in one copy, and the call synchronises once.  Same record layouts as irlosc_upload / irlosc_set_targets; wrench and
  * tgt_vel may be NULL.  Does not touch the resident slots. */
-int irlosc_tick(irlosc_ctx* ctx, int32_t B, const void* M, const void* J, const void* dq, const void* bias,
+IRLOSC_API int irlosc_tick(irlosc_ctx* ctx, int32_t B, const void* M, const void* J, const void* dq, const void* bias,
                 const void* ee_pose, const void* wrench, const void* tgt_pose, const void* tgt_vel, void* u_host,
                 uint32_t* flags_host);
 
 /* Raw-device-pointer form for callers that already hold the state in HBM (e.g. an on-GPU
  * simulator): same layouts as above, all pointers are device pointers, hip_stream is a
  * hipStream_t (NULL = the context's stream).  No copies, no synchronisation. */
-int irlosc_step_device(irlosc_ctx* ctx, int32_t B, const void* dM, const void* dJ, const void* ddq,
+IRLOSC_API int irlosc_step_device(irlosc_ctx* ctx, int32_t B, const void* dM, const void* dJ, const void* ddq,
                        const void* dbias, const void* dee_pose, const void* dtgt_pose,
                        const void* dtgt_vel, const void* dwrench, void* du, uint32_t* dflags,
                        void* hip_stream);
@@ -285,36 +302,37 @@ typedef struct irlosc_model {
  * max_batch robots.  A model with the compiled Dual-UR5 tree shape selects the lane-per-robot kernel -- its side buffer of
  * ceil(max_batch / 64) x 266 x 512 bytes (139 MB at 65 536 robots) is allocated by the first irlosc_frontend; if that fails the
  * context drops to the generic kernel -- any other tree the generic kernel. */
-int irlosc_set_model(irlosc_ctx* ctx, const irlosc_model* model);
+IRLOSC_API int irlosc_set_model(irlosc_ctx* ctx, const irlosc_model* model);
 /* Joint positions and velocities of one batch into resident slot `slot`: qpos[B][n], qvel[B][n], always double. */
-int irlosc_upload_q(irlosc_ctx* ctx, int32_t slot, int32_t B, const double* qpos, const double* qvel);
+IRLOSC_API int irlosc_upload_q(irlosc_ctx* ctx, int32_t slot, int32_t B, const double* qpos, const double* qvel);
 /* Run the front end on the slot's (qpos, qvel): fills its M, J, dq, bias, ee_pose records (asynchronous, context's
  * stream); irlosc_set_targets + irlosc_step then work as after irlosc_upload.  Afterwards the slot holds the records of
  * exactly B robots (an earlier, larger upload no longer vouches for the instances beyond B); the wrench of the slot stays what
  * the last irlosc_upload / irlosc_upload_raw wrote (undefined for instances beyond THAT call's B). */
-int irlosc_frontend(irlosc_ctx* ctx, int32_t slot, int32_t B);
+IRLOSC_API int irlosc_frontend(irlosc_ctx* ctx, int32_t slot, int32_t B);
 /* Copy records of slot `slot` back to the host (any pointer may be NULL): what irlosc_upload put there, or what the front
  * end / irlosc_upload_raw assembled on the GPU.  Same layouts and element type as irlosc_upload. */
-int irlosc_download_records(irlosc_ctx* ctx, int32_t slot, int32_t B, void* M, void* J, void* dq, void* bias,
+IRLOSC_API int irlosc_download_records(irlosc_ctx* ctx, int32_t slot, int32_t B, void* M, void* J, void* dq, void* bias,
                             void* ee_pose);
 /* One control step from joint coordinates: irlosc_upload_q + irlosc_set_targets, then this (results as after irlosc_step).
  * With the compiled Dual-UR5 tree shape and the fp64 row16 kernel this is the FUSED path: the lane-per-robot walk leaves only
- * the structural non-zeros of M and J, the bias forces and the EE poses in a compact exchange buffer (2.4 KB per robot,
+ * the structural non-zeros of M and J, the bias forces and the EE poses in a compact exchange buffer (2.6 KB per robot,
  * written once, coalesced) and the OSC kernel gathers its operands from there -- the dense records of the slot are neither
  * written nor read -- except that robots the in-kernel eigen stage hands to the generic kernel get theirs from the
  * wave-per-robot front end, into the slot.  AFTER A FUSED STEP THE SLOT THEREFORE HOLDS NO RECORDS: irlosc_step,
  * irlosc_step_resident and irlosc_download_records on it fail with IRLOSC_ERR_STATE until irlosc_frontend / irlosc_upload* fills
  * it again (its joint coordinates and targets stay).  Other models / kernels: irlosc_frontend + irlosc_step (records left behind).
- * The exchange buffers (ceil(max_batch / 64) x 318 x 512 bytes each) are allocated by the first fused step: one for this call,
+ * The exchange buffers (ceil(max_batch / 64) x 334 x 512 bytes each: 318 entries of the walk + IRLOSC_MAX_K rows for the gained task error
+ * that a task pass between the walk and the OSC kernel leaves; 175 MB at 65 536 robots) are allocated by the first fused step: one for this call,
  * one per step of a train (8) for irlosc_step_resident_from_q; if that allocation fails the context drops to the path through
  * dense records. */
-int irlosc_step_from_q(irlosc_ctx* ctx, int32_t slot, int32_t B, void* u_host, uint32_t* flags_host);
+IRLOSC_API int irlosc_step_from_q(irlosc_ctx* ctx, int32_t slot, int32_t B, void* u_host, uint32_t* flags_host);
 /* What irlosc_step_from_q / irlosc_step_resident_from_q launch ("" before irlosc_set_model). */
-const char* irlosc_from_q_name(const irlosc_ctx* ctx);
+IRLOSC_API const char* irlosc_from_q_name(const irlosc_ctx* ctx);
 /* Benchmark form of the whole path from joint coordinates: `iters` steps like irlosc_step_from_q on resident (qpos, qvel),
  * chained into trains on the fused path, slot = (first_slot + i) % n_slots; HIP-event time of the region on the library's
  * stream. */
-int irlosc_step_resident_from_q(irlosc_ctx* ctx, int32_t first_slot, int32_t B, int32_t iters, float* ms_total,
+IRLOSC_API int irlosc_step_resident_from_q(irlosc_ctx* ctx, int32_t first_slot, int32_t B, int32_t iters, float* ms_total,
                                 float* ms_step_avg);
 
 /* ---- multi-GPU: the final throughput reduction -----------------------------------------------
@@ -325,16 +343,16 @@ int irlosc_step_resident_from_q(irlosc_ctx* ctx, int32_t first_slot, int32_t B, 
  * handed to the other ranks by the host program (irl_control_amd/sharding.py: a file next to MASTER_PORT). */
 typedef struct irlosc_comm irlosc_comm;
 #define IRLOSC_COMM_ID_BYTES 128
-int irlosc_comm_unique_id(uint8_t id_out[IRLOSC_COMM_ID_BYTES]);
-int irlosc_comm_create(int32_t hip_device, int32_t rank, int32_t world, const uint8_t id[IRLOSC_COMM_ID_BYTES],
+IRLOSC_API int irlosc_comm_unique_id(uint8_t id_out[IRLOSC_COMM_ID_BYTES]);
+IRLOSC_API int irlosc_comm_create(int32_t hip_device, int32_t rank, int32_t world, const uint8_t id[IRLOSC_COMM_ID_BYTES],
                        irlosc_comm** out);
-void irlosc_comm_destroy(irlosc_comm* comm);
-const char* irlosc_comm_last_error(const irlosc_comm* comm);   /* comm may be NULL: last create()/unique_id() error */
+IRLOSC_API void irlosc_comm_destroy(irlosc_comm* comm);
+IRLOSC_API const char* irlosc_comm_last_error(const irlosc_comm* comm);   /* comm may be NULL: last create()/unique_id() error */
 /* In place: *steps_sum <- sum over ranks, *elapsed_max <- max over ranks (two ncclAllReduce on the comm's stream,
  * then a stream sync).  Doubles as the barrier of the benchmark bracket. */
-int irlosc_bench_allreduce(irlosc_comm* comm, double* steps_sum, double* elapsed_max);
+IRLOSC_API int irlosc_bench_allreduce(irlosc_comm* comm, double* steps_sum, double* elapsed_max);
 /* all[r] <- rank r's `mine` (ncclAllGather): per-shard output checksums, to show that sharding changes no bit. */
-int irlosc_comm_allgather_u64(irlosc_comm* comm, uint64_t mine, uint64_t* all);
+IRLOSC_API int irlosc_comm_allgather_u64(irlosc_comm* comm, uint64_t mine, uint64_t* all);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,10 @@ EXPORTS = ["irlosc_abi_version", "irlosc_device_count", "irlosc_create", "irlosc
            "irlosc_tick", "irlosc_comm_unique_id", "irlosc_comm_create", "irlosc_comm_destroy",
            "irlosc_comm_last_error", "irlosc_bench_allreduce", "irlosc_comm_allgather_u64", "irlosc_set_model",
            "irlosc_upload_q", "irlosc_frontend", "irlosc_step_resident_from_q", "irlosc_download_records",
-           "irlosc_step_from_q", "irlosc_from_q_name", "irlosc_slot_structure", "irlosc_probe_structure", "irlosc_time_trains", "irlosc_giveup_counts"]
+           "irlosc_step_from_q", "irlosc_from_q_name", "irlosc_slot_structure", "irlosc_probe_structure", "irlosc_time_trains", "irlosc_giveup_counts",
+           "irlosc_kernel_class"]
+ABI_VERSION = 2
+CLASS_GENERIC, CLASS_ROW16, CLASS_ROW16_PADDED, CLASS_GROUP = 0, 1, 2, 3
 COMM_ID_BYTES = 128
 
 
@@ -71,6 +74,9 @@ def load():
     lib = C.CDLL(LIB_PATH)
     vp, i32 = C.c_void_p, C.c_int32
     lib.irlosc_abi_version.restype = C.c_int
+    if lib.irlosc_abi_version() != ABI_VERSION:
+        raise IrloscError(f"{LIB_PATH} has ABI version {lib.irlosc_abi_version()}, this binding is written for {ABI_VERSION}: "
+                          "rebuild with `python __graft_entry__.py`")
     lib.irlosc_device_count.restype = C.c_int
     lib.irlosc_create.argtypes = [C.POINTER(Cfg), C.POINTER(vp)]
     lib.irlosc_destroy.argtypes = [vp]
@@ -79,6 +85,8 @@ def load():
     lib.irlosc_last_error.restype = C.c_char_p
     lib.irlosc_kernel_name.argtypes = [vp]
     lib.irlosc_kernel_name.restype = C.c_char_p
+    lib.irlosc_kernel_class.argtypes = [vp]
+    lib.irlosc_kernel_class.restype = C.c_int
     lib.irlosc_frontend_name.argtypes = [vp]
     lib.irlosc_frontend_name.restype = C.c_char_p
     lib.irlosc_set_gains.argtypes = [vp, vp, vp, i32]

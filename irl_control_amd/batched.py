@@ -32,11 +32,11 @@ class BatchedOSC:
                                    f"{self.lib.irlosc_last_error(None).decode()}")
         self._h = h
         self._B = [0] * self.n_slots
-        if kernel == _lib.KERNEL_AUTO and self.max_batch >= 1024 and "generic" in self.kernel_name:
+        if kernel == _lib.KERNEL_AUTO and self.max_batch >= 1024 and self.kernel_class == _lib.CLASS_GENERIC:
             import warnings
-            warnings.warn(f"layout (n={layout.n}, k={layout.k}, ndev={layout.ndev}) has no throughput instantiation: "
+            warnings.warn(f"layout (n={layout.n}, k={layout.k}, ndev={layout.ndev}) has no throughput kernel: "
                           f"{self.kernel_name} (one wavefront per instance, ~25x slower than osc_row16 at this batch size); "
-                          "row16 shapes: n=25 with (k, ndev) in {(13,3), (12,2), (7,3), (6,2)}", RuntimeWarning, stacklevel=2)
+                          "the row16 kernels take every layout of an n=25 robot (k <= 16, ndev <= 4)", RuntimeWarning, stacklevel=2)
 
     # -- plumbing ---------------------------------------------------------------------------------
     def _chk(self, rc):
@@ -63,6 +63,12 @@ class BatchedOSC:
     @property
     def kernel_name(self) -> str:
         return self.lib.irlosc_kernel_name(self._h).decode()
+
+    @property
+    def kernel_class(self) -> int:
+        """_lib.CLASS_GENERIC / CLASS_ROW16 (an instantiation for exactly this layout) / CLASS_ROW16_PADDED (row16 kernel of the
+        next tier KMAX >= k, k and ndev at run time) / CLASS_GROUP: irlosc_kernel_class."""
+        return int(self.lib.irlosc_kernel_class(self._h))
 
     @property
     def frontend_name(self) -> str:

@@ -101,6 +101,7 @@ struct irlosc_ctx {
     int gains_nb = 0;
     unsigned long long* ddbg = nullptr;  // IRLOSC_PHASE_TIMING=1: 8 cycle stamps + 2 wall-clock stamps per stage-1 wave
     int kernel = IRLOSC_KERNEL_GENERIC;
+    int kernel_class = IRLOSC_CLASS_GENERIC;
     std::string kernel_name;
     std::string err;
 };
@@ -148,6 +149,7 @@ extern "C" const char* irlosc_frontend_name(const irlosc_ctx* ctx) {
 extern "C" const char* irlosc_kernel_name(const irlosc_ctx* ctx) {
     return ctx ? ctx->kernel_name.c_str() : "";
 }
+extern "C" int irlosc_kernel_class(const irlosc_ctx* ctx) { return ctx ? ctx->kernel_class : IRLOSC_ERR_ARG; }
 
 static int validate(const irlosc_cfg* c, int* k_out) {
     if (!c) return fail(nullptr, IRLOSC_ERR_ARG, "cfg is NULL");
@@ -334,6 +336,12 @@ extern "C" int irlosc_create(const irlosc_cfg* cfg, irlosc_ctx** out) {
              c->kernel == IRLOSC_KERNEL_GROUP ? "osc_group" : c->kernel == IRLOSC_KERNEL_ROW16 ? "osc_row16" : "osc_generic",
              mixed ? "f32in_f64" : cfg->dtype == IRLOSC_F64 ? "f64" : "f32", cfg->n, k);
     c->kernel_name = nm;
+    c->kernel_class = c->kernel == IRLOSC_KERNEL_GROUP ? IRLOSC_CLASS_GROUP : c->kernel == IRLOSC_KERNEL_GENERIC ? IRLOSC_CLASS_GENERIC
+                      : row16_kernel_exact(cfg->n, k, cfg->ndev) ? IRLOSC_CLASS_ROW16 : IRLOSC_CLASS_ROW16_PADDED;
+    if (c->kernel_class == IRLOSC_CLASS_ROW16_PADDED) {      // the tier the launches will pick (tu_row16_pad_impl.hpp)
+        snprintf(nm, sizeof nm, "_ndev%d_pad%d", cfg->ndev, row16_pad_tier(k));
+        c->kernel_name += nm;
+    }
     rc = create_impl(c);
     if (rc) {
         free_all(c);
@@ -753,14 +761,19 @@ static int flush_pending(irlosc_ctx* c, hipStream_t st) {
 // up on (net of eigen-candidates full, degenerate A) are recomputed by the generic kernel (Jacobi, fp64 arithmetic) from
 // the lists it leaves behind.
 template <typename T>
-static int row16_train(irlosc_ctx* c, const KParams<T>* ps, int n, bool tree, hipStream_t st) {
+static int row16_train(irlosc_ctx* c, const KParams<T>* ps, int n, bool tree, hipStream_t st, const int* pos = nullptr,
+                       bool reset = true) {
+    // pos[i] = step of the whole train that sub-train step i is (a train that mixes tree-form and dense slots goes out as two
+    // sub-trains): give-up list and counter are those of the ORIGINAL step, and only the first sub-train zeroes the counters, so
+    // that irlosc_giveup_counts reports every step of the train at its own index.
     if (n < 1 || n > R16_TRAIN) return fail(c, IRLOSC_ERR_STATE, "train of %d steps", n);
     Row16Train<T> tr;
     memset(&tr, 0, sizeof tr);
-    HIPCHK(c, hipMemsetAsync(c->dr16_count, 0, R16_TRAIN * sizeof(int32_t), st));
+    if (reset) HIPCHK(c, hipMemsetAsync(c->dr16_count, 0, R16_TRAIN * sizeof(int32_t), st));
     for (int i = 0; i < n; ++i) {
+        const int o = pos ? pos[i] : i;
         tr.p[i] = ps[i];
-        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[i], c->dr16_count + i, nullptr, nullptr, nullptr, c->span_next};
+        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[o], c->dr16_count + o, nullptr, nullptr, nullptr, c->span_next};
     }
     if (c->tev_begin) HIPCHK(c, hipEventRecord(c->tev_begin, st));
     int rc = launch_row16<T>(tr, n, tree, st);
@@ -923,12 +936,14 @@ static int row16_resident(irlosc_ctx* c, int first_slot, int B, int iters, const
     while (done < iters) {
         const int n = std::min((int)R16_TRAIN, iters - done);
         KParams<T> ps[2][R16_TRAIN];        // [1]: steps whose slot qualifies for the tree form, [0]: the others
+        int pos[2][R16_TRAIN];              // step of the train each sub-train step is
         int cnt[2] = {0, 0};
         for (int i = 0; i < n; ++i) {
             const int slot = (first_slot + done + i) % c->cfg.n_slots;
             int rcf = check_slot_filled(c, slot, B);
             if (rcf) return rcf;
             const int kind = slot_tree(c, slot) ? 1 : 0;
+            pos[kind][cnt[kind]] = i;
             fill_params<T>(c, ps[kind][cnt[kind]++], B, c->dM[slot], c->dJ[slot], c->ddq[slot], c->dbias[slot], c->dee[slot], c->dtgt[slot],
                            c->has_tvel[slot] ? c->dtvel[slot] : nullptr, c->has_wrench[slot] ? c->dwrench[slot] : nullptr,
                            c->du_set[i], c->dflags_set[i]);
@@ -940,7 +955,7 @@ static int row16_resident(irlosc_ctx* c, int first_slot, int B, int iters, const
             if (!cnt[kind]) continue;
             c->tev_begin = kind == first ? eb : nullptr;              // the event pair brackets the whole train
             c->tev_end = kind == last ? ee : nullptr;
-            int rc = row16_train<T>(c, ps[kind], cnt[kind], kind == 1, c->stream);
+            int rc = row16_train<T>(c, ps[kind], cnt[kind], kind == 1, c->stream, pos[kind], kind == first);
             c->tev_begin = c->tev_end = nullptr;
             if (rc) return rc;
         }
@@ -1309,7 +1324,7 @@ static int check_slot_q(irlosc_ctx* c, int slot, int B) {
 }
 
 // Exchange buffers of the fused path: allocated by the first fused step, and only as many as the longest train so far needs
-// (a caller of irlosc_step_from_q uses one: 166 MB at 65 536 robots; the benchmark form all R16_TRAIN: 1.33 GB) -- a context
+// (a caller of irlosc_step_from_q uses one: 334 entries x 512 B per 64 robots = 175 MB at 65 536 robots; the benchmark form all R16_TRAIN: 1.4 GB) -- a context
 // that only ever runs irlosc_frontend + irlosc_step pays nothing.  Out of memory: the fused path is switched off for this
 // context and the caller continues through dense records (-> 1).
 static int ensure_xside(irlosc_ctx* c, int n) {
@@ -1326,9 +1341,10 @@ static int ensure_xside(irlosc_ctx* c, int n) {
     return 0;
 }
 
-// Fused path: one train of n steps from joint coordinates (step i: slot slots[i], outputs of set i).  Two launches -- the
+// Fused path: one train of n steps from joint coordinates (step i: slot slots[i], outputs of set i).  Three launches -- the
 // lane-per-robot walk leaves the structural non-zeros of M / J, the bias forces and the EE poses in the compact exchange
-// buffer of each step; the row16 kernel (FROMQ) gathers its operands from there -- and the give-up pass: the few robots the
+// buffer of each step; the task pass (one lane per (robot, device)) adds the k gained task-error rows; the row16 kernel (FROMQ)
+// stages a block's lines in LDS and gathers its operands from there -- and, fourth, the give-up pass: the few robots the
 // eigen stage hands over get their dense records from the wave-per-robot front end (worklist form) and go through the
 // generic kernel like on the record path.  Dense M / J exist in HBM for those robots only.
 template <typename T>

@@ -25,6 +25,17 @@ template <typename TIN>
 int launch_row16_fromq(const Row16Train<TIN>& tr, int nsteps, hipStream_t st);
 template <typename TIN>
 int launch_row16_worklist(const Row16Train<TIN>& tr, int nsteps, int32_t* reset, hipStream_t st);
+// tu_row16_pad_{dense,tree,fromq}_{f64,f32}.hip -- the KMAX-padded variants launch_row16 / launch_row16_fromq fall through to for the
+// layouts without an instantiation of their own (explicit specialisations, one translation unit each)
+template <typename TIN> int launch_row16_pad_dense(const Row16Train<TIN>& tr, int nsteps, hipStream_t st);
+template <typename TIN> int launch_row16_pad_tree(const Row16Train<TIN>& tr, int nsteps, hipStream_t st);
+template <typename TIN> int launch_row16_pad_fromq(const Row16Train<TIN>& tr, int nsteps, hipStream_t st);
+template <> int launch_row16_pad_dense<double>(const Row16Train<double>&, int, hipStream_t);
+template <> int launch_row16_pad_dense<float>(const Row16Train<float>&, int, hipStream_t);
+template <> int launch_row16_pad_tree<double>(const Row16Train<double>&, int, hipStream_t);
+template <> int launch_row16_pad_tree<float>(const Row16Train<float>&, int, hipStream_t);
+template <> int launch_row16_pad_fromq<double>(const Row16Train<double>&, int, hipStream_t);
+template <> int launch_row16_pad_fromq<float>(const Row16Train<float>&, int, hipStream_t);
 
 // tu_frontend.hip / tu_frontend_lane.hip -- rigid-body front end (osc_frontend.hpp, osc_frontend_lane.hpp); TOUT = record type
 struct FeModel;

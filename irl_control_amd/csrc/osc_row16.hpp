@@ -37,6 +37,7 @@
 // (kept in program order), (2) a DPP source is either produced two or more instructions earlier by this file's own
 // asm or sits behind a sched_barrier, and (3) the first DPP instruction after a sched_barrier carries "s_nop 1".
 #pragma once
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -157,9 +158,12 @@ __device__ __forceinline__ double sqrt_fast(double x) { return x > 0.0 ? x * rsq
 
 // In-place L~ D L~^T of A + sigma I.  Out: F[j] in lane c = L~[c][j] for c > j, else 0 (row c of L~); G[i] in lane c =
 // L~[i][c] for i > c, else 0 (column c of L~); invd_own = 1 / d_c in lane c; pd = all pivots positive; det = prod d.
-template <int K>
+// PAD (the KMAX-padded variant of the kernel, see osc_row16_kernel): only the leading kr x kr block is the task space; rows and
+// columns kr .. K - 1 of A are exact zeros.  Their pivots are taken as 1 and stay out of `pd` and `det`, their columns of L~ are
+// zero: the factorisation of the real block is bit for bit what the K = kr instantiation computes.
+template <int K, bool PAD = false>
 __device__ __forceinline__ void ldl16(double (&A)[K], const int l, const double sigma, double (&F)[K], double (&G)[K],
-                                      double& invd_own, bool& pd, double& det) {
+                                      double& invd_own, bool& pd, double& det, const int kr = K) {
     pd = true;
     det = 1.0;
     invd_own = 0.0;
@@ -167,9 +171,10 @@ __device__ __forceinline__ void ldl16(double (&A)[K], const int l, const double 
     static_for<0, K>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         double d = bc_nop<j>(A[j]) + sigma;
-        const bool npd = !(d > 0.0);                   // also catches NaN
+        const bool real = !PAD || j < kr;              // (scalar)
+        const bool npd = real && !(d > 0.0);           // also catches NaN
         pd = pd && !npd;
-        d = npd ? 1.0 : d;      // the verdict is in: what a non-positive pivot leaves behind is never used (the caller refactors
+        d = (npd || !real) ? 1.0 : d;      // the verdict is in: what a non-positive pivot leaves behind is never used (the caller refactors
                                 // with a shift or only asked for `pd`); 1 keeps the rest of the recursion finite
         det *= d;
         const double invd = rcp_refined(d);
@@ -223,10 +228,10 @@ __device__ __forceinline__ double matvec16(const double x, const double (&Ac)[K]
 //   t = P A^-1 P w with P the projector off the eigenvectors at or under 1e-5 lambda_max.  Net full: give up (-> Jacobi).
 // Every quantity is uniform over the 16 lanes of an instance and frozen at the instance's own convergence, so a
 // result never depends on the other instances of the wave (sharding a batch differently changes no bit).
-template <int K>
+template <int K, bool PAD = false>
 __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], double (&G)[K], double& invd_own, const bool pdA,
                                         const double nA2, const double trA, const double w, const int l, const bool flagged,
-                                        double& t, uint32_t& fl, bool& giveup) {
+                                        double& t, uint32_t& fl, bool& giveup, const int kr = K) {
     const double hi = sqrt(nA2);
     double sigma = 0.0;
     giveup = flagged && !(hi > 0.0 && t_finite(hi));
@@ -243,7 +248,7 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
         for (int r = 0; r < K; ++r) A2[r] = Ac[r];
         const bool use = flagged && broken;
         sigma = use ? hi * 0x1p-40 : 0.0;
-        ldl16<K>(A2, l, sigma, F, G, invd_own, pd2, det2);
+        ldl16<K, PAD>(A2, l, sigma, F, G, invd_own, pd2, det2, kr);
         giveup = giveup || (use && !pd2);
     }
     // bracket of lambda_max: the largest diagonal entry is a Rayleigh quotient, the Frobenius norm an upper bound
@@ -271,7 +276,7 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
         if (!__any(active)) break;
         int lq = l;
         asm volatile("" : "+v"(lq));       // (keeps the four start vectors from being computed ahead of the stage and carried through it)
-        double x = lq < K ? 0.3 + 0.1 * (double)(((lq + 3 * slot) * 5) % 7) - 0.05 * (double)slot : 0.0;
+        double x = lq < (PAD ? kr : K) ? 0.3 + 0.1 * (double)(((lq + 3 * slot) * 5) % 7) - 0.05 * (double)slot : 0.0;
         double lam = 0.0, lam_prev = -1.0;
         bool fin = !active;
         for (int it = 0; it < IRLOSC_EIG_MAXIT; ++it) {
@@ -396,7 +401,7 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
             bool pdt = true;
 #pragma unroll
             for (int r = 0; r < K; ++r) A2[r] = -Ac[r];
-            ldl16<K>(A2, l, ask ? th[i] * 1e5 : 4.0 * hi, Ft, Gt, invt, pdt, dett);
+            ldl16<K, PAD>(A2, l, ask ? th[i] * 1e5 : 4.0 * hi, Ft, Gt, invt, pdt, dett, kr);
             cut = cut || (ask && !pdt);
         }
         v[i] = cut ? v[i] : 0.0;
@@ -662,9 +667,19 @@ __device__ __forceinline__ void tree_chains(double& m0, double& m1, double& tj, 
     }
 }
 
-template <int K, int NDEV, typename TIN, int N, bool FROMQ = false, class TOPO = void>
-__global__ __launch_bounds__(FROMQ ? 256 : 64, IRLOSC_R16_WAVES) void osc_row16_kernel(const Row16Train<TIN> tr) {
+//
+// PAD: the KMAX-padded variant for every layout without an instantiation of its own (osc.py:134-138 stacks J over WHATEVER targets
+// are passed, examples/ps_move_example.py:137-150 re-masks a device between ticks): K is then an upper bound KMAX >= p.k, NDEV is
+// IRLOSC_MAX_DEV, and the real k = p.k and ndev = p.ndev are kernel arguments (scalar registers).  Rows k .. KMAX - 1 of J are loaded
+// from the page of zeros, so Y, A = Y^T Y, w and t carry exact zeros there; the pivots of the padded block are taken as 1 and kept out
+// of det, trace(A^-1), ||A||_F and the inertia counts (ldl16), the start vectors of the inverse iteration are zero there (and stay
+// zero: A is block diagonal), so det, lambda_max, the 1e-5 cut and every flag are those of the k x k problem -- and since padding only
+// ever adds exact zeros to sums, the torques equal those of a K = k instantiation bit for bit.
+template <int K, int NDEV, typename TIN, int N, bool FROMQ = false, class TOPO = void, bool PAD = false>
+__global__ __launch_bounds__(FROMQ ? 256 : 64, K > 13 ? 2 : IRLOSC_R16_WAVES)      // (K = 14 .. 16 spills at three waves per SIMD: two)
+void osc_row16_kernel(const Row16Train<TIN> tr) {
     using namespace r16;
+    static_assert(!PAD || NDEV == IRLOSC_MAX_DEV, "the padded variant takes the number of devices at run time");
     constexpr bool TREE = !std::is_void_v<TOPO>;      // the records carry the zero pattern of this tree (fused path: by
                                                       // construction; dense records: verified when they were uploaded)
     static_assert(!FROMQ || TREE, "the fused path exists for a compiled tree shape");
@@ -673,6 +688,8 @@ __global__ __launch_bounds__(FROMQ ? 256 : 64, IRLOSC_R16_WAVES) void osc_row16_
     constexpr int NW = FROMQ ? 4 : 1;
     const KParams<TIN>& p = tr.p[blockIdx.y];
     const Row16Extra& x = tr.x[blockIdx.y];
+    const int kr = PAD ? p.k : K;              // real task rows / target devices (scalar; compile-time constants unless PAD)
+    const int nd = PAD ? p.ndev : NDEV;
     using TM = std::conditional_t<FROMQ, double, TIN>;      // type the M / J / dq / bias operands arrive in
     static_assert(N > 16 && N <= 32 && K >= 1 && K <= 16 && NDEV >= 1 && NDEV <= 4, "shape");
     constexpr int N1 = N - 16;                 // real rows in slot 1
@@ -753,16 +770,16 @@ __global__ __launch_bounds__(FROMQ ? 256 : 64, IRLOSC_R16_WAVES) void osc_row16_
     // the big loads are still arriving, instead of behind all of them.
     const bool has_tv = p.tvel != nullptr;
     const int dv = l >> 2, ang_id = l & 3;
-    const int dd = dv < NDEV ? dv : NDEV - 1;
+    const int dd = dv < nd ? dv : nd - 1;
     TM ee_in[7];
     TIN tg_in[7], g_in[IRLOSC_GAIN_WORDS], tv_in[6];
     {
-        const TIN* __restrict__ tgp = p.tgt + ((size_t)bc * NDEV + dd) * 7;
-        const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * NDEV * IRLOSC_GAIN_WORDS : 0) + dd * IRLOSC_GAIN_WORDS;
+        const TIN* __restrict__ tgp = p.tgt + ((size_t)bc * nd + dd) * 7;
+        const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * nd * IRLOSC_GAIN_WORDS : 0) + dd * IRLOSC_GAIN_WORDS;
         if constexpr (FROMQ) {      // part 1 of the task signal was computed by the task pass: only the velocity gain is needed here
             g_in[1] = gp[1];
         } else {
-            const TIN* __restrict__ eep = p.ee + ((size_t)bc * NDEV + dd) * 7;
+            const TIN* __restrict__ eep = p.ee + ((size_t)bc * nd + dd) * 7;
 #pragma unroll
             for (int i = 0; i < 7; ++i) ee_in[i] = eep[i];
 #pragma unroll
@@ -770,7 +787,7 @@ __global__ __launch_bounds__(FROMQ ? 256 : 64, IRLOSC_R16_WAVES) void osc_row16_
 #pragma unroll
             for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) g_in[i] = gp[i];
         }
-        const TIN* __restrict__ tvp = has_tv ? p.tvel + ((size_t)bc * NDEV + dd) * 6 : zeros;      // all six together: as a
+        const TIN* __restrict__ tvp = has_tv ? p.tvel + ((size_t)bc * nd + dd) * 6 : zeros;      // all six together: as a
 #pragma unroll                                                                                      // short-circuit chain each
         for (int i = 0; i < 6; ++i) tv_in[i] = tvp[i];                                              // waited for the one before
     }
@@ -803,10 +820,15 @@ __global__ __launch_bounds__(FROMQ ? 256 : 64, IRLOSC_R16_WAVES) void osc_row16_
         } else {
             static_for<0, PF>([&](auto jc) { constexpr int j = decltype(jc)::value; pm0[j] = m0p[j * N]; pm1[j] = m1p[j * N]; });
         }
-        const TIN* __restrict__ Jb = p.J + (size_t)bc * (K * N);
+        const TIN* __restrict__ Jb = p.J + (size_t)bc * (kr * N);
         const TIN* __restrict__ Jb1 = v1 ? Jb + 16 + l : zeros;
 #pragma unroll
-        for (int r = 0; r < K; ++r) { jl0[r] = Jb[r * N + l]; jl1[r] = Jb1[r * N]; }
+        for (int r = 0; r < K; ++r) {
+            if constexpr (PAD) {      // rows k .. KMAX - 1: the page of zeros (the records hold k rows)
+                jl0[r] = (r < kr ? Jb + r * N + l : zeros)[0];
+                jl1[r] = (r < kr ? Jb1 + r * N : zeros)[0];
+            } else { jl0[r] = Jb[r * N + l]; jl1[r] = Jb1[r * N]; }
+        }
         dq0_in = p.dq[(size_t)bc * N + l];
         dq1_in = (v1 ? p.dq + (size_t)bc * N + 16 + l : zeros)[0];
     }
@@ -837,18 +859,17 @@ __global__ __launch_bounds__(FROMQ ? 256 : 64, IRLOSC_R16_WAVES) void osc_row16_
         bool all_nonzero = has_tv;
 #pragma unroll
         for (int i = 0; i < 6; ++i) all_nonzero = all_nonzero & ((double)tv_in[i] != 0.0);
-        own_brB = all_nonzero && dv < NDEV;          // np.all(target_vel) == 0 quirk, osc.py:173
+        own_brB = all_nonzero && dv < nd;            // np.all(target_vel) == 0 quirk, osc.py:173
         Wl[q][l] = tile_at(Te[l]);
-        if (ang_id == 0 && dv < NDEV) {
+        if (ang_id == 0 && dv < nd) {
             Kvl[q][dv] = (double)g_in[1];
             Brl[q][dv] = all_nonzero ? 0 : 1;
         }
         if (own_brB) {
             flags |= IRLOSC_FLAG_VEL_BRANCH_B;
-            if (dm.jidx0 + dm.rows > K) flags |= IRLOSC_FLAG_BAD_JIDX;
+            if (dm.jidx0 + dm.rows > kr) flags |= IRLOSC_FLAG_BAD_JIDX;
         }
     } else {
-        const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * NDEV * IRLOSC_GAIN_WORDS : 0) + dd * IRLOSC_GAIN_WORDS;
         double ee[7], tg[7], g[IRLOSC_GAIN_WORDS];
 #pragma unroll
         for (int i = 0; i < 7; ++i) { ee[i] = (double)ee_in[i]; tg[i] = (double)tg_in[i]; }
@@ -870,8 +891,8 @@ __global__ __launch_bounds__(FROMQ ? 256 : 64, IRLOSC_R16_WAVES) void osc_row16_
         bool all_nonzero = has_tv;
 #pragma unroll
         for (int i = 0; i < 6; ++i) all_nonzero = all_nonzero & ((double)tv_in[i] != 0.0);
-        own_brB = all_nonzero && dv < NDEV;          // np.all(target_vel) == 0 quirk, osc.py:173
-        if (ang_id == 0 && dv < NDEV) {
+        own_brB = all_nonzero && dv < nd;            // np.all(target_vel) == 0 quirk, osc.py:173
+        if (ang_id == 0 && dv < nd) {
             int cnt = 0;
 #pragma unroll
             for (int i = 0; i < 6; ++i)
@@ -881,7 +902,7 @@ __global__ __launch_bounds__(FROMQ ? 256 : 64, IRLOSC_R16_WAVES) void osc_row16_
         }
         if (own_brB) {
             flags |= IRLOSC_FLAG_VEL_BRANCH_B;
-            if (dm.jidx0 + dm.rows > K) flags |= IRLOSC_FLAG_BAD_JIDX;
+            if (dm.jidx0 + dm.rows > kr) flags |= IRLOSC_FLAG_BAD_JIDX;
         }
     }
     IRLOSC_TS(1);
@@ -1015,20 +1036,20 @@ __global__ __launch_bounds__(FROMQ ? 256 : 64, IRLOSC_R16_WAVES) void osc_row16_
     // ---- task-space signal, part 2: target-velocity branch B and the admittance wrench (osc.py:173-185) -----------
     Dxl[q][l] = dx;
     lds_sync();
-    if ((own_brB || has_wr) && ang_id == 0 && dv < NDEV) {
+    if ((own_brB || has_wr) && ang_id == 0 && dv < nd) {
         const double kv = Kvl[q][dv];
-        const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * NDEV * IRLOSC_GAIN_WORDS : 0) + dd * IRLOSC_GAIN_WORDS;
+        const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * nd * IRLOSC_GAIN_WORDS : 0) + dd * IRLOSC_GAIN_WORDS;
         int cnt = 0;
         for (int i = 0; i < 6; ++i) {
             if (dm.dofmask & (1u << i)) {
                 double v = Wl[q][dm.row0 + cnt];
                 if (own_brB) {
                     const int row = dm.jidx0 + cnt;
-                    const double dxv = row < K ? Dxl[q][row] : 0.0;
+                    const double dxv = row < kr ? Dxl[q][row] : 0.0;
                     const double damp = i < 3 ? (double)gp[6 + i] : 1.0;
-                    v += kv * (dxv - (double)p.tvel[((size_t)bc * NDEV + dd) * 6 + i]) * damp;
+                    v += kv * (dxv - (double)p.tvel[((size_t)bc * nd + dd) * 6 + i]) * damp;
                 }
-                if (has_wr) v += (double)p.wrench[((size_t)bc * NDEV + dd) * 6 + i];
+                if (has_wr) v += (double)p.wrench[((size_t)bc * nd + dd) * 6 + i];
                 Wl[q][dm.row0 + cnt] = v;
                 ++cnt;
             }
@@ -1054,7 +1075,7 @@ __global__ __launch_bounds__(FROMQ ? 256 : 64, IRLOSC_R16_WAVES) void osc_row16_
     double invd_own = 0.0;  // 1 / d_c in lane c
     double detA = 1.0;
     bool pdA = true;
-    ldl16<K>(A, l, 0.0, F, G, invd_own, pdA, detA);
+    ldl16<K, PAD>(A, l, 0.0, F, G, invd_own, pdA, detA, kr);
     // W = L~^-1, row c in lane c: X[m] = W[c][m]
     double X[K];
 #pragma unroll
@@ -1072,6 +1093,7 @@ __global__ __launch_bounds__(FROMQ ? 256 : 64, IRLOSC_R16_WAVES) void osc_row16_
     double trA = 0.0;
 #pragma unroll
     for (int m = 0; m < K; ++m) trA = fma(X[m], X[m], trA);
+    if constexpr (PAD) trA = l < kr ? trA : 0.0;       // (the padded block is the identity: not part of the trace)
     trA = row_sum(trA * invd_own);                     // trace(A^-1) >= 1 / lambda_min
     const bool small_det = !pdA || !(fabs(detA) >= 1e-4);      // a non-positive pivot: A is singular to working precision
     const double cond_bound = sqrt(nA2) * trA;         // >= cond_2(A) for SPD A
@@ -1103,7 +1125,7 @@ __global__ __launch_bounds__(FROMQ ? 256 : 64, IRLOSC_R16_WAVES) void osc_row16_
     if (__any(!plain)) {
         double t2 = 0.0;
         uint32_t f2 = 0;
-        eigen16<K>(Ac, F, G, invd_own, pdA, nA2, trA, w, l, !plain, t2, f2, giveup);
+        eigen16<K, PAD>(Ac, F, G, invd_own, pdA, nA2, trA, w, l, !plain, t2, f2, giveup, kr);
         t = plain ? t : t2;
         flags |= plain ? 0u : f2;
     }
@@ -1151,6 +1173,7 @@ __global__ __launch_bounds__(FROMQ ? 256 : 64, IRLOSC_R16_WAVES) void osc_row16_
     double u0 = 0.0, u1 = 0.0;
 #pragma unroll
     for (int d2 = 0; d2 < NDEV; ++d2) {       // branch A damping, osc.py:174 (assignment, device order)
+        if (PAD && d2 >= nd) break;
         const bool brA = Brl_[wv2][q2][d2] != 0;
         const double kvd = Kvl_[wv2][q2][d2];
         const uint32_t jm = p.dev[d2].joint_mask;
@@ -1221,11 +1244,13 @@ __global__ __launch_bounds__(64) void osc_generic_worklist_kernel(const Row16Tra
 // as k more entries of the exchange block (FeTopo::task_index), which the OSC kernel's tile picks up like everything else.  Same
 // formulas as the in-kernel form of the dense-record path (task_rot, apply_gains6_fast).  ~450 instructions per wave of 64
 // (robot, device) pairs against ~400 per wave of FOUR robots in the OSC kernel.
-template <int K, int NDEV, typename TIN, class TOPO>
+// PAD: one instantiation for every layout (NDEV = IRLOSC_MAX_DEV; the block has 64 x p.ndev threads).
+template <int K, int NDEV, typename TIN, class TOPO, bool PAD = false>
 __global__ __launch_bounds__(64 * NDEV) void osc_task_rows_fromq_kernel(const Row16Train<TIN> tr) {
     using namespace r16;
     const KParams<TIN>& p = tr.p[blockIdx.y];
     const Row16Extra& x = tr.x[blockIdx.y];
+    const int nd = PAD ? p.ndev : NDEV;
     // block = the 64 robots of walk wave blockIdx.x x NDEV waves: wave d computes the rows of target device d.  (The pass moves 230 MB
     // per train of 8 -- poses in, targets in, rows out -- and takes 60 us either way, one wave per robot or per (robot, device).)
     const int lane = threadIdx.x & 63;
@@ -1239,8 +1264,8 @@ __global__ __launch_bounds__(64 * NDEV) void osc_task_rows_fromq_kernel(const Ro
     // The targets of the block's 64 robots are 64 x NDEV x 7 consecutive words: wave loads, all in flight together, transposed
     // through LDS (read straight per lane -- 168-byte strides, 64 lines per load instruction -- the texture addresser handles a
     // line per cycle).  Wave d brings in the d-th third of them.
-    constexpr int TW = NDEV * 7;                   // odd: conflict-free reads with the robot as the slow index
-    __shared__ double tgs[64 * TW];
+    const int TW = nd * 7;                         // NDEV = 3: odd, conflict-free reads with the robot as the slow index
+    __shared__ double tgs[64 * NDEV * 7];
     {
         const size_t g0 = (size_t)blockIdx.x * 64 * TW + (size_t)d * 64 * 7, glast = (size_t)p.B * TW - 1;
         TIN tv[7];
@@ -1254,7 +1279,7 @@ __global__ __launch_bounds__(64 * NDEV) void osc_task_rows_fromq_kernel(const Ro
 #pragma unroll
     for (int i = 0; i < 7; ++i) eet[i] = tb->eetab[d][i];
     const DevMeta dm = p.dev[d];
-    const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * NDEV * IRLOSC_GAIN_WORDS : 0) + d * IRLOSC_GAIN_WORDS;
+    const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * nd * IRLOSC_GAIN_WORDS : 0) + d * IRLOSC_GAIN_WORDS;
     double ee[7], tg[7], g[IRLOSC_GAIN_WORDS];
 #pragma unroll
     for (int i = 0; i < 7; ++i) ee[i] = col[(size_t)eet[i] * 64];
@@ -1281,9 +1306,21 @@ __global__ __launch_bounds__(64 * NDEV) void osc_task_rows_fromq_kernel(const Ro
         if (dm.dofmask & (1u << i)) { col[(size_t)(e0 + dm.row0 + cnt) * 64] = e[i]; ++cnt; }
 }
 
+// Shapes with an instantiation of their own (tuned: register budget, prefetch depth) ...
+inline bool row16_kernel_exact(int n, int k, int ndev) {
+    const char* e = getenv("IRLOSC_FORCE_PAD");      // A/B aid: the padded variant on a shape that has an instantiation (tests, tools/layout_sweep.py)
+    if (e && e[0] == '1') return false;
+    return n == 25 && ((k == 13 && ndev == 3) || (k == 12 && ndev == 2) || (k == 7 && ndev == 3) || (k == 6 && ndev == 2));
+}
+// ... and the KMAX-padded variants that take every other n = 25 layout: the smallest tier that holds k
+constexpr int R16_PAD_TIERS[] = {4, 7, 10, 13, 16};
+inline int row16_pad_tier(int k) {
+    for (int t : R16_PAD_TIERS) if (k <= t) return t;
+    return 0;
+}
 inline bool row16_kernel_supports(int dtype, int n, int k, int ndev) {
     (void)dtype;     // fp64 records, or fp32 records with fp64 arithmetic (mixed path)
-    return n == 25 && ((k == 13 && ndev == 3) || (k == 12 && ndev == 2) || (k == 7 && ndev == 3) || (k == 6 && ndev == 2));
+    return n == 25 && k >= 1 && k <= IRLOSC_MAX_K && ndev >= 1 && ndev <= IRLOSC_MAX_DEV;
 }
 
 }  // namespace irlosc

@@ -21,6 +21,52 @@ LAYOUTS = {
     "k12_admit": (["ur5right", "ur5left"], [XYZ + ABG, XYZ + ABG], [RIGHT_J, LEFT_J], [1, 7],
                   dict(admittance=True)),
 }
+ROBOT_ORDER = ["base", "ur5right", "ur5left"]              # robot.sub_devices order: J_idxs count rows in it (robot.py:50-55)
+DEV_JOINTS = {"base": BASE_J, "ur5right": RIGHT_J, "ur5left": LEFT_J}
+YAML_MASKS = {"base": [False] * 3 + YAW, "ur5right": XYZ + ABG, "ur5left": XYZ + ABG}      # default_xyz_abg.yaml
+
+
+def register_layout(name: str, devices, admittance: bool = False, branch_b: bool = False) -> str:
+    """Add a layout to LAYOUTS: `devices` = [(device name, 6-entry ctrlr_dof mask)] in TARGETS order -- any subset / order of the
+    robot's devices, any row mask (what osc.py:134-138 stacks when a caller passes other targets, or a YAML sets another
+    ctrlr_dof).  j_idx0 follows robot.py:50-55: rows of the robot's devices in ITS order, the devices that are not targeted
+    keeping their YAML masks."""
+    masks = dict(YAML_MASKS)
+    masks.update({nm: list(m) for nm, m in devices})
+    row0, r = {}, 0
+    for nm in ROBOT_ORDER:
+        row0[nm] = r
+        r += int(sum(masks[nm]))
+    LAYOUTS[name] = ([nm for nm, _ in devices], [list(map(bool, m)) for _, m in devices], [DEV_JOINTS[nm] for nm, _ in devices],
+                     [row0[nm] for nm, _ in devices], dict(admittance=admittance, branch_b=branch_b))
+    return name
+
+
+def _m(bits: str):
+    return [c == "1" for c in bits]
+
+
+# Layouts a Dual-UR5 caller can reach beyond the four with a kernel instantiation of their own: target subsets, xyz-only arms,
+# partial masks (tests/test_gpu_parity.py sweeps them on the KMAX-padded row16 kernels; tools/layout_sweep.py times them)
+REACHABLE = [
+    register_layout("r6", [("ur5right", _m("111111"))]),                                            # single arm          k 6, 1 dev
+    register_layout("r3", [("ur5right", _m("111000"))]),                                            # single arm, xyz     k 3
+    register_layout("b1", [("base", _m("000001"))]),                                                # stand yaw only      k 1
+    register_layout("l2", [("ur5left", _m("110000"))]),                                             #                     k 2
+    register_layout("br4", [("base", _m("000001")), ("ur5right", _m("111000"))]),                   # arm + base          k 4, 2 dev
+    register_layout("rl5", [("ur5right", _m("111000")), ("ur5left", _m("110000"))]),                #                     k 5
+    register_layout("br7", [("base", _m("000001")), ("ur5right", _m("111111"))]),                   # arm + base          k 7, 2 dev
+    register_layout("rl8", [("ur5right", _m("111110")), ("ur5left", _m("111000"))]),                #                     k 8
+    register_layout("rl9_admit", [("ur5right", _m("111111")), ("ur5left", _m("111000"))], admittance=True),    # k 9 + wrench
+    register_layout("rlb10", [("ur5right", _m("111111")), ("ur5left", _m("111000")), ("base", _m("000001"))]),  # k 10, 3 dev
+    register_layout("rlbr10", [("ur5right", _m("111000")), ("ur5left", _m("111000")), ("base", _m("000001")),
+                               ("ur5right", _m("000111"))]),                                        # four target blocks  k 10, 4 dev
+    register_layout("rlb11_branch_b", [("base", _m("000001")), ("ur5right", _m("111110")), ("ur5left", _m("111011"))],
+                    branch_b=True),                                                                 # k 11, target velocities
+    register_layout("brl14", [("base", _m("000011")), ("ur5right", _m("111111")), ("ur5left", _m("111111"))]),  # k 14
+    register_layout("rlb16", [("ur5right", _m("111111")), ("ur5left", _m("111111")), ("base", _m("110011"))]),  # k 16 = IRLOSC_MAX_K
+]
+
 YAML_GAINS = {  # default_xyz_abg.yaml: base osc0, arms osc2
     "base": dict(kp=2000.0, kv=20.0, ko=2000.0, max_vel=[0.0, 20.0]),
     "ur5right": dict(kp=200.0, kv=50.0, ko=200.0, max_vel=[1.0, 5.0]),

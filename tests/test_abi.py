@@ -26,7 +26,20 @@ def test_library_exports_every_declared_symbol():
     for nm in names:
         assert hasattr(lib, nm), nm
     assert sorted(names) == sorted(_lib.EXPORTS)
-    assert lib.irlosc_abi_version() == 1
+    assert lib.irlosc_abi_version() == _lib.ABI_VERSION == 2
+    hdr = open(os.path.join(ROOT, "include", "irlosc.h")).read()
+    assert f"#define IRLOSC_ABI_VERSION {_lib.ABI_VERSION}" in hdr
+
+
+def test_library_exports_nothing_but_the_c_abi():
+    """`nm -D`: the dynamic symbols the library DEFINES are exactly the irlosc_* entry points of include/irlosc.h -- no mangled
+    launch helpers, kernel handles or template instantiations (-fvisibility=hidden + the linker version script csrc/irlosc.map)."""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    syms = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert syms == sorted(_declared()), sorted(set(syms) ^ set(_declared()))
 
 
 def test_cfg_struct_matches_header_layout():

@@ -1665,17 +1665,6 @@ def test_k6_two_arms_xyz_runs_on_the_row16_kernel():
     osc.close()
 
 
-def test_generic_kernel_warning_for_layouts_without_a_throughput_shape():
-    """A layout the row16 kernel has no instantiation for lands on the generic kernel: irlosc_kernel_name says so and
-    BatchedOSC warns at throughput batch sizes (26x slower)."""
-    from irl_control_amd.layout import OSCLayout as L
-    lay = L(n=25, dev_names=["ur5right"], ctrlr_dof=[[True] * 6], joint_ids=[list(range(1, 13))], j_idx0=[1])
-    with pytest.warns(RuntimeWarning, match="no throughput instantiation"):
-        osc = BatchedOSC(lay, 2048)
-    assert "generic" in osc.kernel_name
-    osc.close()
-
-
 def test_time_trains_spans_and_periods_are_consistent():
     """irlosc_time_trains: per train an event pair and the kernel's own wall-clock stamps.  Starts increase, a train's in-kernel
     span is positive and no longer than its event pair (which also covers the give-up pass), the period between starts is no
@@ -1766,7 +1755,12 @@ def test_bench_line_end_to_end_and_untraced_roofline():
     r = line["roofline"]
     un = r["untraced"]
     assert un["trains"] >= 32 and un["period_us"]["median"] > 0 and un["kernel_span_us"]["median"] > 0
-    assert "frac_rocprof" not in r and "rocprof_kernel_ms" not in r          # committed numbers live under their own key
+    assert ("frac_rocprof" in r) == ("rocprof_source" in r)      # a committed (not live) number never travels without its label
+    # flat scalars for the driver's record (it keeps the scalars of `roofline` / `config`, nested dicts are dropped)
+    assert r["untraced_kernel_span_us"] == un["kernel_span_us"]["median"] and r["untraced_period_us"] == un["period_us"]["median"]
+    assert 0 < r["frac_from_kernel_span"] < 1 and 500 < r["sclk_mhz"] < 2600
+    c = line["config"]
+    assert c["sustained_value"] == line["sustained"]["value"] and c["end_to_end_host_arrays_value"] > 0 and c["end_to_end_tick_b1_us"] > 0
     e = line["end_to_end"]
     assert e["generate_batched"]["value"] > 0 and e["generate_batched"]["pcie_GBps"] > 0.5
     assert 5 < e["tick_b1_us"]["median"] < 2000 and e["upload_raw_step"]["value"] > 0
@@ -1812,3 +1806,28 @@ def test_fused_from_q_with_target_velocities_and_per_instance_gains(dtype):
                                     np.asarray(g["tgt_pose"][:n], dtype=np.float64), None, np.asarray(g["tgt_vel"][:n], dtype=np.float64))
     dom = np.array([in_parity_domain(*osc_oracle.task_inertia(r["J"][b], r["M"][b])[2:]) for b in range(n)])
     assert dom.sum() > n // 2 and rel_err(u_f[:n].astype(np.float64), ref)[dom].max() <= TOL64
+
+
+def _visible_gpus():
+    return int(_lib.load().irlosc_device_count())
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_rccl_ranks_when_that_many_gpus_are_visible(world):
+    """SURVEY.md section 8(e) on hardware: the first box with >= `world` GPUs runs the real thing -- one process per GPU, RCCL over
+    xGMI for the barrier / final reduction / checksum all-gather, `--require-rccl` so that a fall-back to the file transport is
+    a failure, not a line -- and checks the rank checksums against one process cutting the same total batch into `world` slices.
+    Skips with the reason on a smaller box (the builder's boxes have one GPU: RCCL with N > 1 ranks has never executed)."""
+    have = _visible_gpus()
+    if have < world:
+        pytest.skip(f"{have} GPU(s) visible: the {world}-rank RCCL run needs {world}")
+    common = ["--steps", "16", "--warmup", "8", "--preroll", "0", "--total-batch", str(4096 * world), "--no-cpu-baseline",
+              "--no-secondary", "--no-from-q", "--no-end-to-end"]
+    rc, many, n, err = _bench_run(["--gpus", str(world), "--require-rccl"] + common, {})
+    assert rc == 0 and n == 1, err[-3000:]
+    assert many["n_gpus"] == world and many["config"]["rccl_ranks"] == world and "RCCL" in many["config"]["sharding"].upper()
+    assert len(set(many["rank_checksums"])) == world and many["value"] > 0
+    rc1, one, n1, err1 = _bench_run(["--gpus", "1", "--slices", str(world)] + common, {})
+    assert rc1 == 0 and n1 == 1, err1[-3000:]
+    assert [r[0] for r in many["slice_checksums"]] == one["slice_checksums"][0]
+    assert many["rank_checksums"] == [r[0] for r in many["slice_checksums"]]
