@@ -160,10 +160,12 @@ __device__ __forceinline__ double sqrt_fast(double x) { return x > 0.0 ? x * rsq
 // L~[i][c] for i > c, else 0 (column c of L~); invd_own = 1 / d_c in lane c; pd = all pivots positive; det = prod d.
 // PAD (the KMAX-padded variant of the kernel, see osc_row16_kernel): only the leading kr x kr block is the task space; rows and
 // columns kr .. K - 1 of A are exact zeros.  Their pivots are taken as 1 and stay out of `pd` and `det`, their columns of L~ are
-// zero: the factorisation of the real block is bit for bit what the K = kr instantiation computes.
+// zero: the factorisation of the real block is bit for bit what the K = kr instantiation computes.  The same treatment for the
+// rows named in `zrow` (bit j: row j of J is identically zero -- a task row no joint can move, A[j][j] == 0 exactly): such a row
+// is an exact null direction of A, decoupled from the rest, and np.linalg.pinv (osc.py:55) drops it whatever the others do.
 template <int K, bool PAD = false>
 __device__ __forceinline__ void ldl16(double (&A)[K], const int l, const double sigma, double (&F)[K], double (&G)[K],
-                                      double& invd_own, bool& pd, double& det, const int kr = K) {
+                                      double& invd_own, bool& pd, double& det, const int kr = K, const uint32_t zrow = 0u) {
     pd = true;
     det = 1.0;
     invd_own = 0.0;
@@ -171,7 +173,7 @@ __device__ __forceinline__ void ldl16(double (&A)[K], const int l, const double 
     static_for<0, K>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         double d = bc_nop<j>(A[j]) + sigma;
-        const bool real = !PAD || j < kr;              // (scalar)
+        const bool real = !PAD || (j < kr && !((zrow >> j) & 1u));
         const bool npd = real && !(d > 0.0);           // also catches NaN
         pd = pd && !npd;
         d = (npd || !real) ? 1.0 : d;      // the verdict is in: what a non-positive pivot leaves behind is never used (the caller refactors
@@ -231,7 +233,7 @@ __device__ __forceinline__ double matvec16(const double x, const double (&Ac)[K]
 template <int K, bool PAD = false>
 __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], double (&G)[K], double& invd_own, const bool pdA,
                                         const double nA2, const double trA, const double w, const int l, const bool flagged,
-                                        double& t, uint32_t& fl, bool& giveup, const int kr = K) {
+                                        double& t, uint32_t& fl, bool& giveup, const int kr = K, const uint32_t zrow = 0u) {
     const double hi = sqrt(nA2);
     double sigma = 0.0;
     giveup = flagged && !(hi > 0.0 && t_finite(hi));
@@ -248,7 +250,7 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
         for (int r = 0; r < K; ++r) A2[r] = Ac[r];
         const bool use = flagged && broken;
         sigma = use ? hi * 0x1p-40 : 0.0;
-        ldl16<K, PAD>(A2, l, sigma, F, G, invd_own, pd2, det2, kr);
+        ldl16<K, PAD>(A2, l, sigma, F, G, invd_own, pd2, det2, kr, zrow);
         giveup = giveup || (use && !pd2);
     }
     // bracket of lambda_max: the largest diagonal entry is a Rayleigh quotient, the Frobenius norm an upper bound
@@ -276,7 +278,8 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
         if (!__any(active)) break;
         int lq = l;
         asm volatile("" : "+v"(lq));       // (keeps the four start vectors from being computed ahead of the stage and carried through it)
-        double x = lq < (PAD ? kr : K) ? 0.3 + 0.1 * (double)(((lq + 3 * slot) * 5) % 7) - 0.05 * (double)slot : 0.0;
+        const bool inblock = PAD ? (lq < kr && !((zrow >> lq) & 1u)) : lq < K;      // (zero outside the real block, and it stays zero: A is block diagonal)
+        double x = inblock ? 0.3 + 0.1 * (double)(((lq + 3 * slot) * 5) % 7) - 0.05 * (double)slot : 0.0;
         double lam = 0.0, lam_prev = -1.0;
         bool fin = !active;
         for (int it = 0; it < IRLOSC_EIG_MAXIT; ++it) {
@@ -401,7 +404,7 @@ __device__ __forceinline__ void eigen16(const double (&Ac)[K], double (&F)[K], d
             bool pdt = true;
 #pragma unroll
             for (int r = 0; r < K; ++r) A2[r] = -Ac[r];
-            ldl16<K, PAD>(A2, l, ask ? th[i] * 1e5 : 4.0 * hi, Ft, Gt, invt, pdt, dett, kr);
+            ldl16<K, PAD>(A2, l, ask ? th[i] * 1e5 : 4.0 * hi, Ft, Gt, invt, pdt, dett, kr, zrow);
             cut = cut || (ask && !pdt);
         }
         v[i] = cut ? v[i] : 0.0;
@@ -1013,6 +1016,15 @@ void osc_row16_kernel(const Row16Train<TIN> tr) {
 
     flags |= ((npd_mask >> lane) & 1ull) ? IRLOSC_FLAG_M_NOT_PD : 0u;
     IRLOSC_TS(3);
+    // The admittance wrench (osc.py:184-185) is consumed behind A = Y^T Y: requested HERE, where the registers of the factor have
+    // just come free, its round trip to HBM hides behind those K x N products.  (Round 4 loaded it where it is added: the k12 +
+    // admittance kernel issued in 56 % of its cycles against 73 % for k13 without the term -- profiles/r05b_row16_f64_k12_admit_pmc_sq.txt.)
+    TIN wr_in[6];
+    if (has_wr) {
+        const TIN* __restrict__ wp = p.wrench + ((size_t)bc * nd + dd) * 6;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) wr_in[i] = wp[i];
+    }
     // ---- A = Y^T Y: lane c ends up with A[r][c], r = 0..K-1 -------------------------------------------------------
     double A[K];
 #pragma unroll
@@ -1040,6 +1052,7 @@ void osc_row16_kernel(const Row16Train<TIN> tr) {
         const double kv = Kvl[q][dv];
         const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * nd * IRLOSC_GAIN_WORDS : 0) + dd * IRLOSC_GAIN_WORDS;
         int cnt = 0;
+#pragma unroll
         for (int i = 0; i < 6; ++i) {
             if (dm.dofmask & (1u << i)) {
                 double v = Wl[q][dm.row0 + cnt];
@@ -1049,7 +1062,7 @@ void osc_row16_kernel(const Row16Train<TIN> tr) {
                     const double damp = i < 3 ? (double)gp[6 + i] : 1.0;
                     v += kv * (dxv - (double)p.tvel[((size_t)bc * nd + dd) * 6 + i]) * damp;
                 }
-                if (has_wr) v += (double)p.wrench[((size_t)bc * nd + dd) * 6 + i];
+                if (has_wr) v += (double)wr_in[i];
                 Wl[q][dm.row0 + cnt] = v;
                 ++cnt;
             }
@@ -1057,7 +1070,7 @@ void osc_row16_kernel(const Row16Train<TIN> tr) {
     }
     lds_sync();
     // w = u_task_all [+ ext_f] - kvn * dx  (null-space term folded in: osc_generic.hpp header)
-    const double w = Wl[q][l] - load_kvn() * dx;
+    double w = Wl[q][l] - load_kvn() * dx;
     // M dq is next needed for the torques at the very end: it waits in the two LDS rows that are free from here on (every
     // lane its own slot; all cross-lane reads of Wl / Dxl are behind the lds_sync above)
     Dxl[q][l] = mdq0;
@@ -1075,7 +1088,20 @@ void osc_row16_kernel(const Row16Train<TIN> tr) {
     double invd_own = 0.0;  // 1 / d_c in lane c
     double detA = 1.0;
     bool pdA = true;
-    ldl16<K, PAD>(A, l, 0.0, F, G, invd_own, pdA, detA, kr);
+    // PAD: task rows that NO joint can move (row r of J identically zero, e.g. a base device asked for translations, or any k > 13
+    // on this robot: 13 columns of J can be non-zero) are exact null directions of A: the reference's det is 0, its pinv drops them
+    // (osc.py:52-55).  They are taken out here like the padding rows, instead of being found one by one by the eigen stage (three at most).
+    uint32_t zrow = 0u;
+    bool zr = false;
+    if constexpr (PAD) {
+        double dg = 1.0;
+#pragma unroll
+        for (int r = 0; r < K; ++r) dg = (l == r) ? A[r] : dg;
+        zr = l < kr && dg == 0.0;                       // A[r][r] = |row r of Y|^2: zero exactly when row r of J is zero
+        zrow = (uint32_t)(__ballot(zr) >> (q * 16)) & 0xffffu;
+        w = zr ? 0.0 : w;
+    }
+    ldl16<K, PAD>(A, l, 0.0, F, G, invd_own, pdA, detA, kr, zrow);
     // W = L~^-1, row c in lane c: X[m] = W[c][m]
     double X[K];
 #pragma unroll
@@ -1093,13 +1119,14 @@ void osc_row16_kernel(const Row16Train<TIN> tr) {
     double trA = 0.0;
 #pragma unroll
     for (int m = 0; m < K; ++m) trA = fma(X[m], X[m], trA);
-    if constexpr (PAD) trA = l < kr ? trA : 0.0;       // (the padded block is the identity: not part of the trace)
+    if constexpr (PAD) trA = (l < kr && !zr) ? trA : 0.0;      // (the padded block is the identity: not part of the trace)
     trA = row_sum(trA * invd_own);                     // trace(A^-1) >= 1 / lambda_min
-    const bool small_det = !pdA || !(fabs(detA) >= 1e-4);      // a non-positive pivot: A is singular to working precision
+    const bool small_det = !pdA || !(fabs(detA) >= 1e-4) || zrow != 0u;      // a non-positive pivot: A is singular to working precision
     const double cond_bound = sqrt(nA2) * trA;         // >= cond_2(A) for SPD A
     const bool plain = pdA && t_finite(cond_bound) && (!small_det || cond_bound < 0.99e5);
     flags |= small_det ? IRLOSC_FLAG_PINV_BRANCH : 0u;
     flags |= plain ? 0u : IRLOSC_FLAG_EIGEN_PATH;
+    flags |= zrow != 0u ? IRLOSC_FLAG_TRUNCATED : 0u;       // (the exact zero eigenvalues are under any cut)
     // t = A^-1 w = L~^-T D^-1 (W w)
     double z = 0.0;
     __builtin_amdgcn_sched_barrier(0);
@@ -1125,7 +1152,7 @@ void osc_row16_kernel(const Row16Train<TIN> tr) {
     if (__any(!plain)) {
         double t2 = 0.0;
         uint32_t f2 = 0;
-        eigen16<K, PAD>(Ac, F, G, invd_own, pdA, nA2, trA, w, l, !plain, t2, f2, giveup, kr);
+        eigen16<K, PAD>(Ac, F, G, invd_own, pdA, nA2, trA, w, l, !plain, t2, f2, giveup, kr, zrow);
         t = plain ? t : t2;
         flags |= plain ? 0u : f2;
     }
