@@ -76,6 +76,7 @@ struct irlosc_ctx {
     FeModel* dmodel = nullptr;
     size_t fe_smem = 0;
     int fe_lane = 0;                  // 1: the model has the compiled Dual-UR5 shape -> lane-per-instance front end
+    int fe_lane_s = 0;                // 1: ... and the structural constants of its MJCF -> the fused walk with them compiled in (TopoDualUr5S)
     double* fe_side = nullptr;        // side buffer of the lane kernel: [wave][entry][64]
     // fused path (irlosc_step_from_q / irlosc_step_resident_from_q on the row16 kernel): entry tables of the compact exchange
     // buffer and one buffer per step of a train
@@ -85,6 +86,7 @@ struct irlosc_ctx {
     int fused = 0;
     int fused_train = R16_TRAIN;
     std::vector<double*> dqpos, dqvel;
+    std::vector<double*> dqt;          // per slot: the same coordinates in the fused walk's layout [wave][2 n][64 robots] (irlosc_upload_q writes both)
     std::vector<int> has_q;
     // irlosc_tick: one pinned host block and one device block per direction, grown on demand
     void* tick_hin = nullptr; void* tick_din = nullptr; size_t tick_in_bytes = 0;
@@ -197,6 +199,7 @@ static void free_all(irlosc_ctx* c) {
     for (int k = 0; k < R16_TRAIN; ++k) if (c->fe_xside[k]) (void)hipFree(c->fe_xside[k]);
     for (double* p : c->dqpos) if (p) (void)hipFree(p);
     for (double* p : c->dqvel) if (p) (void)hipFree(p);
+    for (double* p : c->dqt) if (p) (void)hipFree(p);
     if (c->tick_hin) (void)hipHostFree(c->tick_hin);
     if (c->tick_din) (void)hipFree(c->tick_din);
     if (c->tick_hout) (void)hipHostFree(c->tick_hout);
@@ -1189,6 +1192,15 @@ extern "C" int irlosc_set_model(irlosc_ctx* c, const irlosc_model* m) {
                     h.icb[b][e++] = R[r * 3] * h.inertia[b][0] * R[cc * 3] + R[r * 3 + 1] * h.inertia[b][1] * R[cc * 3 + 1] + R[r * 3 + 2] * h.inertia[b][2] * R[cc * 3 + 2];
         }
     }
+    for (int b = 0; b < m->nb; ++b) {      // the per-body records of the walk (FeModel::rec)
+        double* w = h.rec[b];
+        const int jb = h.joint_of_body[b];
+        for (int i = 0; i < 3; ++i) { w[i] = h.pos[b][i]; w[7 + i] = h.ipos[b][i]; }
+        for (int i = 0; i < 4; ++i) w[3 + i] = h.quat[b][i];
+        for (int i = 0; i < 6; ++i) w[10 + i] = h.icb[b][i];
+        w[16] = h.mass[b];
+        for (int i = 0; i < 3; ++i) { w[17 + i] = jb >= 0 ? h.jaxis[jb][i] : 0.0; w[20 + i] = jb >= 0 ? h.jpos[jb][i] : 0.0; w[23 + i] = jb >= 0 ? h.jpos_par[jb][i] : 0.0; }
+    }
     int row = 0;
     for (int d = 0; d < c->cfg.ndev; ++d) {
         if (m->ee_body[d] < 0 || m->ee_body[d] >= m->nb) return fail(c, IRLOSC_ERR_ARG, "ee_body[%d]=%d out of range", d, m->ee_body[d]);
@@ -1202,6 +1214,8 @@ extern "C" int irlosc_set_model(irlosc_ctx* c, const irlosc_model* m) {
     {
         const char* e = getenv("IRLOSC_FRONTEND");           // "generic": force the wave-per-instance kernel (A/B measurements)
         c->fe_lane = frontend_lane_dual_ur5_matches(h) && !(e && !strcmp(e, "generic"));
+        const char* w = getenv("IRLOSC_WALK");               // "general": the shape-only walk on the fused path (A/B measurements, tests)
+        c->fe_lane_s = c->fe_lane && frontend_lane_dual_ur5_s_matches(h) && !(w && !strcmp(w, "general"));
     }
     // (the lane kernel's side buffer -- 139 MB at 65 536 robots -- is allocated by the first irlosc_frontend: a context that only
     // ever takes the fused path never needs it)
@@ -1229,10 +1243,12 @@ extern "C" int irlosc_set_model(irlosc_ctx* c, const irlosc_model* m) {
     if (c->dqpos.empty()) {
         c->dqpos.assign(c->cfg.n_slots, nullptr);
         c->dqvel.assign(c->cfg.n_slots, nullptr);
+        c->dqt.assign(c->cfg.n_slots, nullptr);
         c->has_q.assign(c->cfg.n_slots, 0);
         for (int s2 = 0; s2 < c->cfg.n_slots; ++s2) {
             HIPCHK(c, hipMalloc((void**)&c->dqpos[s2], (size_t)c->cfg.max_batch * c->cfg.n * sizeof(double)));
             HIPCHK(c, hipMalloc((void**)&c->dqvel[s2], (size_t)c->cfg.max_batch * c->cfg.n * sizeof(double)));
+            HIPCHK(c, hipMalloc((void**)&c->dqt[s2], (((size_t)c->cfg.max_batch + 63) / 64) * 2 * c->cfg.n * 64 * sizeof(double)));
         }
     }
     return IRLOSC_OK;
@@ -1249,6 +1265,9 @@ extern "C" int irlosc_upload_q(irlosc_ctx* c, int32_t slot, int32_t B, const dou
     const size_t bytes = (size_t)B * c->cfg.n * sizeof(double);
     HIPCHK(c, hipMemcpyAsync(c->dqpos[slot], qpos, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->dqvel[slot], qvel, bytes, hipMemcpyHostToDevice, c->stream));
+    // the fused walk reads its own layout of the same numbers ([wave][2 n][64 robots]: coalesced, hinge by hinge): one small kernel
+    // behind the copies (10 us per 65 536 robots against 0.8 ms of PCIe for them)
+    HIPCHK(c, (hipError_t)launch_q_layout(c->dqpos[slot], c->dqvel[slot], c->dqt[slot], B, c->cfg.n, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->has_q[slot] = B;
     return IRLOSC_OK;
@@ -1362,6 +1381,7 @@ static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, hipStream_
         const int sl = slots[i];
         ft.qpos[i] = ga.qpos[i] = c->dqpos[sl];
         ft.qvel[i] = ga.qvel[i] = c->dqvel[sl];
+        ft.qt[i] = c->dqt[sl];
         ft.side[i] = c->fe_xside[i];
         fill_params<T>(c, tr.p[i], B, c->dM[sl], c->dJ[sl], c->ddq[sl], c->dbias[sl], c->dee[sl], c->dtgt[sl],
                        c->has_tvel[sl] ? c->dtvel[sl] : nullptr, c->has_wrench[sl] ? c->dwrench[sl] : nullptr, c->du_set[i], c->dflags_set[i]);
@@ -1371,7 +1391,8 @@ static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, hipStream_
         ga.count[i] = c->dr16_count + i;
     }
     if (c->tev_begin) HIPCHK(c, hipEventRecord(c->tev_begin, st));
-    HIPCHK(c, (hipError_t)launch_frontend_lane_compact_dual_ur5(c->dmodel, ft, n, st));
+    HIPCHK(c, (hipError_t)(c->fe_lane_s ? launch_frontend_lane_compact_dual_ur5_s(c->dmodel, ft, n, st)
+                                        : launch_frontend_lane_compact_dual_ur5(c->dmodel, ft, n, st)));
     HIPCHK(c, (hipError_t)launch_row16_fromq<T>(tr, n, st));
     HIPCHK(c, (hipError_t)launch_frontend_generic_lists<T>(c->dmodel, ga, n, c->fe_smem, st));
     HIPCHK(c, (hipError_t)launch_row16_worklist<T>(tr, n, nullptr, st));
@@ -1406,7 +1427,7 @@ static int fused_resident(irlosc_ctx* c, int first_slot, int B, int iters) {
 extern "C" const char* irlosc_from_q_name(const irlosc_ctx* c) {
     static thread_local std::string nm;
     if (!c || !c->dmodel) return "";
-    if (c->fused) nm = std::string("osc_frontend_lane_compact_dual_ur5 + ") + c->kernel_name + "_fromq (fused: compact exchange buffer, no dense M / J)";
+    if (c->fused) nm = std::string(c->fe_lane_s ? "osc_frontend_lane_compact_dual_ur5_s + " : "osc_frontend_lane_compact_dual_ur5 + ") + c->kernel_name + "_fromq (fused: compact exchange buffer, no dense M / J)";
     else nm = std::string(irlosc_frontend_name(c)) + " + " + c->kernel_name + " (through dense records)";
     return nm.c_str();
 }

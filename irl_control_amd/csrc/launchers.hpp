@@ -53,6 +53,10 @@ int launch_frontend_generic_lists(const FeModel* dmodel, const FeGenericArgs<TOU
 struct FeLaneTrain;
 struct FeCompactTables;
 int launch_frontend_lane_compact_dual_ur5(const FeModel* dmodel, const FeLaneTrain& tr, int nsteps, hipStream_t st);
+// tu_frontend_lane_compact_s.hip -- the same walk with the structural constants of the Dual-UR5's MJCF compiled in (TopoDualUr5S)
+int launch_frontend_lane_compact_dual_ur5_s(const FeModel* dmodel, const FeLaneTrain& tr, int nsteps, hipStream_t st);
+bool frontend_lane_dual_ur5_s_matches(const FeModel& h);
+int launch_q_layout(const double* qpos, const double* qvel, double* qt, int B, int nj, hipStream_t st);      // [wave][2 nj][64]: the fused walk's input layout
 void frontend_lane_dual_ur5_tables(const FeModel& h, FeCompactTables* t);
 size_t frontend_lane_dual_ur5_side_doubles_per_wave();
 bool frontend_lane_dual_ur5_matches(const FeModel& h);

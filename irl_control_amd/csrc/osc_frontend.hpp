@@ -51,6 +51,10 @@ struct FeModel {
     double jpos_par[FE_MAXJ][3];         // hinge anchor in the PARENT body's frame offset: R(quat_b) jpos
     double icb[FE_MAXB][6];              // body-frame inertia about the centre of mass: Ri diag(inertia) Ri^T (xx xy xz yy yz zz)
     double cmass[FE_MAXJ];               // mass of everything hinge j moves
+    // the constants the walk needs when it ENTERS body b, gathered in one 256-byte record (one burst of scalar loads per body, issued
+    // while the body before it is still being worked on): 0-2 pos, 3-6 quat, 7-9 ipos, 10-15 icb, 16 mass, 17-19 jaxis, 20-22 jpos,
+    // 23-25 jpos_par (hinge entries of the body's own hinge, zeros for a welded body)
+    double rec[FE_MAXB][32];
 };
 
 struct V3 { double x, y, z; };
@@ -132,6 +136,8 @@ constexpr int FE_TILE_TAB_WORDS = 32 * 32 + IRLOSC_MAX_K * 32 + IRLOSC_MAX_DEV *
 struct FeLaneTrain {
     const double* qpos[FE_TRAIN];
     const double* qvel[FE_TRAIN];
+    const double* qt[FE_TRAIN];          // the same coordinates as irlosc_upload_q lays them out for the walk: [walk wave][2 NJ][64 robots],
+                                         // entry 2 j = q_j, 2 j + 1 = qvel_j (idle lanes of a ragged last wave repeat the last robot)
     double* side[FE_TRAIN];
     int32_t B;
 };

@@ -20,6 +20,11 @@ int launch_frontend_lane_compact_dual_ur5(const FeModel* dmodel, const FeLaneTra
     hipLaunchKernelGGL((osc_frontend_lane_compact_kernel<TopoDualUr5>), dim3((tr.B + 63) / 64, nsteps), dim3(64), 0, st, dmodel, tr);
     return (int)hipGetLastError();
 }
+int launch_q_layout(const double* qpos, const double* qvel, double* qt, int B, int nj, hipStream_t st) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(osc_q_layout_kernel<double>, dim3((B + 63) / 64), dim3(64), 0, st, qpos, qvel, qt, B, nj);
+    return (int)hipGetLastError();
+}
 void frontend_lane_dual_ur5_tables(const FeModel& h, FeCompactTables* t) { frontend_lane_tables<TopoDualUr5>(h, t); }
 
 size_t frontend_lane_dual_ur5_side_doubles_per_wave() { return (size_t)FeTopo<TopoDualUr5>::n_side() * 64; }
