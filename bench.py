@@ -68,7 +68,9 @@ def flops_osc_step(layout_name, k):
     if layout_name in FLOPS_OSC_STEP:
         return FLOPS_OSC_STEP[layout_name], "counted (profiles/NOTES.md section 4.6)"
     return 14.2e3 + (k - 7) * (23.3e3 - 14.2e3) / 6.0, "interpolated in k between the counted k = 7 and k = 13 figures"
-FLOPS_FRONT_END = 20.1e3                                                # FK, EE Jacobians, CRBA, RNEA of the Dual-UR5 tree (counted in the ISA)
+FLOPS_FRONT_END = 15.4e3                                                # FK, EE Jacobians, CRBA, RNEA of the Dual-UR5 tree, counted in the ISA of the
+                                                                        # round-5 walk (profiles/r05_walk_isa_mix.txt; the round-4 walk did 20.1e3:
+                                                                        # products with the MJCF's exact zeros and ones, a dot product per (body, hinge) pair)
 MODES = {   # --dtype -> (record dtype, arithmetic label, kernel id)
     "f64": (np.float64, "f64", 0),
     "mixed": (np.float32, "f64", 3),

@@ -38,6 +38,7 @@ struct irlosc_ctx {
     std::vector<void*> dM, dJ, ddq, dbias, dee, dwrench, dtgt, dtvel;
     std::vector<int> has_wrench, has_tvel;
     std::vector<int> uploaded, targeted;    // instances of the slot that hold state / targets (0 = nothing yet, -1 = an empty batch)
+    std::vector<int> fused_away;            // 1: the slot's dense records were invalidated by a fused step from joint coordinates (error text only)
     // Output sets (u, flags, stage-2 hand-off records, give-up list).  The group path chains up to TRAIN steps in
     // one launch and the stage 2 of a train's steps rides in the NEXT train, so two trains' worth of sets exist;
     // the generic path only ever uses set 0.
@@ -818,6 +819,9 @@ static int launch(irlosc_ctx* c, int B, const void* M, const void* J, const void
 
 // A step over B instances needs B instances of state AND of targets in the slot (stale or uninitialised HBM otherwise).
 static int check_slot_filled(irlosc_ctx* c, int slot, int B) {
+    if (!c->uploaded[slot] && !c->fused_away.empty() && c->fused_away[slot])
+        return fail(c, IRLOSC_ERR_STATE, "slot %d holds no dense records: the preceding fused irlosc_step_from_q / irlosc_step_resident_from_q "
+                    "invalidated them (it never writes M / J); run irlosc_frontend or an upload first", slot);
     if (!c->uploaded[slot] || !c->targeted[slot])
         return fail(c, IRLOSC_ERR_STATE, "slot %d: irlosc_upload and irlosc_set_targets must precede a step", slot);
     if (B > std::max(0, c->uploaded[slot]) || B > std::max(0, c->targeted[slot]))
@@ -1400,7 +1404,8 @@ static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, hipStream_
     // The give-up pass wrote dense records of the robots on its lists into the slots (and nothing for the others): what the
     // slots held before no longer belongs to one state.  They hold no records from here on -- irlosc_step / irlosc_step_resident
     // / irlosc_download_records on them fail with IRLOSC_ERR_STATE until irlosc_frontend / irlosc_upload* fills them again.
-    for (int i = 0; i < n; ++i) { c->uploaded[slots[i]] = 0; c->tree_ok[slots[i]] = 0; }
+    if (c->fused_away.empty()) c->fused_away.assign(c->cfg.n_slots, 0);
+    for (int i = 0; i < n; ++i) { c->uploaded[slots[i]] = 0; c->tree_ok[slots[i]] = 0; c->fused_away[slots[i]] = 1; }
     return IRLOSC_OK;
 }
 

@@ -1124,6 +1124,75 @@ def test_fused_from_q_against_the_chained_oracles():
     assert dom.sum() >= B // 2 and rel_err(u, ref)[dom].max() <= TOL64
 
 
+def test_structural_walk_equals_the_shape_only_walk(monkeypatch):
+    """The fused path's walk exists twice: with the structural constants of the Dual-UR5's MJCF compiled in (TopoDualUr5S: frames not
+    rotated against / coincident with their parent's, hinges about coordinate axes through their body's origin, diagonal body-frame
+    inertias -- products with those exact zeros and ones left out) and shape-only (any numbers).  irlosc_set_model picks the first
+    for the shipped model; IRLOSC_WALK=general forces the second.  Same mathematics: torques agree to rounding, flags exactly."""
+    B = 2048 + 11
+    lay, gains, g, model, osc, _ = _from_q_setup("k13", B, np.float64, seed=31, singular_every=6)
+    assert "compact_dual_ur5_s +" in osc.from_q_name
+    u_s, fl_s = osc.step_q(return_flags=True)
+    osc.close()
+    monkeypatch.setenv("IRLOSC_WALK", "general")
+    lay, gains, g, model, osc, _ = _from_q_setup("k13", B, np.float64, seed=31, singular_every=6)
+    assert "compact_dual_ur5 +" in osc.from_q_name
+    u_g, fl_g = osc.step_q(return_flags=True)
+    osc.close()
+    assert np.array_equal(fl_s, fl_g)
+    d = np.abs(u_s - u_g).max(axis=1) / np.abs(u_g).max(axis=1)
+    assert d.max() <= 1e-9, float(d.max())
+
+
+def test_a_model_without_the_structural_constants_runs_the_shape_only_walk(tmp_path):
+    """A robot with the Dual-UR5's tree SHAPE but other numbers where the MJCF has its exact zeros and ones -- a tilted hinge axis, an
+    anchor off the body origin, a rotated body frame, a rotated inertial frame, a shifted frame origin -- must not get the walk those
+    constants are compiled into: irlosc_set_model falls back to the shape-only instantiation (still the fused path), and the result
+    equals the chained oracles on the SAME perturbed model."""
+    import copy
+    import json
+    from irl_control_amd.rigid_body import DUAL_UR5_EE, RigidBodyModel
+    from oracle import rigid_body as rb
+    base = RigidBodyModel.load("dual_ur5")
+    table = copy.deepcopy(base.table)
+    bodies = table["bodies"]
+    nrm = lambda v: [float(x) for x in (np.asarray(v, float) / np.linalg.norm(v))]
+    hinge_bodies = [i for i, b in enumerate(bodies) if b["joint"]]
+    bodies[hinge_bodies[3]]["joint"]["axis"] = nrm([1.0, 0.15, -0.1])          # a hinge that is no coordinate axis
+    bodies[hinge_bodies[9]]["joint"]["pos"] = [0.01, -0.02, 0.005]             # an anchor off the body origin
+    bodies[10]["quat"] = nrm([0.99, 0.05, -0.08, 0.02])                        # ur_EE_ur5right no longer aligned with link6
+    bodies[2]["pos"] = [0.0, 0.0, 0.3]                                         # the base's EE frame off the stand's origin
+    bodies[5]["iquat"] = nrm([0.9, 0.3, 0.1, -0.2])                            # link2: inertial frame rotated
+    bodies[11]["ipos"] = [0.0, 0.003, 0.01]
+    path = tmp_path / "dual_ur5_perturbed.json"
+    path.write_text(json.dumps(table))
+    model = RigidBodyModel.load(str(path))
+    B = 96
+    lay = synth.make_layout("k13")
+    _, gains, g = synth.make_batch("k13", B, seed=5)
+    qpos, qvel = model.random_state(np.random.default_rng(6), B)
+    osc = BatchedOSC(lay, B, dtype=np.float64)
+    osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+    osc.set_model(model)
+    assert "compact_dual_ur5 +" in osc.from_q_name and "fused" in osc.from_q_name, osc.from_q_name
+    u = osc.step_from_q(qpos, qvel, g["tgt_pose"])
+    osc.close()
+    om = rb.Model(str(path))
+    recs = [rb.records(om, lay.as_oracle_dict(), DUAL_UR5_EE, qpos[b], qvel[b]) for b in range(B)]
+    R = {k: np.array([r[k] for r in recs]) for k in ("M", "J", "dq", "bias", "ee_pose")}
+    ref = osc_oracle.generate_batch(lay.as_oracle_dict(), gains, R["M"], R["J"], R["dq"], R["bias"], R["ee_pose"], g["tgt_pose"])
+    dom = np.array([in_parity_domain(*osc_oracle.task_inertia(R["J"][b], R["M"][b])[2:]) for b in range(B)])
+    assert dom.sum() >= B // 2 and rel_err(u, ref)[dom].max() <= TOL64
+    # and the shipped model, same states: the structural walk, another answer (the perturbation matters)
+    osc = BatchedOSC(lay, B, dtype=np.float64)
+    osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+    osc.set_model(base)
+    assert "compact_dual_ur5_s +" in osc.from_q_name
+    u0 = osc.step_from_q(qpos, qvel, g["tgt_pose"])
+    osc.close()
+    assert np.abs(u0 - u).max() > 1e-3
+
+
 @pytest.mark.parametrize("B", [1, 3, 63, 64, 65, 130, 515])
 def test_fused_from_q_ragged_batches_bit_exact(B):
     """A walk wave carries 64 robots, a row16 block 4, and the block -> robots map groups 128 blocks per 8 walk waves: batch
@@ -1674,9 +1743,9 @@ def test_a_fused_step_leaves_no_records_in_the_slot():
     u_fused = osc.step_q()
     assert rel_err(u_fused, u_rec.astype(np.float64)).max() <= 1e-9
     assert not osc.slot_structure(0)
-    with pytest.raises(_lib.IrloscError, match="must precede a step"):
+    with pytest.raises(_lib.IrloscError, match="invalidated"):      # (the text names the fused step as the reason: ADVICE r4)
         osc.step()
-    with pytest.raises(_lib.IrloscError, match="must precede a step"):
+    with pytest.raises(_lib.IrloscError, match="invalidated"):
         osc.step_resident(3)
     with pytest.raises(_lib.IrloscError, match="holds state for 0 instances"):
         osc.download_records(0)
