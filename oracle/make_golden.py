@@ -75,12 +75,16 @@ def quat_about(axis, angle):
 
 def make_case(name, seed, B, cfg_file, target_order, dev_gain_names, nullspace=True, use_g=True,
               admittance=False, all_actuated=False, branch_b=False, degenerate=None, gimbal=False,
-              random_gains=False, no_max_vel=(), n_free_bodies=0):
+              random_gains=False, no_max_vel=(), n_free_bodies=0, dof_override=None):
+    """dof_override: {device name: (ctrlr_dof_xyz, ctrlr_dof_abg)} replaces the YAML's row masks (device.py:36) -- the layouts a caller
+    reaches with another YAML; target_order may name any subset of the robot's devices (osc.py:134-138 stacks J over the targets)."""
     rng = np.random.default_rng(seed)
     cfg = load_cfg(cfg_file)
     for d in cfg["devices"]:
         if d["name"] in no_max_vel:
             d.pop("max_vel")
+        if dof_override and d["name"] in dof_override:
+            d["ctrlr_dof_xyz"], d["ctrlr_dof_abg"] = [list(map(bool, m)) for m in dof_override[d["name"]]]
     rec = {k: [] for k in ("M", "J", "dq", "bias", "ee_pose", "tgt_pose", "wrench", "tgt_vel",
                            "kp", "kv", "ko", "kk", "dd", "max_vel", "null_kv",
                            "Mx", "M_inv", "Mx_inv", "det", "forces_flat")}
@@ -637,3 +641,17 @@ if __name__ == "__main__":
     # reference's own loop bodies on scripted input streams
     make_teleop_golden("loop_space_mouse", "space_mouse", 5, 200)
     make_teleop_golden("loop_ps_move", "ps_move", 6, 200)
+    # round 5: layouts beyond the four of the shipped examples -- target SUBSETS and other row masks -- which the HIP path runs on the
+    # KMAX-padded row16 kernels: the reference's own answers for them (its OSC.generate stacks J over whatever targets it is handed)
+    T, F = True, False
+    make_case("k6_single_arm", S + 31, 16, "default_xyz_abg.yaml", ("ur5right",), [("ur5right", "osc2")], all_actuated=True)
+    make_case("k3_single_arm_xyz", S + 32, 16, "default_xyz.yaml", ("ur5left",), [("ur5left", "osc2")], all_actuated=True)
+    make_case("k7_base_and_arm", S + 33, 16, "default_xyz_abg.yaml", ("base", "ur5left"), [("base", "osc0"), ("ur5left", "osc2")],
+              all_actuated=True)
+    make_case("k10_mixed_masks", S + 34, 16, "default_xyz_abg.yaml", RLB, G_GAIN, all_actuated=True,
+              dof_override={"ur5left": ([T, T, T], [F, F, F])})
+    make_case("k9_admittance_masks", S + 35, 16, "default_xyz_abg.yaml", ("ur5right", "ur5left"), G_ADMIT, admittance=True,
+              all_actuated=True, n_free_bodies=2, dof_override={"ur5left": ([T, F, T], [F, T, F])})
+    # a device asked for rows no joint can move (the stand only yaws): exact zero rows of J, det = 0, the reference's pinv drops them
+    make_case("k15_base_three_rows", S + 36, 16, "default_xyz_abg.yaml", RLB, G_GAIN, all_actuated=True,
+              dof_override={"base": ([F, F, F], [T, T, T])})
