@@ -652,6 +652,7 @@ if __name__ == "__main__":
               dof_override={"ur5left": ([T, T, T], [F, F, F])})
     make_case("k9_admittance_masks", S + 35, 16, "default_xyz_abg.yaml", ("ur5right", "ur5left"), G_ADMIT, admittance=True,
               all_actuated=True, n_free_bodies=2, dof_override={"ur5left": ([T, F, T], [F, T, F])})
+    make_e2e_case("e2e_single_arm", S + 37, 6, "default_xyz_abg.yaml", ("ur5right",), [("ur5right", "osc2")], n_free_bodies=1)
     # a device asked for rows no joint can move (the stand only yaws): exact zero rows of J, det = 0, the reference's pinv drops them
     make_case("k15_base_three_rows", S + 36, 16, "default_xyz_abg.yaml", RLB, G_GAIN, all_actuated=True,
               dof_override={"base": ([F, F, F], [T, T, T])})

@@ -76,9 +76,10 @@ def assemble_device(osc, hb, desc, arrs, B, slot=0):
 
 
 @pytest.mark.parametrize("entry", ["upload_raw", "assemble_device"])
-@pytest.mark.parametrize("name", ["e2e_gain_test", "e2e_admit_test"])
+@pytest.mark.parametrize("name", ["e2e_gain_test", "e2e_admit_test", "e2e_single_arm"])
 def test_raw_arrays_through_device_assembly_give_the_references_forces(name, entry):
-    """fixture raw arrays (nv = 25: gain_test, k = 7; nv = 37: admit_test, k = 12 + wrench) -> assembly ON THE GPU -> step ->
+    """fixture raw arrays (nv = 25: gain_test, k = 7; nv = 37: admit_test, k = 12 + wrench; nv = 31: one arm alone, k = 6 on the padded
+    kernel) -> assembly ON THE GPU -> step ->
     the reference's forces, fp64 <= 1e-5 (measured ~1e-12); the assembled records equal the reference's assembled M / J / dq
     bit for bit; flags equal the reference's branch."""
     g = load_e2e(name)

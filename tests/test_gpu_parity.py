@@ -192,7 +192,7 @@ def test_per_instance_gains_and_branch_b_batch():
     assert rel_err(u[idx], ref[idx])[dom].max() <= TOL64
 
 
-@pytest.mark.parametrize("name", ["e2e_gain_test", "e2e_admit_test"])
+@pytest.mark.parametrize("name", ["e2e_gain_test", "e2e_admit_test", "e2e_single_arm"])
 def test_osc_generate_end_to_end_vs_reference(name):
     """Drop-in check: the build's MujocoApp/Robot/Device/OSC.generate on a FakeSim reproduces the
     reference's (force_idxs, forces) for the gain_test and admit_test call patterns."""

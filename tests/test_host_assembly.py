@@ -9,7 +9,7 @@ from irl_control_amd import DeviceState, RobotState
 from conftest import app_from_e2e, load_e2e
 
 
-@pytest.mark.parametrize("name", ["e2e_gain_test", "e2e_admit_test"])
+@pytest.mark.parametrize("name", ["e2e_gain_test", "e2e_admit_test", "e2e_single_arm"])
 def test_assembly_matches_reference(name):
     g = load_e2e(name)
     meta = g["meta"]
