@@ -664,6 +664,7 @@ static void fill_params(const irlosc_ctx* c, KParams<T>& p, int B, const void* M
     p.dbg = c->ddbg;
     p.gains_per_instance = c->gains_nb > 1;
     p.B = B; p.n = c->cfg.n; p.k = c->k; p.ndev = c->cfg.ndev; p.cfgflags = c->cfg.flags;
+    p.padded = c->kernel_class == IRLOSC_CLASS_ROW16_PADDED ? 1 : 0;      // decided once, at irlosc_create (IRLOSC_FORCE_PAD is read there)
     int row = 0;
     for (int d = 0; d < c->cfg.ndev; ++d) {
         DevMeta& m = p.dev[d];
@@ -1252,7 +1253,6 @@ extern "C" int irlosc_set_model(irlosc_ctx* c, const irlosc_model* m) {
         for (int s2 = 0; s2 < c->cfg.n_slots; ++s2) {
             HIPCHK(c, hipMalloc((void**)&c->dqpos[s2], (size_t)c->cfg.max_batch * c->cfg.n * sizeof(double)));
             HIPCHK(c, hipMalloc((void**)&c->dqvel[s2], (size_t)c->cfg.max_batch * c->cfg.n * sizeof(double)));
-            HIPCHK(c, hipMalloc((void**)&c->dqt[s2], (((size_t)c->cfg.max_batch + 63) / 64) * 2 * c->cfg.n * 64 * sizeof(double)));
         }
     }
     return IRLOSC_OK;
@@ -1271,7 +1271,11 @@ extern "C" int irlosc_upload_q(irlosc_ctx* c, int32_t slot, int32_t B, const dou
     HIPCHK(c, hipMemcpyAsync(c->dqvel[slot], qvel, bytes, hipMemcpyHostToDevice, c->stream));
     // the fused walk reads its own layout of the same numbers ([wave][2 n][64 robots]: coalesced, hinge by hinge): one small kernel
     // behind the copies (10 us per 65 536 robots against 0.8 ms of PCIe for them)
-    HIPCHK(c, (hipError_t)launch_q_layout(c->dqpos[slot], c->dqvel[slot], c->dqt[slot], B, c->cfg.n, c->stream));
+    if (c->fused) {      // (only the fused path reads this layout; its buffer is allocated by the slot's first upload)
+        if (!c->dqt[slot])
+            HIPCHK(c, hipMalloc((void**)&c->dqt[slot], (((size_t)c->cfg.max_batch + 63) / 64) * 2 * c->cfg.n * 64 * sizeof(double)));
+        HIPCHK(c, (hipError_t)launch_q_layout(c->dqpos[slot], c->dqvel[slot], c->dqt[slot], B, c->cfg.n, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->has_q[slot] = B;
     return IRLOSC_OK;
@@ -1385,6 +1389,10 @@ static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, hipStream_
         const int sl = slots[i];
         ft.qpos[i] = ga.qpos[i] = c->dqpos[sl];
         ft.qvel[i] = ga.qvel[i] = c->dqvel[sl];
+        if (!c->dqt[sl]) {      // coordinates uploaded before the model made the fused path available: lay them out now
+            HIPCHK(c, hipMalloc((void**)&c->dqt[sl], (((size_t)c->cfg.max_batch + 63) / 64) * 2 * c->cfg.n * 64 * sizeof(double)));
+            HIPCHK(c, (hipError_t)launch_q_layout(c->dqpos[sl], c->dqvel[sl], c->dqt[sl], std::max(1, c->has_q[sl]), c->cfg.n, st));
+        }
         ft.qt[i] = c->dqt[sl];
         ft.side[i] = c->fe_xside[i];
         fill_params<T>(c, tr.p[i], B, c->dM[sl], c->dJ[sl], c->ddq[sl], c->dbias[sl], c->dee[sl], c->dtgt[sl],

@@ -56,6 +56,7 @@ struct KParams {
     int32_t gains_per_instance;
     int32_t B, n, k, ndev;
     uint32_t cfgflags;
+    int32_t padded;              // host-side launch choice (irlosc_create: IRLOSC_CLASS_ROW16_PADDED): the KMAX-padded row16 variant; kernels ignore it
     DevMeta dev[IRLOSC_MAX_DEV];
 };
 

@@ -1335,7 +1335,7 @@ __global__ __launch_bounds__(64 * NDEV) void osc_task_rows_fromq_kernel(const Ro
 
 // Shapes with an instantiation of their own (tuned: register budget, prefetch depth) ...
 inline bool row16_kernel_exact(int n, int k, int ndev) {
-    const char* e = getenv("IRLOSC_FORCE_PAD");      // A/B aid: the padded variant on a shape that has an instantiation (tests, tools/layout_sweep.py)
+    const char* e = getenv("IRLOSC_FORCE_PAD");      // A/B aid, read by irlosc_create only: the padded variant on a shape that has an instantiation
     if (e && e[0] == '1') return false;
     return n == 25 && ((k == 13 && ndev == 3) || (k == 12 && ndev == 2) || (k == 7 && ndev == 3) || (k == 6 && ndev == 2));
 }

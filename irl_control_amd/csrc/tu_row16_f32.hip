@@ -13,7 +13,7 @@ int launch_row16(const Row16Train<TIN>& tr, int nsteps, bool tree, hipStream_t s
     const KParams<TIN>& p = tr.p[0];
     if (p.B <= 0 || nsteps <= 0) return 0;
     const dim3 grid((p.B + 3) / 4, nsteps);
-    if (!row16_kernel_exact(p.n, p.k, p.ndev))      // every other n = 25 layout: the KMAX-padded variants (tu_row16_pad_impl.hpp)
+    if (p.padded)      // every other n = 25 layout: the KMAX-padded variants (tu_row16_pad_impl.hpp)
         return tree ? launch_row16_pad_tree<TIN>(tr, nsteps, st) : launch_row16_pad_dense<TIN>(tr, nsteps, st);
     if (tree) {
         if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25, false, TopoDualUr5>), grid, dim3(64), 0, st, tr);
@@ -40,7 +40,7 @@ int launch_row16_fromq(const Row16Train<TIN>& tr, int nsteps, hipStream_t st) {
     if (p.B <= 0 || nsteps <= 0) return 0;
     const int waves = (p.B + 63) / 64;
     const dim3 grid(waves * 4, nsteps), tgrid(waves, nsteps);      // the task pass first: one lane per robot, block = walk wave
-    if (!row16_kernel_exact(p.n, p.k, p.ndev)) return launch_row16_pad_fromq<TIN>(tr, nsteps, st);
+    if (p.padded) return launch_row16_pad_fromq<TIN>(tr, nsteps, st);
     if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<13, 3, TIN, TopoDualUr5>), tgrid, dim3(64 * 3), 0, st, tr);
     else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<12, 2, TIN, TopoDualUr5>), tgrid, dim3(64 * 2), 0, st, tr);
     else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<7, 3, TIN, TopoDualUr5>), tgrid, dim3(64 * 3), 0, st, tr);
