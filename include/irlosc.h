@@ -301,9 +301,15 @@ typedef struct irlosc_model {
 /* Validates the tree (parents precede children, one body per hinge, masses >= 0) and allocates per slot qpos / qvel of
  * max_batch robots.  A model with the compiled Dual-UR5 tree shape selects the lane-per-robot kernel -- its side buffer of
  * ceil(max_batch / 64) x 266 x 512 bytes (139 MB at 65 536 robots) is allocated by the first irlosc_frontend; if that fails the
- * context drops to the generic kernel -- any other tree the generic kernel. */
+ * context drops to the generic kernel -- any other tree the generic kernel.  The fused path's walk (irlosc_step_from_q) exists twice
+ * for that shape: with the structural constants of the Dual-UR5's MJCF compiled in (body frames not rotated against / coincident with
+ * their parent's, hinges about coordinate axes through their body's origin, inertial frames aligned with the body frame: csrc/topo_dual_ur5.hpp,
+ * TopoDualUr5S) and shape-only; the model's numbers are checked against those constants here and decide which one runs
+ * (irlosc_from_q_name says: "..._dual_ur5_s + ..." is the first). */
 IRLOSC_API int irlosc_set_model(irlosc_ctx* ctx, const irlosc_model* model);
-/* Joint positions and velocities of one batch into resident slot `slot`: qpos[B][n], qvel[B][n], always double. */
+/* Joint positions and velocities of one batch into resident slot `slot`: qpos[B][n], qvel[B][n], always double.  On a context whose
+ * model takes the fused path the library keeps a second copy in the walk's own layout ([ceil(B / 64)][2 n][64 robots]: a hinge's pair is two
+ * coalesced loads), written by a small kernel behind the copies. */
 IRLOSC_API int irlosc_upload_q(irlosc_ctx* ctx, int32_t slot, int32_t B, const double* qpos, const double* qvel);
 /* Run the front end on the slot's (qpos, qvel): fills its M, J, dq, bias, ee_pose records (asynchronous, context's
  * stream); irlosc_set_targets + irlosc_step then work as after irlosc_upload.  Afterwards the slot holds the records of
