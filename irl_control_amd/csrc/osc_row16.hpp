@@ -735,6 +735,13 @@ void osc_row16_kernel(const Row16Train<TIN> tr) {
     auto tile_at = [&](const unsigned row_off) -> double {          // row_off = entry x FE_TILE_ROW_BYTES (from the tables)
         return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(Tile) + (row_off + rob8));
     };
+    // IRLOSC_PHASE_TIMING=1 debug runs: cycle stamps per phase and the wall clock of the wave (p.dbg != nullptr);
+    // FROMQ: the tile fill below belongs to the first phase
+    unsigned long long ts[8];
+    const unsigned long long rt0 = (p.dbg || x.span) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long cyc0 = x.span ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
+#define IRLOSC_TS(i) ts[i] = p.dbg ? __builtin_readcyclecounter() : 0ull
+    IRLOSC_TS(0);
     if constexpr (FROMQ) {
         const FeCompactTables* __restrict__ tb = x.tables;
         const double* __restrict__ src = x.side + ((size_t)(blk >> 2) * BLK_E) * 64 + (blk & 3) * 16;
@@ -760,12 +767,6 @@ void osc_row16_kernel(const Row16Train<TIN> tr) {
 
     double* Jq = Jl + (FROMQ ? 0 : q * ((K + 1) * N));      // (dense records only)
     uint32_t flags = 0;
-    // IRLOSC_PHASE_TIMING=1 debug runs: cycle stamps per phase and the wall clock of the wave (p.dbg != nullptr)
-    unsigned long long ts[8];
-    const unsigned long long rt0 = (p.dbg || x.span) ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    const unsigned long long cyc0 = x.span ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
-#define IRLOSC_TS(i) ts[i] = p.dbg ? __builtin_readcyclecounter() : 0ull
-    IRLOSC_TS(0);
 
     // ---- the inputs of the task-space signal FIRST: s_waitcnt counts loads in issue order, so whoever is requested last
     // waits for everything before it.  Requested ahead of the 8 rows of M and the 26 words of J per lane, the poses /
