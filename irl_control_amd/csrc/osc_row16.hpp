@@ -859,7 +859,8 @@ void osc_row16_kernel(const Row16Train<TIN> tr) {
         // Part 1 arrives as k rows of the tile (osc_task_rows_fromq_kernel, one lane per robot, ran between the walk and this
         // kernel): lane l takes row l (rows >= k: the entry of zeros); the device lanes only leave the velocity gain and the
         // damping-branch verdict of their device (osc.py:173).  405 of the ~2 650 VALU instructions of a wave went into sixteen
-        // lanes per robot each running the pipeline for one Euler angle; with the operands in LDS this kernel is issue-bound.
+        // lanes per robot each running the pipeline for one Euler angle.  (Computing the rows HERE, by wave 0 while the tile arrives,
+        // was measured in round 5: the other three waves wait at the barrier for its ~450 dependent instructions -- profiles/NOTES.md.)
         bool all_nonzero = has_tv;
 #pragma unroll
         for (int i = 0; i < 6; ++i) all_nonzero = all_nonzero & ((double)tv_in[i] != 0.0);
@@ -1148,7 +1149,9 @@ void osc_row16_kernel(const Row16Train<TIN> tr) {
     // (Handing the flagged instances to a pass of their own, four to a wave, was built and measured in round 3: the main
     // kernel drops from 1 212 to 1 045 us per train of 8 and the pass costs 140 us -- zero-sum.  eigen16 is chains of
     // dependent broadcast-FMAs that issue at a fraction of the main loop's rate; here they hide behind the wave-mate's
-    // main loop, in a pass of their own two such chains share a SIMD.  profiles/r03c_eigen_handover_experiment_*.)
+    // main loop, in a pass of their own two such chains share a SIMD.  profiles/r03c_eigen_handover_experiment_*.  Round 5 repeated
+    // it for the fused path, whose blocks of four waves wait for their slowest wave: OSC kernel 821 -> 637 us, pass 176 us at three
+    // waves per SIMD -- the stage costs the same SIMD time per flagged robot wherever it runs.  profiles/NOTES.md.)
     bool giveup = false;
     if (__any(!plain)) {
         double t2 = 0.0;
