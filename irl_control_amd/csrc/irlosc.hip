@@ -84,6 +84,7 @@ struct irlosc_ctx {
     FeCompactTables* dtables = nullptr;
     size_t fe_xentries = 0;
     double* fe_xside[R16_TRAIN] = {};
+    double* dtrows[R16_TRAIN] = {};        // float32 records on the row16 path: task rows of each step of a train (osc_task_rows_dense_kernel)
     int fused = 0;
     int fused_train = R16_TRAIN;
     std::vector<double*> dqpos, dqvel;
@@ -198,6 +199,7 @@ static void free_all(irlosc_ctx* c) {
     if (c->fe_side) (void)hipFree(c->fe_side);
     if (c->dtables) (void)hipFree(c->dtables);
     for (int k = 0; k < R16_TRAIN; ++k) if (c->fe_xside[k]) (void)hipFree(c->fe_xside[k]);
+    for (int k = 0; k < R16_TRAIN; ++k) if (c->dtrows[k]) (void)hipFree(c->dtrows[k]);
     for (double* p : c->dqpos) if (p) (void)hipFree(p);
     for (double* p : c->dqvel) if (p) (void)hipFree(p);
     for (double* p : c->dqt) if (p) (void)hipFree(p);
@@ -275,6 +277,11 @@ static int create_impl(irlosc_ctx* c) {
         HIPCHK(nullptr, hipMemsetAsync(c->dzeros, 0, ZB, c->stream));
         for (int k2 = 0; k2 < R16_TRAIN; ++k2) HIPCHK(nullptr, hipMalloc((void**)&c->dr16_list[k2], B * sizeof(int32_t)));
         HIPCHK(nullptr, hipMalloc((void**)&c->dr16_count, R16_TRAIN * sizeof(int32_t)));
+        {   // float32 records: part 1 of the task signal runs as a pass ahead of the row16 kernel (IRLOSC_TASK_PASS=0: in the kernel; A/B, tests)
+            const char* e = getenv("IRLOSC_TASK_PASS");
+            if (c->cfg.dtype == IRLOSC_F32 && !(e && !strcmp(e, "0")))
+                for (int k2 = 0; k2 < R16_TRAIN; ++k2) HIPCHK(nullptr, hipMalloc((void**)&c->dtrows[k2], (size_t)B * 16 * sizeof(double)));
+        }
         HIPCHK(nullptr, hipMemsetAsync(c->dr16_count, 0, R16_TRAIN * sizeof(int32_t), c->stream));
     }
     c->du = c->du_set[0];
@@ -778,7 +785,7 @@ static int row16_train(irlosc_ctx* c, const KParams<T>* ps, int n, bool tree, hi
     for (int i = 0; i < n; ++i) {
         const int o = pos ? pos[i] : i;
         tr.p[i] = ps[i];
-        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[o], c->dr16_count + o, nullptr, nullptr, nullptr, c->span_next};
+        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[o], c->dr16_count + o, nullptr, nullptr, nullptr, c->span_next, c->dtrows[i]};
     }
     if (c->tev_begin) HIPCHK(c, hipEventRecord(c->tev_begin, st));
     int rc = launch_row16<T>(tr, n, tree, st);

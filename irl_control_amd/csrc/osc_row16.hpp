@@ -609,6 +609,9 @@ struct Row16Extra {
     // R16_SPAN_SLOTS pairs per TRAIN (every step of a train points at the same block; a wave uses pair blockIdx.x % slots: 131 072
     // waves hammering ONE address serialise in the L2 -- measured: a train took 3.07 ms instead of 0.85); nullptr = no stamps
     unsigned long long* span;
+    // float32 records (the mixed path): part 1 of the task-space signal as k rows per instance, [B][16] doubles, left by
+    // osc_task_rows_dense_kernel ahead of this kernel; nullptr: computed in the kernel (always, on float64 records)
+    const double* trows;
 };
 
 // One launch = a TRAIN of up to R16_TRAIN steps (blockIdx.y = step): consecutive steps of irlosc_step_resident are
@@ -777,11 +780,22 @@ void osc_row16_kernel(const Row16Train<TIN> tr) {
     const int dd = dv < nd ? dv : nd - 1;
     TM ee_in[7];
     TIN tg_in[7], g_in[IRLOSC_GAIN_WORDS], tv_in[6];
+    // float32 records: part 1 of the task signal may arrive as rows (Row16Extra::trows, osc_task_rows_dense_kernel) -- this kernel
+    // is issue-bound there (VALU busy 86 %) and the ~405 instructions of part 1, run by sixteen lanes per instance here, cost it 70 us
+    // per train; one lane per (instance, device) does them in a pass of half that.  On float64 records the pass would move as many
+    // bytes as it saves time (NOTES.md, round 5): `pre` is a compile-time false there.
+    constexpr bool TPASS = !FROMQ && std::is_same_v<TIN, float>;
+    bool pre = false;
+    if constexpr (TPASS) pre = x.trows != nullptr;
+    double trow_in = 0.0;
     {
         const TIN* __restrict__ tgp = p.tgt + ((size_t)bc * nd + dd) * 7;
         const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * nd * IRLOSC_GAIN_WORDS : 0) + dd * IRLOSC_GAIN_WORDS;
         if constexpr (FROMQ) {      // part 1 of the task signal was computed by the task pass: only the velocity gain is needed here
             g_in[1] = gp[1];
+        } else if (pre) {
+            g_in[1] = gp[1];
+            trow_in = l < kr ? x.trows[(size_t)bc * 16 + l] : 0.0;
         } else {
             const TIN* __restrict__ eep = p.ee + ((size_t)bc * nd + dd) * 7;
 #pragma unroll
@@ -855,7 +869,7 @@ void osc_row16_kernel(const Row16Train<TIN> tr) {
     const bool has_wr = (p.cfgflags & IRLOSC_ADMITTANCE) && p.wrench != nullptr;
     const DevMeta dm = p.dev[dd];
     bool own_brB = false;
-    if constexpr (FROMQ) {
+    if (FROMQ || pre) {
         // Part 1 arrives as k rows of the tile (osc_task_rows_fromq_kernel, one lane per robot, ran between the walk and this
         // kernel): lane l takes row l (rows >= k: the entry of zeros); the device lanes only leave the velocity gain and the
         // damping-branch verdict of their device (osc.py:173).  405 of the ~2 650 VALU instructions of a wave went into sixteen
@@ -865,7 +879,8 @@ void osc_row16_kernel(const Row16Train<TIN> tr) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) all_nonzero = all_nonzero & ((double)tv_in[i] != 0.0);
         own_brB = all_nonzero && dv < nd;            // np.all(target_vel) == 0 quirk, osc.py:173
-        Wl[q][l] = tile_at(Te[l]);
+        if constexpr (FROMQ) Wl[q][l] = tile_at(Te[l]);
+        else Wl[q][l] = trow_in;               // (float32 records with the task pass: rows >= k are zeros)
         if (ang_id == 0 && dv < nd) {
             Kvl[q][dv] = (double)g_in[1];
             Brl[q][dv] = all_nonzero ? 0 : 1;
@@ -1335,6 +1350,64 @@ __global__ __launch_bounds__(64 * NDEV) void osc_task_rows_fromq_kernel(const Ro
 #pragma unroll
     for (int i = 0; i < 6; ++i)
         if (dm.dofmask & (1u << i)) { col[(size_t)(e0 + dm.row0 + cnt) * 64] = e[i]; ++cnt; }
+}
+
+// float32 records (the mixed path): part 1 of the task-space signal (calc_error, velocity limit, gains, stiffness: osc.py:101-118,
+// 70-99,160-168) as a pass ahead of the row16 kernel -- ONE LANE PER (INSTANCE, DEVICE): block x = instances 64 x .. 64 x + 63, wave d =
+// target device d (the block has 64 x ndev threads), blockIdx.y = step.  Reads pose, target and gains of its pair, leaves the k gained
+// error rows of the block's instances in Row16Extra::trows ([B][16] doubles; rows >= k: zeros), transposed through LDS so that the
+// 8 KB go out as whole lines.  Same formulas, in the same order, as the in-kernel form (task_rot, atan2, apply_gains6_fast): the
+// row16 kernel's results do not depend on which of the two ran.
+template <typename TIN>
+__global__ __launch_bounds__(64 * IRLOSC_MAX_DEV) void osc_task_rows_dense_kernel(const Row16Train<TIN> tr) {
+    using namespace r16;
+    const KParams<TIN>& p = tr.p[blockIdx.y];
+    const Row16Extra& x = tr.x[blockIdx.y];
+    const int nd = p.ndev;
+    const int lane = threadIdx.x & 63;
+    const int d = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x * 64 + lane;
+    const int bc = b < p.B ? b : p.B - 1;
+    __shared__ double rows[64][17];
+    for (int i = threadIdx.x; i < 64 * 17; i += blockDim.x) (&rows[0][0])[i] = 0.0;
+    const DevMeta dm = p.dev[d];
+    const TIN* __restrict__ eep = p.ee + ((size_t)bc * nd + d) * 7;
+    const TIN* __restrict__ tgp = p.tgt + ((size_t)bc * nd + d) * 7;
+    const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * nd * IRLOSC_GAIN_WORDS : 0) + d * IRLOSC_GAIN_WORDS;
+    TIN ee_in[7], tg_in[7], g_in[IRLOSC_GAIN_WORDS];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) ee_in[i] = eep[i];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) tg_in[i] = tgp[i];
+#pragma unroll
+    for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) g_in[i] = gp[i];
+    double ee[7], tg[7], g[IRLOSC_GAIN_WORDS];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { ee[i] = (double)ee_in[i]; tg[i] = (double)tg_in[i]; }
+#pragma unroll
+    for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) g[i] = (double)g_in[i];
+    double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (dm.calc & 1u) { e[0] = ee[0] - tg[0]; e[1] = ee[1] - tg[1]; e[2] = ee[2] - tg[2]; }
+    if (dm.calc & 2u) {
+        const TaskRot R = task_rot(ee, tg);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            double ay, ax;
+            R.angle_args(a, ay, ax);
+            e[3 + a] = atan2(ay, ax);
+        }
+    }
+    apply_gains6_fast(g, e);
+    __syncthreads();                               // the zeros are in place
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        if (dm.dofmask & (1u << i)) { rows[lane][dm.row0 + cnt] = e[i]; ++cnt; }
+    __syncthreads();
+    double* __restrict__ out = const_cast<double*>(x.trows) + (size_t)blockIdx.x * (64 * 16);
+    const size_t last = (size_t)p.B * 16;
+    for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x)
+        if ((size_t)blockIdx.x * (64 * 16) + i < last) out[i] = rows[i >> 4][i & 15];
 }
 
 // Shapes with an instantiation of their own (tuned: register budget, prefetch depth) ...
