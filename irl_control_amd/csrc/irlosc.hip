@@ -84,7 +84,7 @@ struct irlosc_ctx {
     FeCompactTables* dtables = nullptr;
     size_t fe_xentries = 0;
     double* fe_xside[R16_TRAIN] = {};
-    double* dtrows[R16_TRAIN] = {};        // float32 records on the row16 path: task rows of each step of a train (osc_task_rows_dense_kernel)
+    double* dtrows[R16_TRAIN] = {};        // row16 path on dense records: task rows of each step of a train (osc_task_rows_dense_kernel)
     int fused = 0;
     int fused_train = R16_TRAIN;
     std::vector<double*> dqpos, dqvel;
@@ -277,9 +277,9 @@ static int create_impl(irlosc_ctx* c) {
         HIPCHK(nullptr, hipMemsetAsync(c->dzeros, 0, ZB, c->stream));
         for (int k2 = 0; k2 < R16_TRAIN; ++k2) HIPCHK(nullptr, hipMalloc((void**)&c->dr16_list[k2], B * sizeof(int32_t)));
         HIPCHK(nullptr, hipMalloc((void**)&c->dr16_count, R16_TRAIN * sizeof(int32_t)));
-        {   // float32 records: part 1 of the task signal runs as a pass ahead of the row16 kernel (IRLOSC_TASK_PASS=0: in the kernel; A/B, tests)
+        {   // part 1 of the task signal runs as a pass ahead of the row16 kernel (IRLOSC_TASK_PASS=0: in the kernel; A/B, tests)
             const char* e = getenv("IRLOSC_TASK_PASS");
-            if (c->cfg.dtype == IRLOSC_F32 && !(e && !strcmp(e, "0")))
+            if (!(e && !strcmp(e, "0")))
                 for (int k2 = 0; k2 < R16_TRAIN; ++k2) HIPCHK(nullptr, hipMalloc((void**)&c->dtrows[k2], (size_t)B * 16 * sizeof(double)));
         }
         HIPCHK(nullptr, hipMemsetAsync(c->dr16_count, 0, R16_TRAIN * sizeof(int32_t), c->stream));

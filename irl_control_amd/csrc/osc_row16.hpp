@@ -609,8 +609,8 @@ struct Row16Extra {
     // R16_SPAN_SLOTS pairs per TRAIN (every step of a train points at the same block; a wave uses pair blockIdx.x % slots: 131 072
     // waves hammering ONE address serialise in the L2 -- measured: a train took 3.07 ms instead of 0.85); nullptr = no stamps
     unsigned long long* span;
-    // float32 records (the mixed path): part 1 of the task-space signal as k rows per instance, [B][16] doubles, left by
-    // osc_task_rows_dense_kernel ahead of this kernel; nullptr: computed in the kernel (always, on float64 records)
+    // dense records: part 1 of the task-space signal as k rows per instance, [B][16] doubles, left by osc_task_rows_dense_kernel
+    // ahead of this kernel; nullptr: computed in the kernel
     const double* trows;
 };
 
@@ -780,13 +780,12 @@ void osc_row16_kernel(const Row16Train<TIN> tr) {
     const int dd = dv < nd ? dv : nd - 1;
     TM ee_in[7];
     TIN tg_in[7], g_in[IRLOSC_GAIN_WORDS], tv_in[6];
-    // float32 records: part 1 of the task signal may arrive as rows (Row16Extra::trows, osc_task_rows_dense_kernel) -- this kernel
-    // is issue-bound there (VALU busy 86 %) and the ~405 instructions of part 1, run by sixteen lanes per instance here, cost it 70 us
-    // per train; one lane per (instance, device) does them in a pass of half that.  On float64 records the pass would move as many
-    // bytes as it saves time (NOTES.md, round 5): `pre` is a compile-time false there.
-    constexpr bool TPASS = !FROMQ && std::is_same_v<TIN, float>;
+    // Dense records: part 1 of the task signal may arrive as rows (Row16Extra::trows, osc_task_rows_dense_kernel).  Its ~405
+    // instructions, run by sixteen lanes per instance here, cost this kernel 47 us per train on float64 records and 70 us on float32
+    // records (where it is issue-bound); one lane per (instance, device) does them in a pass of ~30 us: 5.83 -> 5.99e8 and 7.19 ->
+    // 7.59e8 steps/s, bit for bit the same torques (profiles/NOTES.md, round 5).  x.trows == nullptr (IRLOSC_TASK_PASS=0): computed here.
     bool pre = false;
-    if constexpr (TPASS) pre = x.trows != nullptr;
+    if constexpr (!FROMQ) pre = x.trows != nullptr;
     double trow_in = 0.0;
     {
         const TIN* __restrict__ tgp = p.tgt + ((size_t)bc * nd + dd) * 7;
@@ -880,7 +879,7 @@ void osc_row16_kernel(const Row16Train<TIN> tr) {
         for (int i = 0; i < 6; ++i) all_nonzero = all_nonzero & ((double)tv_in[i] != 0.0);
         own_brB = all_nonzero && dv < nd;            // np.all(target_vel) == 0 quirk, osc.py:173
         if constexpr (FROMQ) Wl[q][l] = tile_at(Te[l]);
-        else Wl[q][l] = trow_in;               // (float32 records with the task pass: rows >= k are zeros)
+        else Wl[q][l] = trow_in;               // (dense records with the task pass: rows >= k are zeros)
         if (ang_id == 0 && dv < nd) {
             Kvl[q][dv] = (double)g_in[1];
             Brl[q][dv] = all_nonzero ? 0 : 1;
@@ -1352,7 +1351,7 @@ __global__ __launch_bounds__(64 * NDEV) void osc_task_rows_fromq_kernel(const Ro
         if (dm.dofmask & (1u << i)) { col[(size_t)(e0 + dm.row0 + cnt) * 64] = e[i]; ++cnt; }
 }
 
-// float32 records (the mixed path): part 1 of the task-space signal (calc_error, velocity limit, gains, stiffness: osc.py:101-118,
+// Dense records: part 1 of the task-space signal (calc_error, velocity limit, gains, stiffness: osc.py:101-118,
 // 70-99,160-168) as a pass ahead of the row16 kernel -- ONE LANE PER (INSTANCE, DEVICE): block x = instances 64 x .. 64 x + 63, wave d =
 // target device d (the block has 64 x ndev threads), blockIdx.y = step.  Reads pose, target and gains of its pair, leaves the k gained
 // error rows of the block's instances in Row16Extra::trows ([B][16] doubles; rows >= k: zeros), transposed through LDS so that the

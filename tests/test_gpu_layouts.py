@@ -139,17 +139,18 @@ def test_kernel_class_reports_the_generic_fallback():
     osc.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("cfg", ["k13", "k12_admit", "k13_branch_b", "k7", "r6", "rlbr10", "rlb16"])
-def test_float32_records_task_pass_changes_no_bit(cfg, monkeypatch):
-    """float32 records on the row16 path: part 1 of the task-space signal (osc.py:101-118,70-99,160-168) runs as a pass of its own ahead of
+def test_task_pass_changes_no_bit(cfg, dtype, monkeypatch):
+    """Dense records on the row16 path: part 1 of the task-space signal (osc.py:101-118,70-99,160-168) runs as a pass of its own ahead of
     the kernel (osc_task_rows_dense_kernel: one lane per (instance, device)); IRLOSC_TASK_PASS=0 keeps it inside the kernel (sixteen
     lanes per instance).  Same formulas in the same order: torques and flags identical, on exact and padded kernels, with the wrench
-    and the target-velocity branch, on a ragged batch."""
+    and the target-velocity branch, on a ragged batch, float64 and float32 records."""
     B = 4096 + 37
-    lay, gains, g = synth.make_batch(cfg, B, seed=91, dtype=np.float32)
-    u_p, fl_p, name = run_gpu(lay, gains, g, np.float32, kernel=_lib.KERNEL_ROW16)
+    lay, gains, g = synth.make_batch(cfg, B, seed=91, dtype=dtype)
+    u_p, fl_p, name = run_gpu(lay, gains, g, dtype, kernel=_lib.KERNEL_ROW16)
     monkeypatch.setenv("IRLOSC_TASK_PASS", "0")
-    u_k, fl_k, name_k = run_gpu(lay, gains, g, np.float32, kernel=_lib.KERNEL_ROW16)
+    u_k, fl_k, name_k = run_gpu(lay, gains, g, dtype, kernel=_lib.KERNEL_ROW16)
     assert "row16" in name and name == name_k
     assert np.array_equal(fl_p, fl_k) and np.array_equal(u_p, u_k, equal_nan=True)
     assert np.isfinite(u_p).all() and np.abs(u_p).max() > 0
