@@ -1367,24 +1367,36 @@ __global__ __launch_bounds__(64 * IRLOSC_MAX_DEV) void osc_task_rows_dense_kerne
     const int d = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int b = blockIdx.x * 64 + lane;
     const int bc = b < p.B ? b : p.B - 1;
-    __shared__ double rows[64][17];
-    for (int i = threadIdx.x; i < 64 * 17; i += blockDim.x) (&rows[0][0])[i] = 0.0;
+    // The poses and targets of the block's 64 instances are 64 x ndev x 7 consecutive words each: wave loads, all in flight together,
+    // transposed through LDS.  (Read straight per lane -- 7 x ndev-word strides, 64 lines per load instruction -- the texture addresser
+    // handles a line per cycle: 14 such loads per wave made this pass 63 us per train where its bytes take 45.)
+    constexpr int WMAX = 64 * IRLOSC_MAX_DEV * 7;
+    constexpr size_t SB = 2 * WMAX * sizeof(TIN) > 64 * 17 * sizeof(double) ? 2 * WMAX * sizeof(TIN) : 64 * 17 * sizeof(double);
+    __shared__ __align__(16) unsigned char smem_t[SB];              // poses + targets; afterwards the rows, [instance][16 + 1 pad]
+    TIN* const s_ee = reinterpret_cast<TIN*>(smem_t);
+    TIN* const s_tg = s_ee + WMAX;
+    double (*rows)[17] = reinterpret_cast<double (*)[17]>(smem_t);
+    {
+        const int T = 64 * nd;                                       // threads of the block = words per round
+        const size_t g0 = (size_t)blockIdx.x * 64 * nd * 7, glast = (size_t)p.B * nd * 7 - 1;
+        TIN ve[7], vt[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { const size_t g = g0 + threadIdx.x + (size_t)T * i; ve[i] = p.ee[g < glast ? g : glast]; }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { const size_t g = g0 + threadIdx.x + (size_t)T * i; vt[i] = p.tgt[g < glast ? g : glast]; }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { s_ee[threadIdx.x + T * i] = ve[i]; s_tg[threadIdx.x + T * i] = vt[i]; }
+    }
     const DevMeta dm = p.dev[d];
-    const TIN* __restrict__ eep = p.ee + ((size_t)bc * nd + d) * 7;
-    const TIN* __restrict__ tgp = p.tgt + ((size_t)bc * nd + d) * 7;
     const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * nd * IRLOSC_GAIN_WORDS : 0) + d * IRLOSC_GAIN_WORDS;
-    TIN ee_in[7], tg_in[7], g_in[IRLOSC_GAIN_WORDS];
+    double g[IRLOSC_GAIN_WORDS];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) ee_in[i] = eep[i];
+    for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) g[i] = (double)gp[i];
+    __syncthreads();                               // poses and targets are in LDS
+    double ee[7], tg[7];
+    // (a ragged last block: the lanes past the batch read the words the clamped loads left -- finite, never written out)
 #pragma unroll
-    for (int i = 0; i < 7; ++i) tg_in[i] = tgp[i];
-#pragma unroll
-    for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) g_in[i] = gp[i];
-    double ee[7], tg[7], g[IRLOSC_GAIN_WORDS];
-#pragma unroll
-    for (int i = 0; i < 7; ++i) { ee[i] = (double)ee_in[i]; tg[i] = (double)tg_in[i]; }
-#pragma unroll
-    for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) g[i] = (double)g_in[i];
+    for (int i = 0; i < 7; ++i) { ee[i] = (double)s_ee[(lane * nd + d) * 7 + i]; tg[i] = (double)s_tg[(lane * nd + d) * 7 + i]; }
     double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (dm.calc & 1u) { e[0] = ee[0] - tg[0]; e[1] = ee[1] - tg[1]; e[2] = ee[2] - tg[2]; }
     if (dm.calc & 2u) {
@@ -1397,7 +1409,7 @@ __global__ __launch_bounds__(64 * IRLOSC_MAX_DEV) void osc_task_rows_dense_kerne
         }
     }
     apply_gains6_fast(g, e);
-    __syncthreads();                               // the zeros are in place
+    __syncthreads();                               // every wave has its poses and targets in registers: the rows take their place
     int cnt = 0;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -1405,8 +1417,9 @@ __global__ __launch_bounds__(64 * IRLOSC_MAX_DEV) void osc_task_rows_dense_kerne
     __syncthreads();
     double* __restrict__ out = const_cast<double*>(x.trows) + (size_t)blockIdx.x * (64 * 16);
     const size_t last = (size_t)p.B * 16;
+    const int k = p.k;                             // (every row < k belongs to one device and has been written; the others are zeros)
     for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x)
-        if ((size_t)blockIdx.x * (64 * 16) + i < last) out[i] = rows[i >> 4][i & 15];
+        if ((size_t)blockIdx.x * (64 * 16) + i < last) out[i] = (i & 15) < k ? rows[i >> 4][i & 15] : 0.0;
 }
 
 // Shapes with an instantiation of their own (tuned: register budget, prefetch depth) ...
