@@ -663,7 +663,9 @@ def main():
         if "group" in kname:
             note = ":fused(stage 1 of %d chained steps + riding stage 2 of the previous launch)" % spl
         elif "row16" in kname:
-            note = ":step(all instances incl. the in-kernel truncated-pinv stage; + the give-up list launch)" + (
+            tpass = os.environ.get("IRLOSC_TASK_PASS", "1") != "0"
+            note = ":step(" + ("the task pass osc_task_rows_dense_kernel (part 1 of the task signal, one lane per (instance, device)) + the row16 "
+                               "kernel: " if tpass else "") + "all instances incl. the in-kernel truncated-pinv stage; + the give-up list launch)" + (
                 "; tree-structured factorisation M = L^T L on the dense records (their zero pattern verified at upload / by construction)"
                 if tree else "")
         prof = measured_profile(kname)
@@ -694,10 +696,14 @@ def main():
             roof["committed_profile"] = {
                 "file": "profiles/hbm_traffic.json", "entry": kname,
                 "rocprof_avg_us": prof["rocprof_avg_us"], "traffic_bytes_per_launch": prof.get("traffic_bytes_per_launch"),
-                "frac_rocprof": bytes_launch / (prof["rocprof_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                "note": "a kernel trace serialises dispatches: its per-dispatch average corresponds to untraced.kernel_span_us, not to "
-                        "ms_per_step x steps_per_launch (= untraced.period_us); profiles/README.md"}
-            roof.update(rocprof_avg_us=prof["rocprof_avg_us"], frac_rocprof=roof["committed_profile"]["frac_rocprof"],
+                "rocprof_pass_avg_us": prof.get("rocprof_pass_avg_us"),
+                # the step = task pass + row16 kernel: both durations of the committed trace count
+                "frac_rocprof": bytes_launch / ((prof["rocprof_avg_us"] + (prof.get("rocprof_pass_avg_us") or 0.0)) * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "note": "a kernel trace serialises dispatches: the row16 kernel's per-dispatch average corresponds to untraced.kernel_span_us "
+                        "(that kernel alone), the sum with the task pass to ms_per_step x steps_per_launch (= untraced.period_us, which also "
+                        "holds the give-up launch and the gaps); profiles/README.md"}
+            roof.update(rocprof_avg_us=prof["rocprof_avg_us"], rocprof_pass_avg_us=prof.get("rocprof_pass_avg_us"),
+                        frac_rocprof=roof["committed_profile"]["frac_rocprof"],
                         rocprof_source="profiles/hbm_traffic.json (committed kernel trace of this command on another box; not measured in this run)")
         res = dict(value=rate, ms_per_step=elapsed / steps * 1e3, kernel=kname, mode=mode, arith=arith,
                    records="float64" if esz == 8 else "float32", layout=lay, roofline=roof, workload=workload, sustained=sustained)

@@ -3,6 +3,7 @@
 # profiles/ quote, on ONE box with the library as committed.  Summaries under gpurun_out/ (raw rocprofv3 databases are deleted).
 T=${1:-r05k}
 python -m pytest tests -q -m gpu 2>&1 | tail -15 > gpurun_out/${T}_gpu_all.log; grep -E "passed|failed|error" gpurun_out/${T}_gpu_all.log
+python bench.py --no-from-q --no-end-to-end > gpurun_out/${T}_bench_before_the_trace.json 2> /dev/null      # (untraced, minutes before the trace: boxes drift)
 bash tools/gpu_profile.sh ${T}_f64 "double, 25, false, irlosc::TopoDualUr5" "osc_row16_f64_n25_k13+tree" > gpurun_out/profile_${T}_f64.log 2>&1
 bash tools/gpu_pmc_sq.sh ${T}_f64 "osc_row16_kernel" --no-from-q --no-end-to-end > gpurun_out/sq_${T}_f64.log 2>&1
 bash tools/gpu_profile.sh ${T}_mixed "float, 25, false, irlosc::TopoDualUr5" "osc_row16_f32in_f64_n25_k13+tree" --dtype mixed > gpurun_out/profile_${T}_mixed.log 2>&1
@@ -28,7 +29,7 @@ python tools/parity_sweep.py --seeds 8 > gpurun_out/${T}_parity_sweep.txt 2>&1
 python tools/parity_sweep.py --seeds 8 --stress >> gpurun_out/${T}_parity_sweep.txt 2>&1
 python tools/parity_sweep.py --seeds 8 --physical >> gpurun_out/${T}_parity_sweep.txt 2>&1
 python tools/parity_sweep.py --seeds 4 --stress --layout k12_admit >> gpurun_out/${T}_parity_sweep.txt 2>&1
-for f in default driver mixed k12_admit k7 b4096 b32768; do python -c "
+for f in before_the_trace default driver mixed k12_admit k7 b4096 b32768; do python -c "
 import json
 d=json.loads(open('gpurun_out/${T}_bench_$f.json').read().strip().splitlines()[-1]); r=d['roofline']; c=d['config']
 print('$f', '%.4g' % d['value'], '%.5f' % d['ms_per_step'], 'frac %.3f' % r['frac'], 'span', r.get('untraced_kernel_span_us'), 'sclk', r.get('sclk_mhz'), 'sustained', c.get('sustained_value'), 'from_q', c.get('from_q_value'), 'parity', c.get('parity_max_rel_err'), c.get('parity_n_over_tol'))
