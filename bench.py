@@ -674,7 +674,9 @@ def main():
         # (profiles/hbm_traffic.json) and says so under committed_profile; everything else in `roofline` is measured in THIS run
         roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=achieved / HBM_PEAK_GBS,
-                    traffic=prof.get("traffic_bytes_per_launch") if same else None,
+                    # (PMC bytes of the step's kernels: the row16 kernel + the task pass ahead of it)
+                    traffic=(prof.get("traffic_bytes_per_launch") + (prof.get("pass_traffic_bytes_per_launch") or 0.0))
+                    if same and prof.get("traffic_bytes_per_launch") else None,
                     traffic_source="committed_profile (PMC passes need a tracer; not measured in this run)" if same and prof.get("traffic_bytes_per_launch") else None,
                     kernel=kname + note, kernel_ms=ms_dom, steps_per_launch=spl, step_ms_events=ms_kernel,
                     whole_step_achieved=bytes_step / (ms_kernel * 1e-3) / 1e9,
