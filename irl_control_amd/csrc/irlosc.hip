@@ -21,6 +21,7 @@
 #include "osc_assemble.hpp"
 #include "osc_row16.hpp"
 #include "osc_frontend.hpp"
+#include "osc_lane_types.hpp"
 #include "launchers.hpp"
 
 using namespace irlosc;
@@ -87,6 +88,12 @@ struct irlosc_ctx {
     double* dtrows[R16_TRAIN] = {};        // row16 path on dense records: task rows of each step of a train (osc_task_rows_dense_kernel)
     int fused = 0;
     int fused_train = R16_TRAIN;
+    // the OSC step of the fused path in lane-per-robot form (osc_lane.hpp): the instantiation that holds the layout (-1: none: the row16
+    // FROMQ kernel stays), its row map, the records + counters of the eigen pass behind it (allocated by the first fused step)
+    int lane_tier = -1;
+    lane::RowMap lane_map{};
+    double* lane_rec[R16_TRAIN] = {};
+    int32_t* dlane_count = nullptr;        // [R16_TRAIN]
     std::vector<double*> dqpos, dqvel;
     std::vector<double*> dqt;          // per slot: the same coordinates in the fused walk's layout [wave][2 n][64 robots] (irlosc_upload_q writes both)
     std::vector<int> has_q;
@@ -200,6 +207,8 @@ static void free_all(irlosc_ctx* c) {
     if (c->dtables) (void)hipFree(c->dtables);
     for (int k = 0; k < R16_TRAIN; ++k) if (c->fe_xside[k]) (void)hipFree(c->fe_xside[k]);
     for (int k = 0; k < R16_TRAIN; ++k) if (c->dtrows[k]) (void)hipFree(c->dtrows[k]);
+    for (int k = 0; k < R16_TRAIN; ++k) if (c->lane_rec[k]) (void)hipFree(c->lane_rec[k]);
+    if (c->dlane_count) (void)hipFree(c->dlane_count);
     for (double* p : c->dqpos) if (p) (void)hipFree(p);
     for (double* p : c->dqvel) if (p) (void)hipFree(p);
     for (double* p : c->dqt) if (p) (void)hipFree(p);
@@ -1249,6 +1258,17 @@ extern "C" int irlosc_set_model(irlosc_ctx* c, const irlosc_model* m) {
         HIPCHK(c, hipMemcpyAsync(c->dtables, &t, sizeof t, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));      // t lives on this stack frame
         // (the exchange buffers themselves are allocated by the first fused step: ensure_xside)
+        // The OSC step behind the walk: lane-per-robot form when an instantiation holds this layout (IRLOSC_LANE=0: the row16 FROMQ
+        // kernel, A/B measurements and tests); its records are laid out by the row map, so another layout starts from zeroed ones
+        const char* le = getenv("IRLOSC_LANE");
+        lane::RowMap map;
+        const int tier = (le && !strcmp(le, "0")) ? -1 : lane_plan(h, &map);
+        if (tier != c->lane_tier || (tier >= 0 && memcmp(&map, &c->lane_map, sizeof map)))
+            for (int k2 = 0; k2 < R16_TRAIN; ++k2) if (c->lane_rec[k2]) { HIPCHK(c, hipFree(c->lane_rec[k2])); c->lane_rec[k2] = nullptr; }
+        c->lane_tier = tier;
+        if (tier >= 0) c->lane_map = map;
+    } else {
+        c->lane_tier = -1;
     }
     HIPCHK(c, hipMemcpyAsync(c->dmodel, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1278,11 +1298,11 @@ extern "C" int irlosc_upload_q(irlosc_ctx* c, int32_t slot, int32_t B, const dou
     HIPCHK(c, hipMemcpyAsync(c->dqvel[slot], qvel, bytes, hipMemcpyHostToDevice, c->stream));
     // the fused walk reads its own layout of the same numbers ([wave][2 n][64 robots]: coalesced, hinge by hinge): one small kernel
     // behind the copies (10 us per 65 536 robots against 0.8 ms of PCIe for them)
-    if (c->fused) {      // (only the fused path reads this layout; its buffer is allocated by the slot's first upload)
-        if (!c->dqt[slot])
-            HIPCHK(c, hipMalloc((void**)&c->dqt[slot], (((size_t)c->cfg.max_batch + 63) / 64) * 2 * c->cfg.n * 64 * sizeof(double)));
-        HIPCHK(c, (hipError_t)launch_q_layout(c->dqpos[slot], c->dqvel[slot], c->dqt[slot], B, c->cfg.n, c->stream));
-    }
+    // (only the fused path reads this layout; its buffer is allocated by the slot's first upload while the path is on -- and, once it
+    //  exists, refreshed by EVERY upload: a copy left stale while another model had the path switched off would be walked later)
+    if (c->fused && !c->dqt[slot])
+        HIPCHK(c, hipMalloc((void**)&c->dqt[slot], (((size_t)c->cfg.max_batch + 63) / 64) * 2 * c->cfg.n * 64 * sizeof(double)));
+    if (c->dqt[slot]) HIPCHK(c, (hipError_t)launch_q_layout(c->dqpos[slot], c->dqvel[slot], c->dqt[slot], B, c->cfg.n, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->has_q[slot] = B;
     return IRLOSC_OK;
@@ -1372,6 +1392,20 @@ static int ensure_xside(irlosc_ctx* c, int n) {
             return 1;
         }
     }
+    // lane form of the OSC step: one record per robot and step for the eigen pass (all of a batch may be flagged), zeroed once -- the
+    // kernels never write the structural zeros of a record.  Out of memory here only switches the lane form off.
+    if (c->lane_tier >= 0) {
+        if (!c->dlane_count && hipMalloc((void**)&c->dlane_count, R16_TRAIN * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); c->lane_tier = -1; }
+        for (int k2 = 0; c->lane_tier >= 0 && k2 < n && k2 < R16_TRAIN; ++k2) {
+            if (c->lane_rec[k2]) continue;
+            const size_t bytes = (size_t)c->cfg.max_batch * lane::REC_DOUBLES * sizeof(double);
+            if (hipMalloc((void**)&c->lane_rec[k2], bytes) != hipSuccess || hipMemsetAsync(c->lane_rec[k2], 0, bytes, c->stream) != hipSuccess) {
+                (void)hipGetLastError();
+                for (int k3 = 0; k3 < R16_TRAIN; ++k3) if (c->lane_rec[k3]) { (void)hipFree(c->lane_rec[k3]); c->lane_rec[k3] = nullptr; }
+                c->lane_tier = -1;
+            }
+        }
+    }
     return 0;
 }
 
@@ -1409,10 +1443,30 @@ static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, hipStream_
         ga.list[i] = c->dr16_list[i];
         ga.count[i] = c->dr16_count + i;
     }
+    // lane form of the OSC step: not with target velocities (branch B of osc.py:173-177 reads dx between the two halves of the task
+    // signal: the row16 FROMQ kernel keeps those trains)
+    bool use_lane = c->lane_tier >= 0;
+    lane::LaneTrain lt;
+    memset(&lt, 0, sizeof lt);
+    for (int i = 0; i < n && use_lane; ++i) {
+        if (c->has_tvel[slots[i]] || !c->lane_rec[i]) use_lane = false;
+        lt.qt[i] = c->dqt[slots[i]];
+        lt.rec[i] = c->lane_rec[i];
+        lt.rec_count[i] = c->dlane_count + i;
+    }
+    if (use_lane) {
+        lt.map = c->lane_map;
+        HIPCHK(c, hipMemsetAsync(c->dlane_count, 0, R16_TRAIN * sizeof(int32_t), st));
+    }
     if (c->tev_begin) HIPCHK(c, hipEventRecord(c->tev_begin, st));
     HIPCHK(c, (hipError_t)(c->fe_lane_s ? launch_frontend_lane_compact_dual_ur5_s(c->dmodel, ft, n, st)
                                         : launch_frontend_lane_compact_dual_ur5(c->dmodel, ft, n, st)));
-    HIPCHK(c, (hipError_t)launch_row16_fromq<T>(tr, n, st));
+    if (use_lane) {
+        HIPCHK(c, (hipError_t)launch_row16_fromq<T>(tr, n, st, 1));                 // the task pass
+        HIPCHK(c, (hipError_t)launch_lane_osc<T>(tr, lt, n, c->lane_tier, 1024, st));
+    } else {
+        HIPCHK(c, (hipError_t)launch_row16_fromq<T>(tr, n, st));
+    }
     HIPCHK(c, (hipError_t)launch_frontend_generic_lists<T>(c->dmodel, ga, n, c->fe_smem, st));
     HIPCHK(c, (hipError_t)launch_row16_worklist<T>(tr, n, nullptr, st));
     if (c->tev_end) HIPCHK(c, hipEventRecord(c->tev_end, st));
@@ -1447,7 +1501,13 @@ static int fused_resident(irlosc_ctx* c, int first_slot, int B, int iters) {
 extern "C" const char* irlosc_from_q_name(const irlosc_ctx* c) {
     static thread_local std::string nm;
     if (!c || !c->dmodel) return "";
-    if (c->fused) nm = std::string(c->fe_lane_s ? "osc_frontend_lane_compact_dual_ur5_s + " : "osc_frontend_lane_compact_dual_ur5 + ") + c->kernel_name + "_fromq (fused: compact exchange buffer, no dense M / J)";
+    if (c->fused && c->lane_tier >= 0) {
+        char sh[64];
+        snprintf(sh, sizeof sh, "osc_lane_%s_rows_%d_%d_%d + eigen pass", c->cfg.dtype == IRLOSC_F64 ? "f64" : "f32in_f64", lane::TIER_ROWS[c->lane_tier][0],
+                 lane::TIER_ROWS[c->lane_tier][1], lane::TIER_ROWS[c->lane_tier][2]);
+        nm = std::string(c->fe_lane_s ? "osc_frontend_lane_compact_dual_ur5_s + " : "osc_frontend_lane_compact_dual_ur5 + ") + sh +
+             " (fused: compact exchange buffer, no dense M / J; OSC step one lane per robot; target velocities: " + c->kernel_name + "_fromq)";
+    } else if (c->fused) nm = std::string(c->fe_lane_s ? "osc_frontend_lane_compact_dual_ur5_s + " : "osc_frontend_lane_compact_dual_ur5 + ") + c->kernel_name + "_fromq (fused: compact exchange buffer, no dense M / J)";
     else nm = std::string(irlosc_frontend_name(c)) + " + " + c->kernel_name + " (through dense records)";
     return nm.c_str();
 }

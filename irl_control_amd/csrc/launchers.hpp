@@ -21,21 +21,32 @@ template <typename TIN> struct Row16Train;
 template <typename TIN>
 int launch_row16(const Row16Train<TIN>& tr, int nsteps, bool tree, hipStream_t st);      // tree: tree-structured factorisation
 void row16_tree_masks(uint32_t mrow[32], uint32_t* jcols);      // zero pattern the tree form relies on (osc_row16.hpp)
+// parts: bit 0 = the task pass (part 1 of the task signal as rows of the exchange buffer), bit 1 = the row16 FROMQ kernel
 template <typename TIN>
-int launch_row16_fromq(const Row16Train<TIN>& tr, int nsteps, hipStream_t st);
+int launch_row16_fromq(const Row16Train<TIN>& tr, int nsteps, hipStream_t st, int parts = 3);
 template <typename TIN>
 int launch_row16_worklist(const Row16Train<TIN>& tr, int nsteps, int32_t* reset, hipStream_t st);
 // tu_row16_pad_{dense,tree,fromq}_{f64,f32}.hip -- the KMAX-padded variants launch_row16 / launch_row16_fromq fall through to for the
 // layouts without an instantiation of their own (explicit specialisations, one translation unit each)
 template <typename TIN> int launch_row16_pad_dense(const Row16Train<TIN>& tr, int nsteps, hipStream_t st);
 template <typename TIN> int launch_row16_pad_tree(const Row16Train<TIN>& tr, int nsteps, hipStream_t st);
-template <typename TIN> int launch_row16_pad_fromq(const Row16Train<TIN>& tr, int nsteps, hipStream_t st);
+template <typename TIN> int launch_row16_pad_fromq(const Row16Train<TIN>& tr, int nsteps, hipStream_t st, int parts);
 template <> int launch_row16_pad_dense<double>(const Row16Train<double>&, int, hipStream_t);
 template <> int launch_row16_pad_dense<float>(const Row16Train<float>&, int, hipStream_t);
 template <> int launch_row16_pad_tree<double>(const Row16Train<double>&, int, hipStream_t);
 template <> int launch_row16_pad_tree<float>(const Row16Train<float>&, int, hipStream_t);
-template <> int launch_row16_pad_fromq<double>(const Row16Train<double>&, int, hipStream_t);
-template <> int launch_row16_pad_fromq<float>(const Row16Train<float>&, int, hipStream_t);
+template <> int launch_row16_pad_fromq<double>(const Row16Train<double>&, int, hipStream_t, int);
+template <> int launch_row16_pad_fromq<float>(const Row16Train<float>&, int, hipStream_t, int);
+
+// tu_lane_f64.hip / tu_lane_f32.hip -- the OSC step of the fused path in lane-per-robot form + its eigen pass (osc_lane.hpp).
+// tier: 0 = rows per end-effector body (stand, right, left) up to (1, 6, 6), 1 = up to (1, 3, 3)
+namespace lane { struct LaneTrain; struct RowMap; }
+struct FeModel;
+int lane_plan(const FeModel& h, lane::RowMap* map);      // -> tier, or -1: no instantiation for this layout
+template <typename TIN>
+int launch_lane_osc(const Row16Train<TIN>& tr, const lane::LaneTrain& lt, int nsteps, int tier, int eig_blocks, hipStream_t st);
+template <> int launch_lane_osc<double>(const Row16Train<double>&, const lane::LaneTrain&, int, int, int, hipStream_t);
+template <> int launch_lane_osc<float>(const Row16Train<float>&, const lane::LaneTrain&, int, int, int, hipStream_t);
 
 // tu_frontend.hip / tu_frontend_lane.hip -- rigid-body front end (osc_frontend.hpp, osc_frontend_lane.hpp); TOUT = record type
 struct FeModel;

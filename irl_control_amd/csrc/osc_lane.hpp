@@ -1,0 +1,577 @@
+// The OSC step of the fused path in LANE-PER-ROBOT form (round 6): one lane = one robot, 64 robots per wavefront, the tree and the
+// task-row structure compiled in.  It replaces the row16 FROMQ kernel behind the lane-per-robot walk (osc_frontend_lane.hpp) for the
+// layouts it has an instantiation for; every other layout keeps the FROMQ kernel.
+//
+// Why.  The row16 form gives a robot 16 lanes and runs a 25-row / 13-row problem on them at ~25 % lane efficiency: 2 300 VALU
+// instructions per wave of FOUR robots = 36 800 per 64 robots, three times the issue slots of the whole rigid-body walk
+// (profiles/NOTES.md, round 5).  The exchange buffer the walk leaves is already laid out [entry][64 robots] --
+// the native layout for one lane per robot: every operand is one coalesced 512-byte load, every matrix entry is a register with a
+// compile-time index, and the sparsity of the tree AND of the task rows can be used entry by entry:
+//
+//   M = L^T L from the leaves up (hinges NJ-1 .. 0, no fill-in: osc_row16.hpp, TOPO) in right-looking "accumulated update" form:
+//       row j of M is read when hinge j is eliminated, m_ji - Delta[j][i], Delta[a][b] += L[c][a] L[c][b] for the hinges c below
+//       both -- a Delta is live from the first hinge under both until its own row is eliminated: <= 36 of the 180 at any time
+//   Y = L^-T J^T rides along the same way (DJ): row r of J only has entries at the hinges that move ITS end effector
+//       (device.py:125-133), so an arm's six rows see seven hinges, not twenty-five
+//   A = Y^T Y = blockdiag(arm blocks) + y0 y0^T: rows of different end effectors only meet at their common hinges (the stand)
+//   k x k: L~ D L~^T, trace(A^-1) by columns of L~^-1, the certificate and the plain solve of osc_row16.hpp (osc.py:51-55) --
+//       ~1 500 lane-instructions where the row16 form spends ~700 per FOUR robots
+//   u = u0 + bias - kvn M dq - J^T t (osc.py:148-200), transposed through LDS and stored row-major, coalesced.
+//
+// The task rows are kept in a CANONICAL order (grouped by end-effector body, padded to the instantiation's rows per body), not in
+// targets order: A, w and t are permuted consistently (t = Mx w does not depend on the order of the rows), J^T t is a sum over
+// rows.  Padded rows and rows no joint can move (A[r][r] == 0 exactly) are taken out of the factorisation like the KMAX-padded
+// row16 kernels do (pivot 1, not part of det / trace; PINV and TRUNCATED set for an exact zero row as the reference's det = 0 /
+// pinv imply).
+//
+// Robots whose solve is not certifiably the reference's inverse branch (15 % of physical states) are NOT finished here: the lane
+// writes A, w and the Jacobian columns into a compact record (slot from one atomic per wave) and osc_lane_eigen_kernel -- four
+// records per wave in the row16 layout, eigen16 unchanged -- computes t = pinv(A) w (osc.py:55) and subtracts J^T t from the
+// torques this kernel left without the task term.  What that stage gives up on goes to the generic kernel as before.
+#pragma once
+#include "osc_generic.hpp"
+#include "osc_row16.hpp"
+#include "osc_lane_types.hpp"
+
+namespace irlosc {
+namespace lane {
+
+// Rows per end-effector candidate of the tree (bodies with TOPO::ee_cand, in body order) an instantiation holds
+template <int... R>
+struct Shape {
+    static constexpr int NC = sizeof...(R);
+    static constexpr int rows[NC] = {R...};
+    static constexpr int K = (R + ...);
+};
+
+template <class TOPO, class SH>
+struct LT {
+    using TI = FeTopo<TOPO>;
+    static constexpr int NJ = TOPO::NJ;
+    static constexpr int K = SH::K;
+    static constexpr int n_cand() { int n = 0; for (int b = 0; b < TOPO::NB; ++b) n += TOPO::ee_cand[b] ? 1 : 0; return n; }
+    static constexpr int cand_body(int c) {
+        int n = 0;
+        for (int b = 0; b < TOPO::NB; ++b) if (TOPO::ee_cand[b]) { if (n == c) return b; ++n; }
+        return -1;
+    }
+    static constexpr int row_cand(int r) { int c = 0; while (r >= SH::rows[c]) { r -= SH::rows[c]; ++c; } return c; }
+    static constexpr int row_body(int r) { return cand_body(row_cand(r)); }
+    static constexpr bool row_moved(int r, int j) { return TI::moves(j, row_body(r)); }                 // J[r][j] may be non-zero
+    static constexpr bool hinge_ee(int j) { for (int r = 0; r < K; ++r) if (row_moved(r, j)) return true; return false; }
+    static constexpr int ee_rank(int j) { int n = 0; for (int i = 0; i < j; ++i) n += hinge_ee(i) ? 1 : 0; return n; }      // position among the EE hinges
+    static constexpr int n_ee() { return ee_rank(NJ); }
+    static constexpr int jentry0(int r, int j) { return TI::ee_index(row_body(r)) + 7 + 6 * TI::anc_rank(j, row_body(r)); }
+    static constexpr int subtree_last(int j) { int l = j; for (int c = j; c < NJ; ++c) if (TI::above(j, c)) l = c; return l; }
+    static constexpr bool has_below(int j) { return subtree_last(j) > j; }
+    // the deepest hinge (largest index = first in the descending recursion) that moves row r's body, resp. both bodies
+    static constexpr int deepest(int r) { int d = -1; for (int j = 0; j < NJ; ++j) if (row_moved(r, j)) d = j; return d; }
+    static constexpr int deepest2(int r, int s) { int d = -1; for (int j = 0; j < NJ; ++j) if (row_moved(r, j) && row_moved(s, j)) d = j; return d; }
+    // is there an EE hinge strictly below j that moves row r's body?  (then DJ[r][j] has been written when hinge j is reached)
+    static constexpr bool dj_written(int r, int j) { for (int c = j + 1; c < NJ; ++c) if (TI::above(j, c) && row_moved(r, c)) return true; return false; }
+    static constexpr int m_entry(int i, int j) { return i == j ? TI::diag_index(j) : TI::pair_index(i, j); }      // i at or above j
+    static constexpr int tri(int r, int s) { return r * (r + 1) / 2 + s; }                                         // s <= r
+};
+
+using r16::static_for;
+using r16::static_for_down;
+
+// Anchor a value where it is computed.  The recursion below is pure arithmetic between loads; the instruction selector orders pure
+// nodes by their USES, and every use sits behind the recursion (the k x k stage) -- left alone, all 330 loads and the M dq sums come
+// first and the factorisation afterwards, with everything live in between (1 kB of scratch).  An empty volatile asm is ordered like a
+// side effect: what it touches is computed before the next pin of the schedule.
+__device__ __forceinline__ void pin(double& v) { asm volatile("" : "+v"(v)); }
+using r16::rsq_refined;
+using r16::rcp_refined;
+
+template <class TOPO, class SH, typename TIN>
+__global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> tr, const LaneTrain lt) {
+    using L = LT<TOPO, SH>;
+    using TI = FeTopo<TOPO>;
+    constexpr int NJ = L::NJ, K = L::K;
+    static_assert(SH::NC == L::n_cand(), "one row count per end-effector candidate of the tree");
+    static_assert(K >= 1 && K <= IRLOSC_MAX_K && L::n_ee() <= 16, "shape");
+    static_assert(TI::depth_first(), "hinges numbered depth first: a subtree is a run of indices");
+    constexpr int BLK_E = TI::n_compact();
+    constexpr int ZERO_E = TI::zero_index();
+    constexpr int TASK_E = TI::task_index(0);
+    constexpr int NE = TI::n_pairs() + NJ;
+    const KParams<TIN>& p = tr.p[blockIdx.y];
+    const Row16Extra& x = tr.x[blockIdx.y];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x * 64 + lane;
+    const bool live = b < p.B;
+    const int bc = live ? b : p.B - 1;
+    const double* __restrict__ col = x.side + (size_t)blockIdx.x * BLK_E * 64 + lane;
+    const double* __restrict__ gq = lt.qt[blockIdx.y] + (size_t)blockIdx.x * (2 * NJ * 64) + lane;
+    const uint32_t realm = lt.map.real;
+    __shared__ double s_u[NJ * 65];                    // M dq as the hinges complete, then the torques: [hinge][64 robots + 1 pad]
+    const unsigned long long rt0 = x.span ? __builtin_amdgcn_s_memrealtime() : 0ull;      // irlosc_time_trains (see Row16Extra::span)
+    const unsigned long long cyc0 = x.span ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
+
+    // The row map as scalars, read ONCE (left where they are used they become scalar loads + branches inside the recursion, which
+    // cut it into basic blocks the scheduling pins cannot hold together): rm[r] = 1 for a task row, 0 for padding; a padding row reads
+    // the entry of zeros -- entry = ZERO + rm (e0 - ZERO) + rm comp, no branch.
+    int rm[K], rmc[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        rm[r] = (int)((realm >> r) & 1u);
+        rmc[r] = rm[r] * lt.map.comp[r];
+    }
+    auto jload = [&](auto rc, auto jc) -> double {
+        constexpr int r = decltype(rc)::value, j = decltype(jc)::value;
+        constexpr int de = L::jentry0(r, j) - ZERO_E;
+        const int e = ZERO_E + rm[r] * de + rmc[r];
+        return col[(size_t)(unsigned)e * 64];
+    };
+
+    // ---- joint velocities: all of them up front (25 coalesced loads) ------------------------------------------------------------
+    double dq[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) dq[j] = gq[(2 * j + 1) * 64];
+
+    double Mv[NE];                  // entries of M as they arrive (prefetched PFD hinges ahead)
+    double Jv[K][NJ];               // entries of J likewise
+    double Dl[NE];                  // accumulated updates, keyed like the entries of M
+    double DJ[K][NJ];
+    double Al[K * (K + 1) / 2];     // lower triangle of A = Y^T Y
+    double macc[NJ];                // M dq: partial sums of the hinges whose row has not been read yet
+    double dx[K];
+    double lrow[NJ];
+    double yv[K];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) macc[j] = 0.0;
+#pragma unroll
+    for (int r = 0; r < K; ++r) dx[r] = 0.0;
+#pragma unroll
+    for (int e = 0; e < K * (K + 1) / 2; ++e) Al[e] = 0.0;      // (rows of different candidates without a common hinge stay zero)
+    bool npd = false;
+
+    auto fetch = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        static_for<0, j + 1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (TI::above(i, j)) { constexpr int e = L::m_entry(i, j); Mv[e] = col[(size_t)e * 64]; }
+        });
+        if constexpr (L::hinge_ee(j)) {
+            static_for<0, K>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                if constexpr (L::row_moved(r, j)) Jv[r][j] = jload(rc, jc);
+            });
+        }
+    };
+    constexpr int PFD = 2;          // hinges requested ahead of the one being eliminated
+    static_for<0, PFD>([&](auto dc) { constexpr int j = NJ - 1 - decltype(dc)::value; if constexpr (j >= 0) fetch(std::integral_constant<int, j>{}); });
+
+    // ---- the recursion, hinges NJ - 1 .. 0 --------------------------------------------------------------------------------------
+    static_for_down<0, NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j - PFD >= 0) fetch(std::integral_constant<int, (j - PFD >= 0 ? j - PFD : 0)>{});
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int ed = L::m_entry(j, j);
+        constexpr bool below = L::has_below(j);
+        double d = Mv[ed];
+        double mj = fma(d, dq[j], macc[j]);
+        if constexpr (below) d -= Dl[ed];
+        static_for<0, j>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (TI::above(i, j)) {
+                constexpr int e = L::m_entry(i, j);
+                const double m = Mv[e];
+                mj = fma(m, dq[i], mj);
+                macc[i] = fma(m, dq[j], macc[i]);
+                lrow[i] = below ? m - Dl[e] : m;
+            }
+        });
+        s_u[j * 65 + lane] = mj;                               // (M dq)_j is complete: every row under j and row j itself have been read
+        npd = npd | !(d > 0.0);                                // also catches NaN
+        d = fmax(d, 1e-300);
+        const double rs = rsq_refined(d);
+        static_for<0, j>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (TI::above(i, j)) lrow[i] *= rs;      // L[j][i]
+        });
+        static_for<0, j>([&](auto ac) {
+            constexpr int a = decltype(ac)::value;
+            if constexpr (TI::above(a, j)) {
+                static_for<0, a + 1>([&](auto bc2) {
+                    constexpr int b2 = decltype(bc2)::value;
+                    if constexpr (TI::above(b2, j)) {
+                        constexpr int e = L::m_entry(b2, a);
+                        // the first hinge (in this order) under both: the last index of the deeper one's subtree
+                        if constexpr (L::subtree_last(a) == j) Dl[e] = lrow[a] * lrow[b2];
+                        else Dl[e] = fma(lrow[a], lrow[b2], Dl[e]);
+                        pin(Dl[e]);
+                    }
+                });
+            }
+        });
+        if constexpr (L::hinge_ee(j)) {
+            static_for<0, K>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                if constexpr (L::row_moved(r, j)) {
+                    const double jv = Jv[r][j];
+                    dx[r] = fma(jv, dq[j], dx[r]);
+                    pin(dx[r]);
+                    double t = jv;
+                    if constexpr (L::dj_written(r, j)) t -= DJ[r][j];
+                    const double y = t * rs;                   // Y[j][r]
+                    yv[r] = y;
+                    static_for<0, j>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        if constexpr (TI::above(i, j)) {
+                            if constexpr (L::deepest(r) == j) DJ[r][i] = lrow[i] * y;
+                            else DJ[r][i] = fma(lrow[i], y, DJ[r][i]);
+                            pin(DJ[r][i]);
+                        }
+                    });
+                }
+            });
+            static_for<0, K>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                if constexpr (L::row_moved(r, j)) {
+                    static_for<0, r + 1>([&](auto sc) {
+                        constexpr int s = decltype(sc)::value;
+                        if constexpr (L::row_moved(s, j)) {
+                            constexpr int e = L::tri(r, s);
+                            if constexpr (L::deepest2(r, s) == j) Al[e] = yv[r] * yv[s];
+                            else Al[e] = fma(yv[r], yv[s], Al[e]);
+                            pin(Al[e]);
+                        }
+                    });
+                }
+            });
+        }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+
+    uint32_t flags = npd ? IRLOSC_FLAG_M_NOT_PD : 0u;
+    // ---- w = u_task_all [+ ext_f] - kvn dx (osc.py:184-185, null-space term folded in: osc_generic.hpp header) ------------------
+    // (No branch between the recursion and the k x k stage: with one in between, the compiler SINKS the whole factorisation -- every value
+    //  that is only used behind the branch -- out of the pinned regions above, and all 330 loads stay live at once.  Hence loads through
+    //  selected addresses instead of `if (flag) load`.)
+    const bool has_wr = (p.cfgflags & IRLOSC_ADMITTANCE) && p.wrench != nullptr;
+    const int nd = p.ndev;
+    const TIN* __restrict__ zeros = reinterpret_cast<const TIN*>(x.zeros);
+    const double kvn = (p.cfgflags & IRLOSC_NULLSPACE) ? (double)p.null_kv[p.gains_per_instance ? bc : 0] * 1.0 : 0.0;
+    double wr[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) {      // (padding: device 0, component 0 -- a valid address, times zero)
+        const TIN* wp = has_wr ? p.wrench + ((size_t)bc * nd + lt.map.dev[r]) * 6 + lt.map.comp[r] : zeros;
+        wr[r] = (double)rm[r] * (double)*wp;
+    }
+    double w[K];
+    bool nr[K];                     // row r is padding, or a task row no joint can move (A[r][r] == 0 exactly: row r of J is zero)
+    bool anyzero = false;
+    static_for<0, K>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        const bool real = rm[r] != 0;
+        const int e = ZERO_E + rm[r] * (TASK_E - ZERO_E + lt.map.ext[r]);
+        double v = col[(size_t)(unsigned)e * 64];
+        v += wr[r];
+        const bool zr = real && Al[L::tri(r, r)] == 0.0;
+        anyzero = anyzero | zr;
+        nr[r] = !real | zr;
+        w[r] = nr[r] ? 0.0 : v - kvn * dx[r];
+    });
+    // ---- k x k: L~ D L~^T in place (Lf), the certificate, the plain solve (osc.py:51-55; osc_row16.hpp) --------------------------
+    double nA2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+#pragma unroll
+        for (int s = 0; s <= r; ++s) { const double a = Al[r * (r + 1) / 2 + s]; nA2 = fma(a, r == s ? a : 2.0 * a, nA2); }
+    }
+    // In place: A itself is not kept (a copy of its 91 entries next to the factor's is 360 registers, and the arithmetic only reaches
+    // the 256 architectural ones).  The robots that need A again -- the eigen pass's -- get it back as L~ D' L~^T - diag(d' - d) below:
+    // a pivot replaced by 1 is a change of that diagonal entry of A and of nothing else.
+    double (&Lf)[K * (K + 1) / 2] = Al;
+    double invd[K], dtrue[K];
+    bool pd = true;
+    double det = 1.0;
+    static_for<0, K>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        double d = Lf[L::tri(j, j)];
+        dtrue[j] = d;
+        const bool bad = !nr[j] & !(d > 0.0);
+        pd = pd & !bad;
+        d = (bad | nr[j]) ? 1.0 : d;
+        det *= d;
+        const double iv = rcp_refined(d);
+        invd[j] = iv;
+        double f[K];
+        static_for<j + 1, K>([&](auto ic) { constexpr int i = decltype(ic)::value; f[i] = Lf[L::tri(i, j)] * iv; });
+        static_for<j + 1, K>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            static_for<j + 1, i + 1>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                Lf[L::tri(i, c)] = fma(-f[i], Lf[L::tri(c, j)], Lf[L::tri(i, c)]);
+            });
+        });
+        static_for<j + 1, K>([&](auto ic) { constexpr int i = decltype(ic)::value; Lf[L::tri(i, j)] = f[i]; });
+    });
+    // trace(A^-1) = sum over the columns m of W = L~^-1 of sum_c W[c][m]^2 / d_c (real rows only)
+    double trA = 0.0;
+    static_for<0, K>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        double xw[K];
+        xw[m] = 1.0;
+        double acc = nr[m] ? 0.0 : invd[m];
+        static_for<m + 1, K>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            double s = -Lf[L::tri(c, m)];
+            static_for<m + 1, c>([&](auto qc) { constexpr int q2 = decltype(qc)::value; s = fma(-Lf[L::tri(c, q2)], xw[q2], s); });
+            xw[c] = s;
+            acc = fma(s * s, nr[c] ? 0.0 : invd[c], acc);
+        });
+        trA += acc;
+    });
+    const bool small_det = !pd | !(fabs(det) >= 1e-4) | anyzero;
+    const double cond_bound = sqrt(nA2) * trA;
+    const bool plain = pd & t_finite(cond_bound) & (!small_det | (cond_bound < 0.99e5));
+    flags |= small_det ? IRLOSC_FLAG_PINV_BRANCH : 0u;
+    flags |= plain ? 0u : IRLOSC_FLAG_EIGEN_PATH;
+    flags |= anyzero ? IRLOSC_FLAG_TRUNCATED : 0u;
+    double t[K];
+    static_for<0, K>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        double s = w[c];
+        static_for<0, c>([&](auto qc) { constexpr int q2 = decltype(qc)::value; s = fma(-Lf[L::tri(c, q2)], t[q2], s); });
+        t[c] = s;
+    });
+    static_for<0, K>([&](auto cc) { constexpr int c = decltype(cc)::value; t[c] *= invd[c]; });
+    static_for_down<0, K>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        double s = t[c];
+        static_for<c + 1, K>([&](auto ic) { constexpr int i = decltype(ic)::value; s = fma(-Lf[L::tri(i, c)], t[i], s); });
+        t[c] = s;
+    });
+    static_for<0, K>([&](auto cc) { constexpr int c = decltype(cc)::value; t[c] = plain ? t[c] : 0.0; });      // the eigen pass adds its own J^T t
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- the robots the certificate does not clear: records for the eigen pass (slot: one atomic per wave) ----------------------------
+    const bool hand = !plain && live;
+    const unsigned long long hm = __ballot(hand);
+    double* __restrict__ rec = nullptr;
+    if (hm != 0ull) {
+        const int first = (int)__builtin_ctzll(hm);
+        int base = 0;
+        if (lane == first) base = atomicAdd(lt.rec_count[blockIdx.y], (int)__builtin_popcountll(hm));
+        base = __builtin_amdgcn_readlane(base, first);
+        if (hand) {
+            const int slot = base + (int)__builtin_popcountll(hm & ((1ull << lane) - 1ull));
+            rec = lt.rec[blockIdx.y] + (size_t)slot * REC_DOUBLES;
+            uint32_t nrm = 0u;
+            // A = L~ D' L~^T - diag(d' - d), column by column: Ld[r] = L~[r][j] d'_j is column j of the matrix as the factorisation met it
+            double Ar[K * (K + 1) / 2];
+            static_for<0, K>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const double dj = (dtrue[j] > 0.0 && !nr[j]) ? dtrue[j] : 1.0;      // d'_j
+                double Ld[K];
+                static_for<j + 1, K>([&](auto rc) { constexpr int r = decltype(rc)::value; Ld[r] = Lf[L::tri(r, j)] * dj; });
+                // entry (j, j): everything the earlier columns contributed has been added already; the true pivot closes it
+                if constexpr (j == 0) Ar[L::tri(j, j)] = dtrue[j];
+                else Ar[L::tri(j, j)] += dtrue[j];
+                static_for<j + 1, K>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    if constexpr (j == 0) Ar[L::tri(r, j)] = Ld[r];
+                    else Ar[L::tri(r, j)] += Ld[r];
+                    static_for<j + 1, r + 1>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        if constexpr (j == 0) Ar[L::tri(r, c)] = Ld[r] * Lf[L::tri(c, j)];
+                        else Ar[L::tri(r, c)] = fma(Ld[r], Lf[L::tri(c, j)], Ar[L::tri(r, c)]);
+                    });
+                });
+            });
+            static_for<0, K>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                nrm |= nr[r] ? (1u << r) : 0u;
+                static_for<0, K>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    rec[REC_A + r * 16 + c] = Ar[r >= c ? L::tri(r, c) : L::tri(c, r)];
+                });
+                rec[REC_W + r] = w[r];
+            });
+            reinterpret_cast<long long*>(rec)[REC_META] = (long long)b;
+            reinterpret_cast<long long*>(rec)[REC_META + 1] = (long long)nrm;
+            // the Jacobian entries, columns = the EE hinges in their order (the structural zeros of the block are never written: the
+            // buffer is zeroed when it is allocated)
+            static_for<0, NJ>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (L::hinge_ee(j)) {
+                    constexpr int cr = L::ee_rank(j);
+                    static_for<0, K>([&](auto rc) {
+                        constexpr int r = decltype(rc)::value;
+                        if constexpr (L::row_moved(r, j)) rec[REC_J + r * 16 + cr] = jload(rc, jc);
+                    });
+                }
+            });
+        }
+    }
+
+    // ---- J^T t, hinge by hinge (the Jacobian entries once more: cached lines) ---------------------------------------------------------
+    double jt[NJ];
+    static_for<0, NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (L::hinge_ee(j)) {
+            double s = 0.0;
+            static_for<0, K>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                if constexpr (L::row_moved(r, j)) s = fma(jload(rc, jc), t[r], s);
+            });
+            jt[j] = s;
+        }
+    });
+    // ---- torques (osc.py:174,184-200): u = u0 + bias - kvn M dq - J^T t, through the LDS tile ------------------------------------
+    const bool use_g = (p.cfgflags & IRLOSC_USE_G) != 0;
+    bool bad = false;
+    double kvd[IRLOSC_MAX_DEV];
+    uint32_t jm[IRLOSC_MAX_DEV];
+#pragma unroll
+    for (int d2 = 0; d2 < IRLOSC_MAX_DEV; ++d2) {
+        const int dd = d2 < nd ? d2 : 0;
+        kvd[d2] = (double)p.gains[(p.gains_per_instance ? (size_t)bc * nd * IRLOSC_GAIN_WORDS : 0) + dd * IRLOSC_GAIN_WORDS + 1];
+        jm[d2] = d2 < nd ? p.dev[dd].joint_mask : 0u;
+    }
+    const TIN* __restrict__ zb = reinterpret_cast<const TIN*>(x.zeros);
+    (void)zb;
+    static_for<0, NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const double mdq = s_u[j * 65 + lane];
+        double u0 = 0.0;
+#pragma unroll
+        for (int d2 = 0; d2 < IRLOSC_MAX_DEV; ++d2) {      // branch A damping, assignment in device order (osc.py:174)
+            u0 = ((jm[d2] >> j) & 1u) ? -kvd[d2] * mdq : u0;
+        }
+        {   // (the entry of zeros when the bias forces are off: a selected address, no branch)
+            constexpr int eb = TI::bias_index(j);
+            u0 += col[(size_t)(use_g ? eb : ZERO_E) * 64];
+        }
+        u0 -= kvn * mdq;
+        if constexpr (L::hinge_ee(j)) u0 -= jt[j];
+        bad = bad || !t_finite(u0);
+        s_u[j * 65 + lane] = u0;
+    });
+    flags |= bad ? IRLOSC_FLAG_NONFINITE : 0u;
+    if (live) p.flags[b] = flags;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int nrob = min(64, p.B - (int)blockIdx.x * 64);
+        TIN* __restrict__ uo = p.u + (size_t)blockIdx.x * 64 * NJ;
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) {
+            const int idx = lane + 64 * i;
+            const int rob = idx / NJ, jn = idx - rob * NJ;
+            if (rob < nrob) uo[idx] = (TIN)s_u[jn * 65 + rob];
+        }
+    }
+    if (x.span && lane == 0) {       // first wave's start / last wave's end of the train, untraced (irlosc_time_trains)
+        unsigned long long* sp = x.span + 2 * (blockIdx.x & (R16_SPAN_SLOTS - 1));
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+        atomicMin(sp, rt0);
+        atomicMax(sp + 1, rt1);
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+            x.span[2 * R16_SPAN_SLOTS] = (unsigned long long)__builtin_readcyclecounter() - cyc0;
+            x.span[2 * R16_SPAN_SLOTS + 1] = rt1 - rt0;
+        }
+    }
+}
+
+
+// The eigen pass behind the lane kernel: the records of a step's flagged robots, FOUR per wave in the row16 layout (16 lanes per robot,
+// lane c = column c of A) -- the factorisation, the certificate's numbers and eigen16 exactly as the row16 kernel runs them in place
+// (osc_row16.hpp), then u -= J^T t on the torques the lane kernel left without the task term.  Persistent blocks, blockIdx.y = step.
+// Rows that are padding or exact zero rows arrive as a mask and are treated like the KMAX-padded kernels treat them (PAD = true).
+template <class TOPO, class SH, typename TIN>
+__global__ __launch_bounds__(64, 2) void osc_lane_eigen_kernel(const Row16Train<TIN> tr, const LaneTrain lt) {
+    using namespace r16;
+    using L = LT<TOPO, SH>;
+    constexpr int NJ = L::NJ, K = L::K;
+    const KParams<TIN>& p = tr.p[blockIdx.y];
+    const Row16Extra& x = tr.x[blockIdx.y];
+    const int n = __builtin_amdgcn_readfirstlane(min(*lt.rec_count[blockIdx.y], p.B));
+    const int lane = threadIdx.x, q = lane >> 4, l = lane & 15;
+    constexpr int NEE = L::n_ee();
+    for (int g = blockIdx.x; g * 4 < n; g += gridDim.x) {
+        const int ri = g * 4 + q;
+        const bool live = ri < n;
+        const double* __restrict__ rec = lt.rec[blockIdx.y] + (size_t)(live ? ri : n - 1) * REC_DOUBLES;
+        double Ac[K], A[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) Ac[r] = rec[REC_A + r * 16 + l];          // (columns >= K are never written: zeros since the allocation)
+        const double w = rec[REC_W + l];
+        const uint32_t zrow = (uint32_t)reinterpret_cast<const long long*>(rec)[REC_META + 1];
+        double nA2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < K; ++r) { nA2 = fma(Ac[r], Ac[r], nA2); A[r] = Ac[r]; }
+        nA2 = row_sum(nA2);
+        double F[K], G[K];
+        double invd_own = 0.0, detA = 1.0;
+        bool pdA = true;
+        ldl16<K, true>(A, l, 0.0, F, G, invd_own, pdA, detA, K, zrow);
+        double X[K];
+#pragma unroll
+        for (int m = 0; m < K; ++m) X[m] = (l == m) ? 1.0 : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, K - 1>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            static_for<0, j + 1>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                if constexpr (j < 3 || m == 0) fmac_bc_n_nop<j>(X[m], X[m], F[j]);
+                else fmac_bc_n<j>(X[m], X[m], F[j]);
+            });
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        double trA = 0.0;
+#pragma unroll
+        for (int m = 0; m < K; ++m) trA = fma(X[m], X[m], trA);
+        trA = (l < K && !((zrow >> l) & 1u)) ? trA : 0.0;
+        trA = row_sum(trA * invd_own);
+        double t = 0.0;
+        uint32_t f2 = 0;
+        bool giveup = false;
+        eigen16<K, true>(Ac, F, G, invd_own, pdA, nA2, trA, w, l, live, t, f2, giveup, K, zrow);
+        // (everything the tail needs is rebuilt from an opaque copy of the lane id: nothing rides through the eigen stage in registers)
+        int lane2 = threadIdx.x;
+        asm volatile("" : "+v"(lane2));
+        const int q2 = lane2 >> 4, l2 = lane2 & 15;
+        const int ri2 = g * 4 + q2;
+        const bool live2 = ri2 < n;
+        const double* __restrict__ rec2 = lt.rec[blockIdx.y] + (size_t)(live2 ? ri2 : n - 1) * REC_DOUBLES;
+        const long long bid = reinterpret_cast<const long long*>(rec2)[REC_META];
+        double jr[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) jr[r] = rec2[REC_J + r * 16 + l2];
+        int hinge = 0;
+        static_for<0, NJ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (L::hinge_ee(j)) { constexpr int cr = L::ee_rank(j); hinge = (l2 == cr) ? j : hinge; }
+        });
+        double jt = 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, K>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            if constexpr (r == 0) fmac_bc_nop<r>(jt, t, jr[r]);
+            else fmac_bc<r>(jt, t, jr[r]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        bool bad = false;
+        if (live2 && l2 < NEE) {
+            TIN* up = p.u + (size_t)bid * NJ + hinge;
+            const double u = (double)*up - jt;
+            bad = !t_finite(u);
+            *up = (TIN)u;
+        }
+        const unsigned long long bm = __ballot(bad);
+        if (live2 && l2 == 0) {
+            uint32_t fl = p.flags[bid] | f2;
+            if ((bm >> (q2 * 16)) & 0xffffull) fl |= IRLOSC_FLAG_NONFINITE;
+            p.flags[bid] = fl;
+            if (giveup) x.worklist[atomicAdd(x.workcount, 1)] = (int32_t)bid;
+        }
+    }
+}
+
+}  // namespace lane
+}  // namespace irlosc

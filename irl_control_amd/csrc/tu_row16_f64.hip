@@ -38,17 +38,19 @@ int launch_row16(const Row16Train<TIN>& tr, int nsteps, bool tree, hipStream_t s
 // factorisation in the tree-structured form of the compiled Dual-UR5 shape.  Blocks of FOUR waves (256 threads): block x takes
 // robots 16 (x % 4) .. of walk wave x / 4, i.e. one 128-byte line of every entry of that wave's exchange block.
 template <typename TIN>
-int launch_row16_fromq(const Row16Train<TIN>& tr, int nsteps, hipStream_t st) {
+int launch_row16_fromq(const Row16Train<TIN>& tr, int nsteps, hipStream_t st, int parts) {
     const KParams<TIN>& p = tr.p[0];
     if (p.B <= 0 || nsteps <= 0) return 0;
     const int waves = (p.B + 63) / 64;
     const dim3 grid(waves * 4, nsteps), tgrid(waves, nsteps);      // the task pass first: one lane per robot, block = walk wave
-    if (p.padded) return launch_row16_pad_fromq<TIN>(tr, nsteps, st);
-    if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<13, 3, TIN, TopoDualUr5>), tgrid, dim3(64 * 3), 0, st, tr);
+    if (p.padded) return launch_row16_pad_fromq<TIN>(tr, nsteps, st, parts);
+    if (!(parts & 1)) {}
+    else if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<13, 3, TIN, TopoDualUr5>), tgrid, dim3(64 * 3), 0, st, tr);
     else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<12, 2, TIN, TopoDualUr5>), tgrid, dim3(64 * 2), 0, st, tr);
     else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<7, 3, TIN, TopoDualUr5>), tgrid, dim3(64 * 3), 0, st, tr);
     else if (p.k == 6 && p.ndev == 2) hipLaunchKernelGGL((osc_task_rows_fromq_kernel<6, 2, TIN, TopoDualUr5>), tgrid, dim3(64 * 2), 0, st, tr);
     else return (int)hipErrorNotSupported;
+    if (!(parts & 2)) return (int)hipGetLastError();
     if (p.k == 13 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<13, 3, TIN, 25, true, TopoDualUr5>), grid, dim3(256), 0, st, tr);
     else if (p.k == 12 && p.ndev == 2) hipLaunchKernelGGL((osc_row16_kernel<12, 2, TIN, 25, true, TopoDualUr5>), grid, dim3(256), 0, st, tr);
     else if (p.k == 7 && p.ndev == 3) hipLaunchKernelGGL((osc_row16_kernel<7, 3, TIN, 25, true, TopoDualUr5>), grid, dim3(256), 0, st, tr);
@@ -68,7 +70,7 @@ int launch_row16_worklist(const Row16Train<TIN>& tr, int nsteps, int32_t* reset,
 }
 
 template int launch_row16<double>(const Row16Train<double>&, int, bool, hipStream_t);
-template int launch_row16_fromq<double>(const Row16Train<double>&, int, hipStream_t);
+template int launch_row16_fromq<double>(const Row16Train<double>&, int, hipStream_t, int);
 template int launch_row16_worklist<double>(const Row16Train<double>&, int, int32_t*, hipStream_t);
 
 void row16_tree_masks(uint32_t mrow[32], uint32_t* jcols) { r16::tree_structure_masks<TopoDualUr5>(mrow, jcols); }

@@ -40,11 +40,13 @@ int launch_row16_pad_tree<IRLOSC_PAD_TIN>(const Row16Train<IRLOSC_PAD_TIN>& tr, 
 #elif defined(IRLOSC_PAD_FROMQ)
 // the fused path: task pass (one lane per (robot, device); the block has 64 x ndev threads), then the OSC kernel on the tile
 template <>
-int launch_row16_pad_fromq<IRLOSC_PAD_TIN>(const Row16Train<IRLOSC_PAD_TIN>& tr, int nsteps, hipStream_t st) {
+int launch_row16_pad_fromq<IRLOSC_PAD_TIN>(const Row16Train<IRLOSC_PAD_TIN>& tr, int nsteps, hipStream_t st, int parts) {
     const KParams<IRLOSC_PAD_TIN>& p = tr.p[0];
     const int waves = (p.B + 63) / 64;
-    hipLaunchKernelGGL((osc_task_rows_fromq_kernel<16, IRLOSC_MAX_DEV, IRLOSC_PAD_TIN, TopoDualUr5, true>), dim3(waves, nsteps),
-                       dim3(64 * p.ndev), 0, st, tr);
+    if (parts & 1)
+        hipLaunchKernelGGL((osc_task_rows_fromq_kernel<16, IRLOSC_MAX_DEV, IRLOSC_PAD_TIN, TopoDualUr5, true>), dim3(waves, nsteps),
+                           dim3(64 * p.ndev), 0, st, tr);
+    if (!(parts & 2)) return (int)hipGetLastError();
     return pad_dispatch<IRLOSC_PAD_TIN, true, TopoDualUr5>(tr, dim3(waves * 4, nsteps), st);
 }
 #else
