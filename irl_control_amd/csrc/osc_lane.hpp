@@ -106,6 +106,7 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
     const double* __restrict__ gq = lt.qt[blockIdx.y] + (size_t)blockIdx.x * (2 * NJ * 64) + lane;
     const uint32_t realm = lt.map.real;
     __shared__ double s_u[NJ * 65];                    // M dq as the hinges complete, then the torques: [hinge][64 robots + 1 pad]
+    __shared__ double s_w[K * 64];                     // the task vector waits here across the recursion and the k x k stage
     const unsigned long long rt0 = x.span ? __builtin_amdgcn_s_memrealtime() : 0ull;      // irlosc_time_trains (see Row16Extra::span)
     const unsigned long long cyc0 = x.span ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
 
@@ -125,13 +126,31 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
         return col[(size_t)(unsigned)e * 64];
     };
 
-    // ---- joint velocities: all of them up front (25 coalesced loads) ------------------------------------------------------------
-    double dq[NJ];
+    // ---- what is uniform over the recursion, up front: gains, null-space gain, the task rows and the wrench (their latency hides
+    // behind the first rows of M) -----------------------------------------------------------------------------------------------------
+    // (No branch anywhere between here and the end of the k x k stage: with one in between, the compiler SINKS the whole factorisation --
+    //  every value that is only used behind the branch -- out of the pinned regions below, and all 330 loads stay live at once.  Hence
+    //  loads through selected addresses instead of `if (flag) load`.)
+    const bool has_wr = (p.cfgflags & IRLOSC_ADMITTANCE) && p.wrench != nullptr;
+    const bool use_g = (p.cfgflags & IRLOSC_USE_G) != 0;
+    const int nd = p.ndev;
+    const TIN* __restrict__ zeros = reinterpret_cast<const TIN*>(x.zeros);
+    const double kvn_in = (double)p.null_kv[p.gains_per_instance ? bc : 0];      // (always allocated; unused without the flag)
+    const double kvn = (p.cfgflags & IRLOSC_NULLSPACE) ? kvn_in : 0.0;
+    double kvd[IRLOSC_MAX_DEV];
+    uint32_t jm[IRLOSC_MAX_DEV];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) dq[j] = gq[(2 * j + 1) * 64];
-
+    for (int d2 = 0; d2 < IRLOSC_MAX_DEV; ++d2) {
+        const int dd = d2 < nd ? d2 : 0;
+        kvd[d2] = (double)p.gains[(p.gains_per_instance ? (size_t)bc * nd * IRLOSC_GAIN_WORDS : 0) + dd * IRLOSC_GAIN_WORDS + 1];
+        jm[d2] = d2 < nd ? p.dev[dd].joint_mask : 0u;
+    }
+    const TIN* __restrict__ wbase = has_wr ? p.wrench : zeros;
+    const size_t wsel = has_wr ? 1 : 0;
+    double dq[NJ];                  // joint velocities: requested with the first row that needs them
     double Mv[NE];                  // entries of M as they arrive (prefetched PFD hinges ahead)
     double Jv[K][NJ];               // entries of J likewise
+    double Bv[NJ];                  // bias forces
     double Dl[NE];                  // accumulated updates, keyed like the entries of M
     double DJ[K][NJ];
     double Al[K * (K + 1) / 2];     // lower triangle of A = Y^T Y
@@ -139,8 +158,6 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
     double dx[K];
     double lrow[NJ];
     double yv[K];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) macc[j] = 0.0;
 #pragma unroll
     for (int r = 0; r < K; ++r) dx[r] = 0.0;
 #pragma unroll
@@ -151,8 +168,16 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
         constexpr int j = decltype(jc)::value;
         static_for<0, j + 1>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            if constexpr (TI::above(i, j)) { constexpr int e = L::m_entry(i, j); Mv[e] = col[(size_t)e * 64]; }
+            if constexpr (TI::above(i, j)) {
+                constexpr int e = L::m_entry(i, j);
+                Mv[e] = col[(size_t)e * 64];
+                if constexpr (L::subtree_last(i) == j) dq[i] = gq[(2 * i + 1) * 64];      // row j is the first that multiplies with dq_i
+            }
         });
+        {   // (the entry of zeros when the bias forces are off: a selected address, no branch)
+            constexpr int eb = TI::bias_index(j);
+            Bv[j] = col[(size_t)(use_g ? eb : ZERO_E) * 64];
+        }
         if constexpr (L::hinge_ee(j)) {
             static_for<0, K>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
@@ -160,8 +185,28 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
             });
         }
     };
-    constexpr int PFD = 2;          // hinges requested ahead of the one being eliminated
-    static_for<0, PFD>([&](auto dc) { constexpr int j = NJ - 1 - decltype(dc)::value; if constexpr (j >= 0) fetch(std::integral_constant<int, j>{}); });
+    // Hinges requested ahead of the one being eliminated.  One wave per SIMD: nothing else covers the ~2 us of an HBM round trip, and
+    // a hinge is only ~150 instructions -- at a distance of 2 every hinge waited for its row (703 us per train: 21 cycles per
+    // instruction).  The prefetched values may sit in the accumulation half of the register file (loads write AGPRs directly).
+#ifndef IRLOSC_LANE_PFD
+#define IRLOSC_LANE_PFD 6
+#endif
+    constexpr int PFD = IRLOSC_LANE_PFD;
+    static_for<0, PFD>([&](auto dc) { constexpr int j = NJ - 1 - decltype(dc)::value; if constexpr (j >= 0) fetch(std::integral_constant<int, (j >= 0 ? j : 0)>{}); });
+    {   // Part 1 of the task signal [+ the wrench]: u_task_all + ext_f (osc.py:184-185), canonical order (padding: the entry of zeros;
+        // device 0, component 0 -- a valid address, times zero).  Requested behind the first rows of M -- one round trip for all of it --
+        // and parked in LDS: the values are next needed behind the k x k stage, and any register they held on the way was spilled, load
+        // by load, each waited for on the spot (13 to 26 round trips per wave).
+        double wt[K], wrv[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const int e = ZERO_E + rm[r] * (TASK_E - ZERO_E + lt.map.ext[r]);
+            wt[r] = col[(size_t)(unsigned)e * 64];
+            wrv[r] = (double)wbase[wsel * (((size_t)bc * nd + lt.map.dev[r]) * 6 + lt.map.comp[r])];
+        }
+#pragma unroll
+        for (int r = 0; r < K; ++r) s_w[r * 64 + lane] = fma((double)rm[r], wrv[r], wt[r]);
+    }
 
     // ---- the recursion, hinges NJ - 1 .. 0 --------------------------------------------------------------------------------------
     static_for_down<0, NJ>([&](auto jc) {
@@ -171,19 +216,27 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
         constexpr int ed = L::m_entry(j, j);
         constexpr bool below = L::has_below(j);
         double d = Mv[ed];
-        double mj = fma(d, dq[j], macc[j]);
-        if constexpr (below) d -= Dl[ed];
+        double mj = d * dq[j];
+        if constexpr (below) { mj += macc[j]; d -= Dl[ed]; }
         static_for<0, j>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             if constexpr (TI::above(i, j)) {
                 constexpr int e = L::m_entry(i, j);
                 const double m = Mv[e];
                 mj = fma(m, dq[i], mj);
-                macc[i] = fma(m, dq[j], macc[i]);
+                if constexpr (L::subtree_last(i) == j) macc[i] = m * dq[j];
+                else macc[i] = fma(m, dq[j], macc[i]);
+                pin(macc[i]);
                 lrow[i] = below ? m - Dl[e] : m;
             }
         });
-        s_u[j * 65 + lane] = mj;                               // (M dq)_j is complete: every row under j and row j itself have been read
+        {   // (M dq)_j is complete -- every row under j and row j itself have been read: the torque without its task term waits in LDS
+            // u0 (branch A damping, assignment in device order: osc.py:174) + bias - kvn (M dq)_j
+            double cf = 0.0;
+#pragma unroll
+            for (int d2 = 0; d2 < IRLOSC_MAX_DEV; ++d2) cf = ((jm[d2] >> j) & 1u) ? -kvd[d2] : cf;
+            s_u[j * 65 + lane] = fma(cf - kvn, mj, Bv[j]);
+        }
         npd = npd | !(d > 0.0);                                // also catches NaN
         d = fmax(d, 1e-300);
         const double rs = rsq_refined(d);
@@ -244,35 +297,38 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
         }
     });
     __builtin_amdgcn_sched_barrier(0);
+#ifndef IRLOSC_LANE_JT_EARLY
+#define IRLOSC_LANE_JT_EARLY 0
+#endif
+    // The Jacobian entries once more, for J^T t behind the k x k stage (and for the records of the flagged robots).  Requested ahead of
+    // that stage their round trip would run under its ~2 000 instructions -- but 85 more live doubles next to the factor's 91 spill
+    // (1.3 kB of scratch): they are requested behind it.
+    double Jt[K][NJ];
+    auto load_jt = [&]() {
+        static_for<0, NJ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (L::hinge_ee(j)) {
+                static_for<0, K>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    if constexpr (L::row_moved(r, j)) Jt[r][j] = jload(rc, jc);
+                });
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (IRLOSC_LANE_JT_EARLY) load_jt();
 
     uint32_t flags = npd ? IRLOSC_FLAG_M_NOT_PD : 0u;
-    // ---- w = u_task_all [+ ext_f] - kvn dx (osc.py:184-185, null-space term folded in: osc_generic.hpp header) ------------------
-    // (No branch between the recursion and the k x k stage: with one in between, the compiler SINKS the whole factorisation -- every value
-    //  that is only used behind the branch -- out of the pinned regions above, and all 330 loads stay live at once.  Hence loads through
-    //  selected addresses instead of `if (flag) load`.)
-    const bool has_wr = (p.cfgflags & IRLOSC_ADMITTANCE) && p.wrench != nullptr;
-    const int nd = p.ndev;
-    const TIN* __restrict__ zeros = reinterpret_cast<const TIN*>(x.zeros);
-    const double kvn = (p.cfgflags & IRLOSC_NULLSPACE) ? (double)p.null_kv[p.gains_per_instance ? bc : 0] * 1.0 : 0.0;
-    double wr[K];
-#pragma unroll
-    for (int r = 0; r < K; ++r) {      // (padding: device 0, component 0 -- a valid address, times zero)
-        const TIN* wp = has_wr ? p.wrench + ((size_t)bc * nd + lt.map.dev[r]) * 6 + lt.map.comp[r] : zeros;
-        wr[r] = (double)rm[r] * (double)*wp;
-    }
-    double w[K];
+    // ---- w = u_task_all [+ ext_f] - kvn dx (null-space term folded in: osc_generic.hpp header) -------------------------------------
     bool nr[K];                     // row r is padding, or a task row no joint can move (A[r][r] == 0 exactly: row r of J is zero)
     bool anyzero = false;
     static_for<0, K>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         const bool real = rm[r] != 0;
-        const int e = ZERO_E + rm[r] * (TASK_E - ZERO_E + lt.map.ext[r]);
-        double v = col[(size_t)(unsigned)e * 64];
-        v += wr[r];
         const bool zr = real && Al[L::tri(r, r)] == 0.0;
         anyzero = anyzero | zr;
         nr[r] = !real | zr;
-        w[r] = nr[r] ? 0.0 : v - kvn * dx[r];
+        s_w[r * 64 + lane] = nr[r] ? 0.0 : s_w[r * 64 + lane] - kvn * dx[r];      // (own slot: no other lane reads it)
     });
     // ---- k x k: L~ D L~^T in place (Lf), the certificate, the plain solve (osc.py:51-55; osc_row16.hpp) --------------------------
     double nA2 = 0.0;
@@ -308,6 +364,7 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
             });
         });
         static_for<j + 1, K>([&](auto ic) { constexpr int i = decltype(ic)::value; Lf[L::tri(i, j)] = f[i]; });
+        __builtin_amdgcn_sched_barrier(0);      // (column by column: left to itself the scheduler interleaves the whole stage and everything long-lived spills)
     });
     // trace(A^-1) = sum over the columns m of W = L~^-1 of sum_c W[c][m]^2 / d_c (real rows only)
     double trA = 0.0;
@@ -324,6 +381,7 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
             acc = fma(s * s, nr[c] ? 0.0 : invd[c], acc);
         });
         trA += acc;
+        if constexpr (m % 2 == 1) __builtin_amdgcn_sched_barrier(0);      // two columns of W at a time
     });
     const bool small_det = !pd | !(fabs(det) >= 1e-4) | anyzero;
     const double cond_bound = sqrt(nA2) * trA;
@@ -331,7 +389,9 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
     flags |= small_det ? IRLOSC_FLAG_PINV_BRANCH : 0u;
     flags |= plain ? 0u : IRLOSC_FLAG_EIGEN_PATH;
     flags |= anyzero ? IRLOSC_FLAG_TRUNCATED : 0u;
-    double t[K];
+    double t[K], w[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) w[r] = s_w[r * 64 + lane];
     static_for<0, K>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
         double s = w[c];
@@ -348,7 +408,7 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
     static_for<0, K>([&](auto cc) { constexpr int c = decltype(cc)::value; t[c] = plain ? t[c] : 0.0; });      // the eigen pass adds its own J^T t
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- the robots the certificate does not clear: records for the eigen pass (slot: one atomic per wave) ----------------------------
+    // ---- the robots the certificate does not clear get a record for the eigen pass: slot from one atomic per wave ---------------------
     const bool hand = !plain && live;
     const unsigned long long hm = __ballot(hand);
     double* __restrict__ rec = nullptr;
@@ -357,58 +417,41 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
         int base = 0;
         if (lane == first) base = atomicAdd(lt.rec_count[blockIdx.y], (int)__builtin_popcountll(hm));
         base = __builtin_amdgcn_readlane(base, first);
-        if (hand) {
-            const int slot = base + (int)__builtin_popcountll(hm & ((1ull << lane) - 1ull));
-            rec = lt.rec[blockIdx.y] + (size_t)slot * REC_DOUBLES;
-            uint32_t nrm = 0u;
-            // A = L~ D' L~^T - diag(d' - d), column by column: Ld[r] = L~[r][j] d'_j is column j of the matrix as the factorisation met it
-            double Ar[K * (K + 1) / 2];
-            static_for<0, K>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                const double dj = (dtrue[j] > 0.0 && !nr[j]) ? dtrue[j] : 1.0;      // d'_j
-                double Ld[K];
-                static_for<j + 1, K>([&](auto rc) { constexpr int r = decltype(rc)::value; Ld[r] = Lf[L::tri(r, j)] * dj; });
-                // entry (j, j): everything the earlier columns contributed has been added already; the true pivot closes it
-                if constexpr (j == 0) Ar[L::tri(j, j)] = dtrue[j];
-                else Ar[L::tri(j, j)] += dtrue[j];
-                static_for<j + 1, K>([&](auto rc) {
-                    constexpr int r = decltype(rc)::value;
-                    if constexpr (j == 0) Ar[L::tri(r, j)] = Ld[r];
-                    else Ar[L::tri(r, j)] += Ld[r];
-                    static_for<j + 1, r + 1>([&](auto cc) {
-                        constexpr int c = decltype(cc)::value;
-                        if constexpr (j == 0) Ar[L::tri(r, c)] = Ld[r] * Lf[L::tri(c, j)];
-                        else Ar[L::tri(r, c)] = fma(Ld[r], Lf[L::tri(c, j)], Ar[L::tri(r, c)]);
-                    });
-                });
-            });
-            static_for<0, K>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                nrm |= nr[r] ? (1u << r) : 0u;
-                static_for<0, K>([&](auto cc) {
-                    constexpr int c = decltype(cc)::value;
-                    rec[REC_A + r * 16 + c] = Ar[r >= c ? L::tri(r, c) : L::tri(c, r)];
-                });
-                rec[REC_W + r] = w[r];
-            });
-            reinterpret_cast<long long*>(rec)[REC_META] = (long long)b;
-            reinterpret_cast<long long*>(rec)[REC_META + 1] = (long long)nrm;
-            // the Jacobian entries, columns = the EE hinges in their order (the structural zeros of the block are never written: the
-            // buffer is zeroed when it is allocated)
-            static_for<0, NJ>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                if constexpr (L::hinge_ee(j)) {
-                    constexpr int cr = L::ee_rank(j);
-                    static_for<0, K>([&](auto rc) {
-                        constexpr int r = decltype(rc)::value;
-                        if constexpr (L::row_moved(r, j)) rec[REC_J + r * 16 + cr] = jload(rc, jc);
-                    });
-                }
-            });
-        }
+        const int slot = base + (int)__builtin_popcountll(hm & ((1ull << lane) - 1ull));
+        rec = lt.rec[blockIdx.y] + (size_t)(hand ? slot : 0) * REC_DOUBLES;
     }
-
-    // ---- J^T t, hinge by hinge (the Jacobian entries once more: cached lines) ---------------------------------------------------------
+    if (hand) {
+        uint32_t nrm = 0u;
+        static_for<0, K>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            nrm |= nr[r] ? (1u << r) : 0u;
+            rec[REC_W + r] = w[r];
+        });
+        reinterpret_cast<long long*>(rec)[REC_META] = (long long)b;
+        reinterpret_cast<long long*>(rec)[REC_META + 1] = (long long)nrm;
+        // A = L~ D' L~^T - diag(d' - d), row by row and straight into the record (no second triangle in registers: with the factor's 91
+        // entries that is what spilled): Ldr[j] = L~[r][j] d'_j, A[r][c] = sum_{j < c} Ldr[j] L~[c][j] + Ldr[c], the true pivot on the diagonal
+        double dpr[K];
+        static_for<0, K>([&](auto jc) { constexpr int j = decltype(jc)::value; dpr[j] = (dtrue[j] > 0.0 && !nr[j]) ? dtrue[j] : 1.0; });
+        static_for<0, K>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            double Ldr[K];
+            static_for<0, r>([&](auto jc) { constexpr int j = decltype(jc)::value; Ldr[j] = Lf[L::tri(r, j)] * dpr[j]; });
+            static_for<0, r + 1>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                double acc;
+                if constexpr (c < r) acc = Ldr[c]; else acc = dtrue[r];
+                static_for<0, c>([&](auto jc) { constexpr int j = decltype(jc)::value; acc = fma(Ldr[j], Lf[L::tri(c, j)], acc); });
+                rec[REC_A + r * 16 + c] = acc;
+                if constexpr (c < r) rec[REC_A + c * 16 + r] = acc;
+            });
+        });
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- J^T t, hinge by hinge, behind the records' A (the factor is dead by now: its 91 entries and these 85 do not fit the
+    // architectural registers together); the flagged robots leave the entries in their record (columns = the EE hinges in their order; the
+    // structural zeros of that block are never written: the buffer is zeroed when it is allocated)
+    if constexpr (!IRLOSC_LANE_JT_EARLY) load_jt();
     double jt[NJ];
     static_for<0, NJ>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -416,40 +459,30 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
             double s = 0.0;
             static_for<0, K>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                if constexpr (L::row_moved(r, j)) s = fma(jload(rc, jc), t[r], s);
+                if constexpr (L::row_moved(r, j)) s = fma(Jt[r][j], t[r], s);
             });
             jt[j] = s;
         }
     });
-    // ---- torques (osc.py:174,184-200): u = u0 + bias - kvn M dq - J^T t, through the LDS tile ------------------------------------
-    const bool use_g = (p.cfgflags & IRLOSC_USE_G) != 0;
-    bool bad = false;
-    double kvd[IRLOSC_MAX_DEV];
-    uint32_t jm[IRLOSC_MAX_DEV];
-#pragma unroll
-    for (int d2 = 0; d2 < IRLOSC_MAX_DEV; ++d2) {
-        const int dd = d2 < nd ? d2 : 0;
-        kvd[d2] = (double)p.gains[(p.gains_per_instance ? (size_t)bc * nd * IRLOSC_GAIN_WORDS : 0) + dd * IRLOSC_GAIN_WORDS + 1];
-        jm[d2] = d2 < nd ? p.dev[dd].joint_mask : 0u;
+    if (hand) {
+        static_for<0, NJ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (L::hinge_ee(j)) {
+                constexpr int cr = L::ee_rank(j);
+                static_for<0, K>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    if constexpr (L::row_moved(r, j)) rec[REC_J + r * 16 + cr] = Jt[r][j];
+                });
+            }
+        });
     }
-    const TIN* __restrict__ zb = reinterpret_cast<const TIN*>(x.zeros);
-    (void)zb;
+    // ---- torques (osc.py:174,184-200): u = (u0 + bias - kvn M dq, parked in LDS hinge by hinge) - J^T t -----------------------------------
+    bool bad = false;
     static_for<0, NJ>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        const double mdq = s_u[j * 65 + lane];
-        double u0 = 0.0;
-#pragma unroll
-        for (int d2 = 0; d2 < IRLOSC_MAX_DEV; ++d2) {      // branch A damping, assignment in device order (osc.py:174)
-            u0 = ((jm[d2] >> j) & 1u) ? -kvd[d2] * mdq : u0;
-        }
-        {   // (the entry of zeros when the bias forces are off: a selected address, no branch)
-            constexpr int eb = TI::bias_index(j);
-            u0 += col[(size_t)(use_g ? eb : ZERO_E) * 64];
-        }
-        u0 -= kvn * mdq;
-        if constexpr (L::hinge_ee(j)) u0 -= jt[j];
-        bad = bad || !t_finite(u0);
-        s_u[j * 65 + lane] = u0;
+        double u0 = s_u[j * 65 + lane];
+        if constexpr (L::hinge_ee(j)) { u0 -= jt[j]; s_u[j * 65 + lane] = u0; }
+        bad = bad | !t_finite(u0);
     });
     flags |= bad ? IRLOSC_FLAG_NONFINITE : 0u;
     if (live) p.flags[b] = flags;

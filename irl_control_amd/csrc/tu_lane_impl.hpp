@@ -31,7 +31,9 @@ int launch_lane_osc<IRLOSC_LANE_TIN>(const Row16Train<IRLOSC_LANE_TIN>& tr, cons
     if (tr.p[0].B <= 0 || nsteps <= 0) return 0;
     switch (tier) {
         case 0: return lane_launch<Shape<1, 6, 6>, IRLOSC_LANE_TIN>(tr, lt, nsteps, eig_blocks, st);
+#ifndef IRLOSC_LANE_ONLY_TIER0      // (register / ISA experiments on one instantiation)
         case 1: return lane_launch<Shape<1, 3, 3>, IRLOSC_LANE_TIN>(tr, lt, nsteps, eig_blocks, st);
+#endif
         default: return (int)hipErrorNotSupported;
     }
 }
