@@ -864,12 +864,14 @@ extern "C" int irlosc_download(irlosc_ctx* c, int32_t B, void* u_host, uint32_t*
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->ddbg && B >= 16) {   // debug: mean cycles per phase over all waves
         const bool r16 = c->kernel == IRLOSC_KERNEL_ROW16;
-        const int tiles = r16 ? B / 4 : B / 16;
+        const bool lanef = getenv("IRLOSC_PHASE_LANE") != nullptr;      // a -DIRLOSC_LANE_STAMPS build: the lane kernel of the fused path stamped
+        const int tiles = lanef ? B / 64 : r16 ? B / 4 : B / 16;
         std::vector<unsigned long long> h((size_t)tiles * 10);
         HIPCHK(c, hipMemcpy(h.data(), c->ddbg, h.size() * 8, hipMemcpyDeviceToHost));
         static const char* nm_g[7] = {"vec-wait", "M-stream+Cholesky", "J+fwd-subst", "task-error", "A=YtY", "kxk", "torques+store"};
         static const char* nm_r[7] = {"loads+task-error", "J->LDS", "main-loop", "A=YtY", "kxk", "eigen", "torques+store"};
-        const char* const* nm = r16 ? nm_r : nm_g;
+        static const char* nm_l[7] = {"first-requests+task-rows", "recursion", "kxk", "records", "Jt+sums", "torques+store", "-"};
+        const char* const* nm = lanef ? nm_l : r16 ? nm_r : nm_g;
         double acc[7] = {0}, rt = 0;
         unsigned long long rmin = ~0ull, rmax = 0;
         for (int t = 0; t < tiles; ++t) {

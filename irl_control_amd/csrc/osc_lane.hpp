@@ -81,6 +81,12 @@ using r16::static_for_down;
 // first and the factorisation afterwards, with everything live in between (1 kB of scratch).  An empty volatile asm is ordered like a
 // side effect: what it touches is computed before the next pin of the schedule.
 __device__ __forceinline__ void pin(double& v) { asm volatile("" : "+v"(v)); }
+// two doubles with one 16-byte store (a record is written by the few flagged lanes of a wave, every lane to a region of its own: such a
+// store costs its issue slot per LANE ADDRESS, not per byte -- the 267 eight-byte stores of a record were a third of the kernel's cycles)
+__device__ __forceinline__ void st2(double* p, const double a, const double b) { *reinterpret_cast<double2*>(p) = make_double2(a, b); }
+// rank among the EE hinges -> hinge (or -1)
+template <class L>
+constexpr int hinge_of_rank(int cr) { for (int j = 0; j < L::NJ; ++j) if (L::hinge_ee(j) && L::ee_rank(j) == cr) return j; return -1; }
 using r16::rsq_refined;
 using r16::rcp_refined;
 
@@ -107,6 +113,16 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
     const uint32_t realm = lt.map.real;
     __shared__ double s_u[NJ * 65];                    // M dq as the hinges complete, then the torques: [hinge][64 robots + 1 pad]
     __shared__ double s_w[K * 64];                     // the task vector waits here across the recursion and the k x k stage
+    // -DIRLOSC_LANE_STAMPS (tools/build_variant.py; tools/phase_timing.py ... fromq with IRLOSC_PHASE_LANE=1): cycle stamps per phase into
+    // p.dbg.  Compile-time only: a run-time `if (p.dbg)` around a stamp is a branch, and a branch inside the recursion lets the compiler
+    // sink the arithmetic out of its pinned regions (see pin()).
+#ifdef IRLOSC_LANE_STAMPS
+    unsigned long long ts[8];
+#define LANE_TS(i) ts[i] = __builtin_readcyclecounter()
+#else
+#define LANE_TS(i)
+#endif
+    LANE_TS(0);
     const unsigned long long rt0 = x.span ? __builtin_amdgcn_s_memrealtime() : 0ull;      // irlosc_time_trains (see Row16Extra::span)
     const unsigned long long cyc0 = x.span ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
 
@@ -208,6 +224,7 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
         for (int r = 0; r < K; ++r) s_w[r * 64 + lane] = fma((double)rm[r], wrv[r], wt[r]);
     }
 
+    LANE_TS(1);
     // ---- the recursion, hinges NJ - 1 .. 0 --------------------------------------------------------------------------------------
     static_for_down<0, NJ>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -316,8 +333,9 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
         });
         __builtin_amdgcn_sched_barrier(0);
     };
-    if constexpr (IRLOSC_LANE_JT_EARLY) load_jt();
+    if constexpr (IRLOSC_LANE_JT_EARLY == 1) load_jt();
 
+    LANE_TS(2);
     uint32_t flags = npd ? IRLOSC_FLAG_M_NOT_PD : 0u;
     // ---- w = u_task_all [+ ext_f] - kvn dx (null-space term folded in: osc_generic.hpp header) -------------------------------------
     bool nr[K];                     // row r is padding, or a task row no joint can move (A[r][r] == 0 exactly: row r of J is zero)
@@ -407,7 +425,8 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
     });
     static_for<0, K>([&](auto cc) { constexpr int c = decltype(cc)::value; t[c] = plain ? t[c] : 0.0; });      // the eigen pass adds its own J^T t
     __builtin_amdgcn_sched_barrier(0);
-
+    LANE_TS(3);
+    if constexpr (IRLOSC_LANE_JT_EARLY == 2) load_jt();      // (in flight while the records are written)
     // ---- the robots the certificate does not clear get a record for the eigen pass: slot from one atomic per wave ---------------------
     const bool hand = !plain && live;
     const unsigned long long hm = __ballot(hand);
@@ -422,13 +441,13 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
     }
     if (hand) {
         uint32_t nrm = 0u;
-        static_for<0, K>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            nrm |= nr[r] ? (1u << r) : 0u;
-            rec[REC_W + r] = w[r];
+        static_for<0, K>([&](auto rc) { constexpr int r = decltype(rc)::value; nrm |= nr[r] ? (1u << r) : 0u; });
+        static_for<0, (K + 1) / 2>([&](auto pc) {
+            constexpr int r = 2 * decltype(pc)::value;
+            if constexpr (r + 1 < K) st2(rec + REC_W + r, w[r], w[r + 1]);
+            else st2(rec + REC_W + r, w[r], 0.0);
         });
-        reinterpret_cast<long long*>(rec)[REC_META] = (long long)b;
-        reinterpret_cast<long long*>(rec)[REC_META + 1] = (long long)nrm;
+        st2(rec + REC_META, __builtin_bit_cast(double, (long long)b), __builtin_bit_cast(double, (long long)nrm));
         // A = L~ D' L~^T - diag(d' - d), row by row and straight into the record (no second triangle in registers: with the factor's 91
         // entries that is what spilled): Ldr[j] = L~[r][j] d'_j, A[r][c] = sum_{j < c} Ldr[j] L~[c][j] + Ldr[c], the true pivot on the diagonal
         double dpr[K];
@@ -437,21 +456,24 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
             constexpr int r = decltype(rc)::value;
             double Ldr[K];
             static_for<0, r>([&](auto jc) { constexpr int j = decltype(jc)::value; Ldr[j] = Lf[L::tri(r, j)] * dpr[j]; });
+            double arow[K + 1];              // the LOWER triangle's row r, stored two entries at a time (the eigen pass mirrors the indices)
+            arow[r + 1] = 0.0;
             static_for<0, r + 1>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
                 double acc;
                 if constexpr (c < r) acc = Ldr[c]; else acc = dtrue[r];
                 static_for<0, c>([&](auto jc) { constexpr int j = decltype(jc)::value; acc = fma(Ldr[j], Lf[L::tri(c, j)], acc); });
-                rec[REC_A + r * 16 + c] = acc;
-                if constexpr (c < r) rec[REC_A + c * 16 + r] = acc;
+                arow[c] = acc;
             });
+            static_for<0, r / 2 + 1>([&](auto pc) { constexpr int c = 2 * decltype(pc)::value; st2(rec + REC_A + r * 16 + c, arow[c], arow[c + 1]); });
         });
     }
     __builtin_amdgcn_sched_barrier(0);
+    LANE_TS(4);
     // ---- J^T t, hinge by hinge, behind the records' A (the factor is dead by now: its 91 entries and these 85 do not fit the
     // architectural registers together); the flagged robots leave the entries in their record (columns = the EE hinges in their order; the
     // structural zeros of that block are never written: the buffer is zeroed when it is allocated)
-    if constexpr (!IRLOSC_LANE_JT_EARLY) load_jt();
+    if constexpr (IRLOSC_LANE_JT_EARLY == 0) load_jt();
     double jt[NJ];
     static_for<0, NJ>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -465,17 +487,22 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
         }
     });
     if (hand) {
-        static_for<0, NJ>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            if constexpr (L::hinge_ee(j)) {
-                constexpr int cr = L::ee_rank(j);
-                static_for<0, K>([&](auto rc) {
-                    constexpr int r = decltype(rc)::value;
-                    if constexpr (L::row_moved(r, j)) rec[REC_J + r * 16 + cr] = Jt[r][j];
-                });
-            }
+        static_for<0, K>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            static_for<0, 8>([&](auto pc) {
+                constexpr int c0 = 2 * decltype(pc)::value;
+                constexpr int j0 = hinge_of_rank<L>(c0), j1 = hinge_of_rank<L>(c0 + 1);
+                constexpr bool m0 = j0 >= 0 && L::row_moved(r, j0 >= 0 ? j0 : 0), m1 = j1 >= 0 && L::row_moved(r, j1 >= 0 ? j1 : 0);
+                if constexpr (m0 || m1) {
+                    double a = 0.0, b2 = 0.0;
+                    if constexpr (m0) a = Jt[r][j0 >= 0 ? j0 : 0];
+                    if constexpr (m1) b2 = Jt[r][j1 >= 0 ? j1 : 0];
+                    st2(rec + REC_J + r * 16 + c0, a, b2);
+                }
+            });
         });
     }
+    LANE_TS(5);
     // ---- torques (osc.py:174,184-200): u = (u0 + bias - kvn M dq, parked in LDS hinge by hinge) - J^T t -----------------------------------
     bool bad = false;
     static_for<0, NJ>([&](auto jc) {
@@ -499,6 +526,17 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
             if (rob < nrob) uo[idx] = (TIN)s_u[jn * 65 + rob];
         }
     }
+#ifdef IRLOSC_LANE_STAMPS
+    LANE_TS(6);
+    if (p.dbg && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) p.dbg[(size_t)blockIdx.x * 10 + i] = ts[i];
+        p.dbg[(size_t)blockIdx.x * 10 + 7] = ts[6];
+        p.dbg[(size_t)blockIdx.x * 10 + 8] = 0;
+        p.dbg[(size_t)blockIdx.x * 10 + 9] = 0;
+    }
+#endif
+#undef LANE_TS
     if (x.span && lane == 0) {       // first wave's start / last wave's end of the train, untraced (irlosc_time_trains)
         unsigned long long* sp = x.span + 2 * (blockIdx.x & (R16_SPAN_SLOTS - 1));
         const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
@@ -516,23 +554,26 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
 // lane c = column c of A) -- the factorisation, the certificate's numbers and eigen16 exactly as the row16 kernel runs them in place
 // (osc_row16.hpp), then u -= J^T t on the torques the lane kernel left without the task term.  Persistent blocks, blockIdx.y = step.
 // Rows that are padding or exact zero rows arrive as a mask and are treated like the KMAX-padded kernels treat them (PAD = true).
+#ifndef IRLOSC_LANE_EIG_WAVES
+#define IRLOSC_LANE_EIG_WAVES 2
+#endif
 template <class TOPO, class SH, typename TIN>
-__global__ __launch_bounds__(64, 2) void osc_lane_eigen_kernel(const Row16Train<TIN> tr, const LaneTrain lt) {
+__global__ __launch_bounds__(64, IRLOSC_LANE_EIG_WAVES) void osc_lane_eigen_kernel(const EigTrain et) {
     using namespace r16;
     using L = LT<TOPO, SH>;
     constexpr int NJ = L::NJ, K = L::K;
-    const KParams<TIN>& p = tr.p[blockIdx.y];
-    const Row16Extra& x = tr.x[blockIdx.y];
-    const int n = __builtin_amdgcn_readfirstlane(min(*lt.rec_count[blockIdx.y], p.B));
+    const EigStep& es = et.s[blockIdx.y];
+    const int n = __builtin_amdgcn_readfirstlane(min(*es.rec_count, et.B));
     const int lane = threadIdx.x, q = lane >> 4, l = lane & 15;
     constexpr int NEE = L::n_ee();
     for (int g = blockIdx.x; g * 4 < n; g += gridDim.x) {
         const int ri = g * 4 + q;
         const bool live = ri < n;
-        const double* __restrict__ rec = lt.rec[blockIdx.y] + (size_t)(live ? ri : n - 1) * REC_DOUBLES;
+        const double* __restrict__ rec = es.rec + (size_t)(live ? ri : n - 1) * REC_DOUBLES;
         double Ac[K], A[K];
 #pragma unroll
-        for (int r = 0; r < K; ++r) Ac[r] = rec[REC_A + r * 16 + l];          // (columns >= K are never written: zeros since the allocation)
+        for (int r = 0; r < K; ++r) Ac[r] = rec[REC_A + (r >= l ? r * 16 + l : l * 16 + r)];      // (the lower triangle is stored; lanes >= K read
+                                                                                                    //  rows that are never written: zeros since the allocation)
         const double w = rec[REC_W + l];
         const uint32_t zrow = (uint32_t)reinterpret_cast<const long long*>(rec)[REC_META + 1];
         double nA2 = 0.0;
@@ -571,7 +612,7 @@ __global__ __launch_bounds__(64, 2) void osc_lane_eigen_kernel(const Row16Train<
         const int q2 = lane2 >> 4, l2 = lane2 & 15;
         const int ri2 = g * 4 + q2;
         const bool live2 = ri2 < n;
-        const double* __restrict__ rec2 = lt.rec[blockIdx.y] + (size_t)(live2 ? ri2 : n - 1) * REC_DOUBLES;
+        const double* __restrict__ rec2 = et.s[blockIdx.y].rec + (size_t)(live2 ? ri2 : n - 1) * REC_DOUBLES;
         const long long bid = reinterpret_cast<const long long*>(rec2)[REC_META];
         double jr[K];
 #pragma unroll
@@ -591,17 +632,18 @@ __global__ __launch_bounds__(64, 2) void osc_lane_eigen_kernel(const Row16Train<
         __builtin_amdgcn_sched_barrier(0);
         bool bad = false;
         if (live2 && l2 < NEE) {
-            TIN* up = p.u + (size_t)bid * NJ + hinge;
+            TIN* up = reinterpret_cast<TIN*>(et.s[blockIdx.y].u) + (size_t)bid * NJ + hinge;
             const double u = (double)*up - jt;
             bad = !t_finite(u);
             *up = (TIN)u;
         }
         const unsigned long long bm = __ballot(bad);
         if (live2 && l2 == 0) {
-            uint32_t fl = p.flags[bid] | f2;
+            const EigStep& e2 = et.s[blockIdx.y];
+            uint32_t fl = e2.flags[bid] | f2;
             if ((bm >> (q2 * 16)) & 0xffffull) fl |= IRLOSC_FLAG_NONFINITE;
-            p.flags[bid] = fl;
-            if (giveup) x.worklist[atomicAdd(x.workcount, 1)] = (int32_t)bid;
+            e2.flags[bid] = fl;
+            if (giveup) e2.worklist[atomicAdd(e2.workcount, 1)] = (int32_t)bid;
         }
     }
 }

@@ -29,6 +29,20 @@ struct LaneTrain {
     RowMap map;
 };
 
+// What the eigen pass needs of a step, and nothing else (the two trains of the lane kernel are 3 kB of kernel arguments; indexed by
+// blockIdx.y they cost the pass a hundred spilled scalar registers)
+struct EigStep {
+    void* u;                            // [B][n] torques, record type
+    uint32_t* flags;                    // [B]
+    int32_t* worklist;                  // give-up list of the step (-> generic kernel)
+    int32_t* workcount;
+    const double* rec;
+    const int32_t* rec_count;
+};
+struct EigTrain {
+    EigStep s[R16_TRAIN];
+    int32_t B;
+};
 
 // tiers of canonical rows per end-effector body of the Dual-UR5 (stand dummy, right EE, left EE): launch_lane_osc's `tier`
 constexpr int N_TIERS = 2;

@@ -16,7 +16,12 @@ static int lane_launch(const Row16Train<TIN>& tr, const lane::LaneTrain& lt, int
     const KParams<TIN>& p = tr.p[0];
     const int waves = (p.B + 63) / 64;
     hipLaunchKernelGGL((lane::osc_lane_kernel<TopoDualUr5, SH, TIN>), dim3(waves, nsteps), dim3(64), 0, st, tr, lt);
-    hipLaunchKernelGGL((lane::osc_lane_eigen_kernel<TopoDualUr5, SH, TIN>), dim3(eig_blocks, nsteps), dim3(64), 0, st, tr, lt);
+    lane::EigTrain et;
+    memset(&et, 0, sizeof et);
+    et.B = p.B;
+    for (int i = 0; i < nsteps; ++i)
+        et.s[i] = lane::EigStep{tr.p[i].u, tr.p[i].flags, tr.x[i].worklist, tr.x[i].workcount, lt.rec[i], lt.rec_count[i]};
+    hipLaunchKernelGGL((lane::osc_lane_eigen_kernel<TopoDualUr5, SH, TIN>), dim3(eig_blocks, nsteps), dim3(64), 0, st, et);
     return (int)hipGetLastError();
 }
 
