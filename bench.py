@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — OSC control steps/sec on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f64|mixed|f32] [--batch B] [--layout k13|k7|k12_admit]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f64|mixed] [--batch B] [--layout k13|k7|k12_admit]
 
 A "step" is one pass of the OSC hot path over one resident batch of B synthetic Dual-UR5 instances per GPU
 (default: B = 65 536, n = 25 joints, layout k13 = both arms xyz+abg and the base yaw, gravity and null-space
@@ -20,7 +20,6 @@ batches are rotated so that successive launches do not re-hit the 256 MiB Infini
 --dtype names the ARITHMETIC of the measured path:
   f64    float64 records, float64 arithmetic (osc_row16 kernel)  - the reference's precision, meets north_star's 1e-5
   mixed  float32 records, float64 arithmetic (osc_row16 kernel)  - BASELINE configs[2]'s fp32 storage at the 1e-5 bar
-  f32    float32 records, float32 arithmetic (osc_group kernel)  - fastest, does NOT meet 1e-5: error ~ eps32 * cond(J M^-1 J^T)
 The JSON line's "dtype" is the arithmetic type ("f64" for f64 and mixed); config.records names the storage.
 
 Instances shard across GPUs with no data-path collective (weak scaling: B per GPU is fixed; `--total-batch T`
@@ -74,7 +73,6 @@ FLOPS_FRONT_END = 15.4e3                                                # FK, EE
 MODES = {   # --dtype -> (record dtype, arithmetic label, kernel id)
     "f64": (np.float64, "f64", 0),
     "mixed": (np.float32, "f64", 3),
-    "f32": (np.float32, "f32", 2),      # explicit opt-in: IRLOSC_KERNEL_GROUP
 }
 
 
@@ -501,11 +499,10 @@ def main():
     ap.add_argument("--total-batch", type=int, default=0, help="instances over all GPUs (overrides --batch)")
     ap.add_argument("--slots", type=int, default=4)
     ap.add_argument("--layout", default="k13")
-    ap.add_argument("--kernel", type=int, default=-1, help="override: 0 auto, 1 generic, 2 group, 3 row16")
+    ap.add_argument("--kernel", type=int, default=-1, help="override: 0 auto, 1 generic, 3 row16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="length of each of the two CPU timing windows (one core, all cores)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other storage variant (mixed) and the synthetic-records run")
-    ap.add_argument("--with-f32", action="store_true", help="also run the fp32-arithmetic group kernel as a secondary (explicit opt-in kernel: does NOT meet 1e-5)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the H2D/D2H-inclusive legs (generate_batched from host arrays, tick at B = 1, upload_raw)")
     ap.add_argument("--require-rccl", action="store_true", help="N > 1: exit non-zero unless every rank's barrier / reduction went through RCCL")
     ap.add_argument("--sustained-steps", type=int, default=8000, help="steps of the long-run leg reported as `sustained` (0: skip)")
@@ -660,9 +657,7 @@ def main():
         tree = all(osc.slot_structure(sl) for sl in range(args.slots))
         kname = osc.kernel_name + ("+tree" if tree else "")
         note = ""
-        if "group" in kname:
-            note = ":fused(stage 1 of %d chained steps + riding stage 2 of the previous launch)" % spl
-        elif "row16" in kname:
+        if "row16" in kname:
             tpass = os.environ.get("IRLOSC_TASK_PASS", "1") != "0"
             note = ":step(" + ("the task pass osc_task_rows_dense_kernel (part 1 of the task signal, one lane per (instance, device)) + the row16 "
                                "kernel: " if tpass else "") + "all instances incl. the in-kernel truncated-pinv stage; + the give-up list launch)" + (
@@ -719,7 +714,7 @@ def main():
 
     # CPU legs first: their worker processes are forked before this process has initialised the HIP runtime
     cb = ref = ref_idx = fq_state = fq_ref = None
-    others = [m for m in (("f64", "mixed") + (("f32",) if args.with_f32 else ())) if m != args.dtype] if (world == 1 and not args.no_secondary) else []
+    others = [m for m in ("f64", "mixed") if m != args.dtype] if (world == 1 and not args.no_secondary) else []
     NSEC = 4096                       # instances of slot 0 the secondary modes are checked on (oracle in this process)
     minted_crc = None
     if rank == 0 and not args.no_cpu_baseline:          # N > 1 too: rank 0's host cores, rank 0's shard (the other ranks wait in make_comm)
@@ -836,7 +831,7 @@ def main():
             try:
                 sec, schk = measure(other, max(24, min(200, args.steps // 4)), max(8, min(24, args.warmup // 4)),
                                     preroll=min(args.preroll, 100), workload=wl, long_leg=False)
-            except Exception as e:                       # e.g. a layout without a group kernel
+            except Exception as e:
                 out["secondary"].append({"mode": other, "records_from": wl, "error": str(e)})
                 continue
             slay = sec.pop("layout")
@@ -847,12 +842,9 @@ def main():
                 n = min(NSEC, B)
                 full = np.full((su.shape[0], su.shape[1]), np.nan)
                 full[:n] = oracle_reference(slay, sgains, sarr, 0, n)
-                f32 = sec["arith"] == "f32"
                 entry["parity_sample"] = parity_sample(
                     sarr, su, full, range(n), tol=1e-5,
-                    note=("float32 ARITHMETIC: error ~ eps32 * cond(J M^-1 J^T); this mode is the fastest one and does NOT meet "
-                          "north_star's 1e-5 (n_over_tol says by how much); " if f32 else "")
-                         + "GPU vs float64 oracle on the same (record-dtype-rounded) records; parity domain per SURVEY.md 8c")
+                    note="GPU vs float64 oracle on the same (record-dtype-rounded) records; parity domain per SURVEY.md 8c")
             out["secondary"].append(entry)
     for e_ in out.get("secondary", []):       # rounds 1-3 quoted this workload as the headline: kept at top level under its own name
         if e_.get("records_from") == "synthetic" and e_.get("mode") == args.dtype and "value" in e_:

@@ -22,7 +22,7 @@
  *                                                                  (dense records) or irlosc_step_from_q (fused: no records)
  *
  * Record layouts (batch-major, row-major, element type = cfg.dtype: float or double):
- *   M[B][n][n]      joint-space inertia, symmetric positive definite (the group kernel reads row j as column j)
+ *   M[B][n][n]      joint-space inertia, symmetric positive definite (the row16 kernels read row j as column j)
  *   J[B][k][n]      stacked task Jacobian, device blocks in TARGETS order, k = sum(dev_rows)
  *   dq[B][n]        joint velocities
  *   bias[B][n]      qfrc_bias (gravity + Coriolis); ignored unless IRLOSC_USE_G
@@ -66,10 +66,10 @@ extern "C" {
 #endif
 
 /* 2 (round 5): a fused irlosc_step_from_q invalidates the slot's dense records (IRLOSC_ERR_STATE on a later irlosc_step);
- * IRLOSC_KERNEL_AUTO on float32 records means fp64 arithmetic (row16 "mixed"), never the fp32 group kernel; every n = 25 layout
+ * IRLOSC_KERNEL_AUTO on float32 records means fp64 arithmetic (row16 "mixed": there is no fp32-arithmetic kernel); every n = 25 layout
  * (k <= 16, ndev <= 4) has a row16-class kernel; irlosc_kernel_class / irlosc_giveup_counts / irlosc_time_trains added;
  * only the irlosc_* symbols are exported.  _lib.py refuses a library whose version differs. */
-#define IRLOSC_ABI_VERSION 2
+#define IRLOSC_ABI_VERSION 3
 /* the entry points below are the ONLY dynamic symbols of libirlosc.so (built with -fvisibility=hidden) */
 #define IRLOSC_API __attribute__((visibility("default")))
 #define IRLOSC_MAX_DEV 4
@@ -104,8 +104,8 @@ typedef enum {
 #define IRLOSC_KERNEL_AUTO    0   /* fp64 ARITHMETIC always (the reference's, osc.py:49-55; meets 1e-5): row16 for every n = 25
                                      layout -- on float64 records and on float32 records alike -- else generic */
 #define IRLOSC_KERNEL_GENERIC 1   /* one wavefront per instance, LDS tiles, any n<=32, k<=16 */
-#define IRLOSC_KERNEL_GROUP   2   /* EXPLICIT OPT-IN ONLY, never picked by AUTO: fp32 records AND fp32 arithmetic, 4 lanes per
-                                     instance (n=25 shapes).  Error ~ eps32 * cond(J M^-1 J^T): does NOT meet the 1e-5 bar */
+#define IRLOSC_KERNEL_REMOVED_GROUP 2 /* (ABI versions 1-2: an fp32-ARITHMETIC kernel, error ~ eps32 * cond(J M^-1 J^T) -- 14 % of physical
+                                     instances missed the 1e-5 contract.  Removed in version 3: irlosc_create answers IRLOSC_ERR_ARG.) */
 #define IRLOSC_KERNEL_ROW16   3   /* fp64 arithmetic: 16 lanes (one DPP row) per instance, broadcast-FMA formulation (n = 25;
                                      instantiations for (k, ndev) = (13,3), (12,2), (7,3), (6,2), KMAX-padded variants for every
                                      other k <= 16, ndev <= 4: irlosc_kernel_class); float32 records = the "mixed" path */
@@ -146,7 +146,6 @@ IRLOSC_API const char* irlosc_kernel_name(const irlosc_ctx* ctx); /* name of the
 #define IRLOSC_CLASS_GENERIC      0
 #define IRLOSC_CLASS_ROW16        1
 #define IRLOSC_CLASS_ROW16_PADDED 2
-#define IRLOSC_CLASS_GROUP        3
 IRLOSC_API int irlosc_kernel_class(const irlosc_ctx* ctx);
 IRLOSC_API const char* irlosc_frontend_name(const irlosc_ctx* ctx); /* name of the kernel irlosc_frontend launches ("" before irlosc_set_model) */
 

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("IRLOSC_LIB", os.path.join(_HERE, "libirlosc.so"))   #
 MAX_DEV, MAX_N, MAX_K, GAIN_WORDS, MAX_BODIES = 4, 32, 16, 12, 64
 F32, F64 = 0, 1
 USE_G, ADMITTANCE, NULLSPACE = 1, 2, 4
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_GROUP, KERNEL_ROW16 = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_ROW16 = 0, 1, 3      # (2: the fp32-arithmetic kernel removed in ABI version 3)
 FLAG_M_NOT_PD, FLAG_PINV_BRANCH, FLAG_EIGEN_PATH, FLAG_TRUNCATED = 1, 2, 4, 8
 FLAG_VEL_BRANCH_B, FLAG_BAD_JIDX, FLAG_NONFINITE = 16, 32, 64
 
@@ -25,8 +25,8 @@ EXPORTS = ["irlosc_abi_version", "irlosc_device_count", "irlosc_create", "irlosc
            "irlosc_upload_q", "irlosc_frontend", "irlosc_step_resident_from_q", "irlosc_download_records",
            "irlosc_step_from_q", "irlosc_from_q_name", "irlosc_slot_structure", "irlosc_probe_structure", "irlosc_time_trains", "irlosc_giveup_counts",
            "irlosc_kernel_class"]
-ABI_VERSION = 2
-CLASS_GENERIC, CLASS_ROW16, CLASS_ROW16_PADDED, CLASS_GROUP = 0, 1, 2, 3
+ABI_VERSION = 3
+CLASS_GENERIC, CLASS_ROW16, CLASS_ROW16_PADDED = 0, 1, 2
 COMM_ID_BYTES = 128
 
 

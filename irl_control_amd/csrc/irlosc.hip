@@ -17,7 +17,6 @@
 #include "../../include/irlosc.h"
 #include "osc_common.hpp"
 #include "osc_generic.hpp"
-#include "osc_group.hpp"
 #include "osc_assemble.hpp"
 #include "osc_row16.hpp"
 #include "osc_frontend.hpp"
@@ -40,31 +39,18 @@ struct irlosc_ctx {
     std::vector<int> has_wrench, has_tvel;
     std::vector<int> uploaded, targeted;    // instances of the slot that hold state / targets (0 = nothing yet, -1 = an empty batch)
     std::vector<int> fused_away;            // 1: the slot's dense records were invalidated by a fused step from joint coordinates (error text only)
-    // Output sets (u, flags, stage-2 hand-off records, give-up list).  The group path chains up to TRAIN steps in
-    // one launch and the stage 2 of a train's steps rides in the NEXT train, so two trains' worth of sets exist;
-    // the generic path only ever uses set 0.
-    static constexpr int TRAIN_MAX = 16;
-    static constexpr int NSETS_MAX = 2 * TRAIN_MAX;
+    // Output sets (u, flags): step i of a row16 train writes set i; the generic path only ever uses set 0.
+    static constexpr int NSETS_MAX = R16_TRAIN;
     int nsets = 1;
     int train = 1;                     // steps per launch in irlosc_step_resident
     void* du_set[NSETS_MAX] = {};
     uint32_t* dflags_set[NSETS_MAX] = {};
-    float* dside_set[NSETS_MAX] = {};
-    int32_t* dwl_set[NSETS_MAX] = {};
-    int32_t* dwc_set[NSETS_MAX] = {};
-    static constexpr int NTABLES = 16;
-    void* dtable[NTABLES] = {};        // device copies of the train tables: a small content-addressed cache
-    std::vector<unsigned char> htable[NTABLES];   // (a resident loop repeats a handful of tables; no copy then)
-    int table_next = 0;
     int cur = 0;                       // output set written by the most recent step
-    int set_half = 0;                  // which half of the sets the next train of irlosc_step_resident writes
     hipEvent_t tev_begin = nullptr, tev_end = nullptr;   // timing events handed to the next train launch (or null)
     unsigned long long* dspan = nullptr;   // irlosc_time_trains: [ntrains][2] wall-clock stamps written by the kernels
     int dspan_cap = 0;
     unsigned long long* span_next = nullptr;   // the pair the next train launch stamps (or null)
     std::vector<hipEvent_t> tev_pool;
-    struct PendingStep { KParams<float> p; int set; int nfast; };
-    std::vector<PendingStep> pending;  // steps whose stage 2 has not run yet (it rides in the next train, or is flushed)
     void* du = nullptr;                // = du_set[cur]
     uint32_t* dflags = nullptr;        // = dflags_set[cur]
     void* draw = nullptr;     // staging for irlosc_upload_raw (raw simulator arrays), grown on demand
@@ -195,12 +181,7 @@ static void free_all(irlosc_ctx* c) {
     for (int k = 0; k < irlosc_ctx::NSETS_MAX; ++k) {
         if (c->du_set[k]) (void)hipFree(c->du_set[k]);
         if (c->dflags_set[k]) (void)hipFree(c->dflags_set[k]);
-        if (c->dside_set[k]) (void)hipFree(c->dside_set[k]);
-        if (c->dwl_set[k]) (void)hipFree(c->dwl_set[k]);
-        if (c->dwc_set[k]) (void)hipFree(c->dwc_set[k]);
     }
-    for (int k = 0; k < irlosc_ctx::NTABLES; ++k)
-        if (c->dtable[k]) (void)hipFree(c->dtable[k]);
     if (c->draw) (void)hipFree(c->draw);
     if (c->dmodel) (void)hipFree(c->dmodel);
     if (c->fe_side) (void)hipFree(c->fe_side);
@@ -258,10 +239,6 @@ static int create_impl(irlosc_ctx* c) {
     c->has_tvel.assign(g.n_slots, 0);
     c->uploaded.assign(g.n_slots, 0);
     c->targeted.assign(g.n_slots, 0);
-    if (c->kernel == IRLOSC_KERNEL_GROUP) {
-        c->train = 8;                       // 16 gains another ~1 % at twice the output-set memory
-        c->nsets = 2 * c->train;
-    }
     if (c->kernel == IRLOSC_KERNEL_ROW16) {
         c->train = R16_TRAIN;
         c->nsets = R16_TRAIN;               // a train completes (give-up pass included) before the next one starts
@@ -270,16 +247,7 @@ static int create_impl(irlosc_ctx* c) {
         HIPCHK(nullptr, hipMalloc(&c->du_set[k2], B * n * e));
         HIPCHK(nullptr, hipMalloc((void**)&c->dflags_set[k2], B * sizeof(uint32_t)));
         HIPCHK(nullptr, hipMemsetAsync(c->dflags_set[k2], 0, B * sizeof(uint32_t), c->stream));
-        if (c->kernel == IRLOSC_KERNEL_GROUP) {
-            HIPCHK(nullptr, hipMalloc((void**)&c->dwl_set[k2], B * sizeof(int32_t)));
-            HIPCHK(nullptr, hipMalloc((void**)&c->dwc_set[k2], 64 * sizeof(int32_t)));
-            HIPCHK(nullptr, hipMalloc((void**)&c->dside_set[k2], (B + 16 * 64) * 104 * sizeof(float)));
-            HIPCHK(nullptr, hipMemsetAsync(c->dwc_set[k2], 0, 64 * sizeof(int32_t), c->stream));
-        }
     }
-    if (c->kernel == IRLOSC_KERNEL_GROUP)
-        for (int t = 0; t < irlosc_ctx::NTABLES; ++t)
-            HIPCHK(nullptr, hipMalloc(&c->dtable[t], irlosc_ctx::TRAIN_MAX * sizeof(TrainStep)));
     if (c->kernel == IRLOSC_KERNEL_ROW16) {
         constexpr size_t ZB = 64 * 1024;
         HIPCHK(nullptr, hipMalloc(&c->dzeros, ZB));
@@ -311,9 +279,6 @@ static int create_impl(irlosc_ctx* c) {
     return IRLOSC_OK;
 }
 
-static bool group_supported(const irlosc_ctx* c) {
-    return group_kernel_supports(c->cfg.dtype, c->cfg.n, c->k, c->cfg.ndev);
-}
 static bool row16_supported(const irlosc_ctx* c) {
     return row16_kernel_supports(c->cfg.dtype, c->cfg.n, c->k, c->cfg.ndev);
 }
@@ -334,29 +299,28 @@ extern "C" int irlosc_create(const irlosc_cfg* cfg, irlosc_ctx** out) {
     c->cfg = *cfg;
     c->k = k;
     c->esz = cfg->dtype == IRLOSC_F64 ? 8 : 4;
-    if (cfg->kernel == IRLOSC_KERNEL_GROUP && !group_supported(c)) {
+    if (cfg->kernel == IRLOSC_KERNEL_REMOVED_GROUP) {
         delete c;
-        return fail(nullptr, IRLOSC_ERR_ARG, "group kernel not available for n=%d k=%d ndev=%d", cfg->n, k, cfg->ndev);
+        return fail(nullptr, IRLOSC_ERR_ARG, "kernel id 2 (the fp32-arithmetic group kernel of ABI versions 1-2) was removed in ABI version 3: its error is "
+                    "eps32 * cond(J M^-1 J^T), 14 %% of physical instances missed the 1e-5 contract; float32 RECORDS run on IRLOSC_KERNEL_AUTO (fp64 arithmetic)");
     }
     if (cfg->kernel == IRLOSC_KERNEL_ROW16 && !row16_supported(c)) {
         delete c;
         return fail(nullptr, IRLOSC_ERR_ARG, "row16 kernel not available for dtype=%d n=%d k=%d ndev=%d", cfg->dtype, cfg->n, k, cfg->ndev);
     }
-    // AUTO = the kernel that meets north_star's 1e-5: fp64 arithmetic.  The row16 kernel where the shape has one -- on float64
-    // records, and on float32 records too (the "mixed" path: fp32 storage, fp64 arithmetic) -- else the generic kernel.  The fp32
-    // group kernel (fp32 arithmetic: error ~ eps32 * cond(J M^-1 J^T), 14 % of physical instances over 1e-5) is never picked
-    // by AUTO; it runs on explicit request only (IRLOSC_KERNEL_GROUP).
+    // Every kernel computes in fp64 (the reference's arithmetic, and what north_star's 1e-5 needs).  AUTO = the row16 kernel where the
+    // shape has one -- on float64 records, and on float32 records too (the "mixed" path: fp32 storage, fp64 arithmetic) -- else the
+    // generic kernel.
     c->kernel = IRLOSC_KERNEL_GENERIC;
     if (cfg->kernel == IRLOSC_KERNEL_ROW16) c->kernel = IRLOSC_KERNEL_ROW16;
-    else if (cfg->kernel == IRLOSC_KERNEL_GROUP) c->kernel = IRLOSC_KERNEL_GROUP;
     else if (cfg->kernel == IRLOSC_KERNEL_AUTO && row16_supported(c)) c->kernel = IRLOSC_KERNEL_ROW16;
     char nm[96];
     const bool mixed = c->kernel == IRLOSC_KERNEL_ROW16 && cfg->dtype == IRLOSC_F32;
     snprintf(nm, sizeof nm, "%s_%s_n%d_k%d",
-             c->kernel == IRLOSC_KERNEL_GROUP ? "osc_group" : c->kernel == IRLOSC_KERNEL_ROW16 ? "osc_row16" : "osc_generic",
+             c->kernel == IRLOSC_KERNEL_ROW16 ? "osc_row16" : "osc_generic",
              mixed ? "f32in_f64" : cfg->dtype == IRLOSC_F64 ? "f64" : "f32", cfg->n, k);
     c->kernel_name = nm;
-    c->kernel_class = c->kernel == IRLOSC_KERNEL_GROUP ? IRLOSC_CLASS_GROUP : c->kernel == IRLOSC_KERNEL_GENERIC ? IRLOSC_CLASS_GENERIC
+    c->kernel_class = c->kernel == IRLOSC_KERNEL_GENERIC ? IRLOSC_CLASS_GENERIC
                       : row16_kernel_exact(cfg->n, k, cfg->ndev) ? IRLOSC_CLASS_ROW16 : IRLOSC_CLASS_ROW16_PADDED;
     if (c->kernel_class == IRLOSC_CLASS_ROW16_PADDED) {      // the tier the launches will pick (tu_row16_pad_impl.hpp)
         snprintf(nm, sizeof nm, "_ndev%d_pad%d", cfg->ndev, row16_pad_tier(k));
@@ -693,90 +657,6 @@ static void fill_params(const irlosc_ctx* c, KParams<T>& p, int B, const void* M
     }
 }
 
-// One fused launch for a train of `n` steps (ps[i] = parameters with the outputs of set sets[i]); the stage 2 of
-// the steps in c->pending rides in front of them.  n == 0: riders only (a flush).  With keep_pending the new steps'
-// stage 2 is left for the next train; otherwise it is flushed right away.
-static int group_train(irlosc_ctx* c, const KParams<float>* ps, const int* sets, int n, hipStream_t st, bool keep_pending) {
-    const int side_cap = c->cfg.max_batch + 16 * 64;
-    const int entries = std::max(n, (int)c->pending.size());
-    if (entries == 0) return IRLOSC_OK;
-    if (entries > irlosc_ctx::TRAIN_MAX) return fail(c, IRLOSC_ERR_STATE, "train of %d entries", entries);
-    std::vector<TrainStep> tab(entries);
-    std::vector<irlosc_ctx::PendingStep> fresh;
-    int acc = 0;
-    bool riders = false;
-    for (int i = 0; i < entries; ++i) {
-        TrainStep& e = tab[i];
-        memset(&e, 0, sizeof e);
-        int tiles = 0;
-        if (i < n) {
-            e.p = ps[i];
-            e.side = c->dside_set[sets[i]];
-            e.giveup_count = c->dwc_set[sets[i]];
-            tiles = ps[i].B / GROUP_TILE;
-            if (tiles > 0) fresh.push_back({ps[i], sets[i], tiles * GROUP_TILE});
-        }
-        e.side_cap = side_cap;
-        if (i < (int)c->pending.size()) {
-            const irlosc_ctx::PendingStep& q = c->pending[i];
-            for (int j = 0; j < n; ++j)
-                if (sets[j] == q.set) return fail(c, IRLOSC_ERR_STATE, "output set %d reused before its stage 2 ran", q.set);
-            e.prev.J = q.p.J; e.prev.u = q.p.u; e.prev.flags = q.p.flags; e.prev.nfast = q.nfast;   // field by field: the
-            e.prev.side = c->dside_set[q.set]; e.prev.side_cap = side_cap;                         // padding stays zero, so
-            e.prev.worklist2 = c->dwl_set[q.set]; e.prev.workcount2 = c->dwc_set[q.set];           // equal tables compare equal
-            e.prev_p = q.p;
-            e.prev_p.index = nullptr;
-            e.n2 = (q.nfast + S2_SPAN - 1) / S2_SPAN;
-            riders = true;
-        }
-        e.block0 = acc;
-        acc += e.n2 + tiles;
-    }
-    if (acc > 0) {
-    // Device copy of the table.  A resident loop keeps producing the same few tables, so the last NTABLES ones are
-    // kept and reused by content; a miss overwrites the oldest (stream order keeps that safe on one stream).
-    TrainStep* dt = nullptr;
-    const size_t tbytes = entries * sizeof(TrainStep);
-    for (int t = 0; t < irlosc_ctx::NTABLES && !dt; ++t)
-        if (c->htable[t].size() == tbytes && memcmp(c->htable[t].data(), tab.data(), tbytes) == 0) dt = (TrainStep*)c->dtable[t];
-    if (!dt || st != c->stream) {
-        const int t = c->table_next;
-        c->table_next = (c->table_next + 1) % irlosc_ctx::NTABLES;
-        dt = (TrainStep*)c->dtable[t];
-        c->htable[t].assign((const unsigned char*)tab.data(), (const unsigned char*)tab.data() + tbytes);
-        HIPCHK(c, hipMemcpyAsync(dt, c->htable[t].data(), tbytes, hipMemcpyHostToDevice, st));
-    }
-    if (c->tev_begin) HIPCHK(c, hipEventRecord(c->tev_begin, st));
-    int rc = launch_group_train(dt, entries, acc, c->k, c->cfg.ndev, st);
-    if (rc) return fail(c, IRLOSC_ERR_HIP, "group kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-    if (c->tev_end) HIPCHK(c, hipEventRecord(c->tev_end, st));
-    if (riders) {     // give-up lists of the steps whose stage 2 just ran (normally empty: 16 idle blocks per step)
-        rc = launch_giveup_lists(dt, entries, c->cfg.n, c->k, c->cfg.ndev, st);
-        if (rc) return fail(c, IRLOSC_ERR_HIP, "give-up kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-    }
-    }   // acc > 0 (a batch smaller than one tile is all ragged tail: nothing to launch here)
-    for (int i = 0; i < n; ++i) {   // ragged tail (< 16 instances): generic kernel on the last instances
-        const int nfast = (ps[i].B / GROUP_TILE) * GROUP_TILE, rem = ps[i].B - nfast;
-        if (rem > 0) {
-            KParams<float> pt = ps[i];
-            pt.index = nullptr;
-            pt.b0 = nfast;
-            HIPCHK(c, (hipError_t)launch_generic<float>(pt, rem, st));
-        }
-    }
-    c->pending = fresh;
-    if (!keep_pending && !c->pending.empty()) return group_train(c, nullptr, nullptr, 0, st, false);
-    return IRLOSC_OK;
-}
-static int flush_pending(irlosc_ctx* c, hipStream_t st) {
-    if (c->pending.empty()) return IRLOSC_OK;
-    hipEvent_t b = c->tev_begin, e = c->tev_end;      // a flush is never the timed launch
-    c->tev_begin = c->tev_end = nullptr;
-    int rc = group_train(c, nullptr, nullptr, 0, st, false);
-    c->tev_begin = b; c->tev_end = e;
-    return rc;
-}
-
 // fp64-arithmetic path: one launch for a train of n steps (ps[i] complete with its own outputs), whatever the storage
 // type T of the records.  All instances run on the row16 kernel, the truncated pseudo-inverse included; the few it gives
 // up on (net of eigen-candidates full, degenerate A) are recomputed by the generic kernel (Jacobi, fp64 arithmetic) from
@@ -810,16 +690,6 @@ static int launch_t(irlosc_ctx* c, int B, const void* M, const void* J, const vo
                     uint32_t* flags, hipStream_t st, bool tree) {
     KParams<T> p;
     fill_params<T>(c, p, B, M, J, dq, bias, ee, tgt, tvel, wrench, u, flags);
-    if (c->kernel == IRLOSC_KERNEL_GROUP) {
-        if constexpr (sizeof(T) == 4) {
-            int rc = flush_pending(c, st);
-            if (rc) return rc;
-            const int set = c->cur;           // hand-off buffers of the current set (u / flags may be the caller's)
-            return group_train(c, &p, &set, 1, st, false);
-        } else {
-            return fail(c, IRLOSC_ERR_ARG, "no fp64 group kernel");
-        }
-    }
     if (c->kernel == IRLOSC_KERNEL_ROW16) return row16_train<T>(c, &p, 1, tree, st);
     HIPCHK(c, (hipError_t)launch_generic<T>(p, B, st));
     return IRLOSC_OK;
@@ -913,44 +783,6 @@ extern "C" int irlosc_step(irlosc_ctx* c, int32_t slot, int32_t B, void* u_host,
     return IRLOSC_OK;
 }
 
-// Parameters of the step on resident slot `slot` with the outputs of set `set`.
-static void slot_params(const irlosc_ctx* c, KParams<float>& p, int slot, int B, int set) {
-    fill_params<float>(c, p, B, c->dM[slot], c->dJ[slot], c->ddq[slot], c->dbias[slot], c->dee[slot], c->dtgt[slot],
-                       c->has_tvel[slot] ? c->dtvel[slot] : nullptr, c->has_wrench[slot] ? c->dwrench[slot] : nullptr,
-                       c->du_set[set], c->dflags_set[set]);
-}
-
-// `iters` steps on the group path, chained `train` per launch; events (if any) go around launch number `timed`.
-static int resident_trains(irlosc_ctx* c, int first_slot, int B, int iters, const std::vector<hipEvent_t>* evs, int skip) {
-    int done = 0, launch_no = 0;
-    while (done < iters) {
-        const int n = std::min(c->train, iters - done);
-        KParams<float> ps[irlosc_ctx::TRAIN_MAX];
-        int sets[irlosc_ctx::TRAIN_MAX];
-        for (int i = 0; i < n; ++i) {
-            const int slot = (first_slot + done + i) % c->cfg.n_slots;
-            int rcf = check_slot_filled(c, slot, B);
-            if (rcf) return rcf;
-            sets[i] = c->set_half * c->train + i;
-            slot_params(c, ps[i], slot, B, sets[i]);
-        }
-        if (evs && launch_no >= skip && 2 * (launch_no - skip) + 1 < (int)evs->size()) {
-            c->tev_begin = (*evs)[2 * (launch_no - skip)];
-            c->tev_end = (*evs)[2 * (launch_no - skip) + 1];
-        }
-        int rc = group_train(c, ps, sets, n, c->stream, true);
-        c->tev_begin = c->tev_end = nullptr;
-        if (rc) return rc;
-        c->cur = sets[n - 1];
-        c->set_half ^= 1;
-        done += n;
-        ++launch_no;
-    }
-    c->du = c->du_set[c->cur];
-    c->dflags = c->dflags_set[c->cur];
-    return flush_pending(c, c->stream);
-}
-
 // `iters` steps on the row16 path, chained R16_TRAIN per launch (step i of a train writes output set i); events (if any)
 // go around the launches from number `skip` on.  One kernel per launch, so a train whose slots do not ALL qualify for the
 // tree-structured form is issued as two sub-trains -- the qualifying steps with the tree kernel, the others with the dense
@@ -1003,13 +835,7 @@ extern "C" int irlosc_step_resident(irlosc_ctx* c, int32_t first_slot, int32_t B
     if (c->gains_nb == 0) return fail(c, IRLOSC_ERR_STATE, "irlosc_set_gains has not been called");
     HIPCHK(c, hipSetDevice(c->cfg.hip_device));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    if (c->kernel == IRLOSC_KERNEL_GROUP && B > 0) {
-        // Group path: up to `train` consecutive steps are chained in one launch (different resident slots, different
-        // output sets), and their stage 2 rides in the next launch; the last train is flushed before returning.
-        rc = flush_pending(c, c->stream);
-        if (!rc) rc = resident_trains(c, first_slot, B, iters, nullptr, 0);
-        if (rc) return rc;
-    } else if (c->kernel == IRLOSC_KERNEL_ROW16 && B > 0) {
+    if (c->kernel == IRLOSC_KERNEL_ROW16 && B > 0) {
         rc = c->cfg.dtype == IRLOSC_F64 ? row16_resident<double>(c, first_slot, B, iters, nullptr, 0)
                                         : row16_resident<float>(c, first_slot, B, iters, nullptr, 0);
         if (rc) return rc;
@@ -1044,10 +870,9 @@ extern "C" int irlosc_time_dominant_kernel(irlosc_ctx* c, int32_t slot, int32_t 
         rc = irlosc_step_resident(c, slot, B, iters, &tot, ms_avg);
         return rc;
     }
-    // Group path: the same chained launches as irlosc_step_resident, with a HIP event pair around each dominant
-    // launch (a train of irlosc_steps_per_launch() steps' stage 1, fused with the riding stage 2 of the previous
-    // train) - this is the kernel a rocprofv3 kernel trace of the timed region shows, so the two averages are
-    // comparable.  The first launch is not timed (nothing rides in it yet).
+    // row16 path: the same chained launches as irlosc_step_resident, with a HIP event pair around each train (task pass + row16 kernel +
+    // give-up pass) -- what a rocprofv3 kernel trace of the timed region shows, so the two averages are comparable.  The first launch is
+    // not timed.
     if (c->gains_nb == 0) return fail(c, IRLOSC_ERR_STATE, "irlosc_set_gains has not been called");
     const int launches = std::max(1, iters / c->train);
     while ((int)c->tev_pool.size() < 2 * launches) {
@@ -1056,13 +881,8 @@ extern "C" int irlosc_time_dominant_kernel(irlosc_ctx* c, int32_t slot, int32_t 
         c->tev_pool.push_back(ev);
     }
     std::vector<hipEvent_t> evs(c->tev_pool.begin(), c->tev_pool.begin() + 2 * launches);
-    if (c->kernel == IRLOSC_KERNEL_ROW16) {       // row16 path: a train of steps + its give-up pass per launch pair
-        rc = c->cfg.dtype == IRLOSC_F64 ? row16_resident<double>(c, slot, B, (launches + 1) * c->train, &evs, 1)
-                                        : row16_resident<float>(c, slot, B, (launches + 1) * c->train, &evs, 1);
-    } else {
-        rc = flush_pending(c, c->stream);
-        if (!rc) rc = resident_trains(c, slot, B, (launches + 1) * c->train, &evs, 1);
-    }
+    rc = c->cfg.dtype == IRLOSC_F64 ? row16_resident<double>(c, slot, B, (launches + 1) * c->train, &evs, 1)
+                                    : row16_resident<float>(c, slot, B, (launches + 1) * c->train, &evs, 1);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     double tot = 0.0;
@@ -1465,7 +1285,8 @@ static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, hipStream_
                                         : launch_frontend_lane_compact_dual_ur5(c->dmodel, ft, n, st)));
     if (use_lane) {
         HIPCHK(c, (hipError_t)launch_row16_fromq<T>(tr, n, st, 1));                 // the task pass
-        HIPCHK(c, (hipError_t)launch_lane_osc<T>(tr, lt, n, c->lane_tier, 1024, st));
+        static const int eig_blocks = [] { const char* e = getenv("IRLOSC_LANE_EIG_BLOCKS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 65536 ? v : 1024; }();
+        HIPCHK(c, (hipError_t)launch_lane_osc<T>(tr, lt, n, c->lane_tier, eig_blocks, st));
     } else {
         HIPCHK(c, (hipError_t)launch_row16_fromq<T>(tr, n, st));
     }

@@ -7,11 +7,6 @@
 
 namespace irlosc {
 
-// tu_group.hip -- fp32 group path (osc_group.hpp, osc_group_stage1.hpp)
-struct TrainStep;
-int launch_group_train(const TrainStep* dtable, int nsteps, int total_blocks, int k, int ndev, hipStream_t st);
-int launch_giveup_lists(const TrainStep* dtable, int nsteps, int n, int k, int ndev, hipStream_t st);
-
 // tu_generic.hip -- one wavefront per instance (osc_generic.hpp); T = float, double
 template <typename T>
 int launch_generic(const KParams<T>& p, int blocks, hipStream_t st);

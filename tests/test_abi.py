@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for nm in names:
         assert hasattr(lib, nm), nm
     assert sorted(names) == sorted(_lib.EXPORTS)
-    assert lib.irlosc_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.irlosc_abi_version() == _lib.ABI_VERSION == 3
     hdr = open(os.path.join(ROOT, "include", "irlosc.h")).read()
     assert f"#define IRLOSC_ABI_VERSION {_lib.ABI_VERSION}" in hdr
 

@@ -23,7 +23,7 @@ def test_baseline_config_names():
     assert bench.baseline_config_of("k13", 65536, 1, "f64").startswith("BASELINE configs[2]")
     assert bench.baseline_config_of("k13", 32768, 8, "f64") == "BASELINE configs[3]"
     assert bench.baseline_config_of("k13", 4096, 1, "f64") == "BASELINE configs[1]"
-    assert bench.baseline_config_of("k12_admit", 65536, 1, "f32") == "BASELINE configs[4]"
+    assert bench.baseline_config_of("k12_admit", 65536, 1, "mixed") == "BASELINE configs[4]"
     assert bench.baseline_config_of("k7", 100, 1, "f64") == "no BASELINE config"
 
 

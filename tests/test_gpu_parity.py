@@ -157,31 +157,6 @@ def test_row16_stress_eigenvalues_all_around_the_cut(cfg):
             assert not in_parity_domain(Mxi, det), (gname, b, e)
 
 
-@pytest.mark.parametrize("cfg", ["k13", "k7", "k12_admit"])
-def test_fp32_vs_oracle_on_fp32_inputs(cfg):
-    """float32-ARITHMETIC group kernel: the FASTEST path, which does NOT meet north_star's 1e-5 (what answers BASELINE
-    configs[2]'s float32 storage at that bar is the mixed path, float32 records on the fp64 row16 kernel:
-    test_mixed_path_meets_1e5_on_fp32_rounded_goldens, test_row16_vs_oracle_flat_1e5[float32]).  Compared with the float64
-    oracle evaluated on the SAME float32-rounded inputs, so what is measured is the kernel's arithmetic, not input
-    rounding: the error scales like eps32 * cond(Mx_inv) and the synthetic batch has cond up to 1e5.  Gate: instances
-    with cond(Mx_inv) <= 1e3 within 2e-3, median within 5e-4."""
-    B = 1024
-    lay, gains, g = synth.make_batch(cfg, B, seed=99)
-    g32 = {k: (v.astype(np.float32).astype(np.float64) if isinstance(v, np.ndarray) else v) for k, v in g.items()}
-    u, fl, kname = run_gpu(lay, gains, g32, np.float32, _lib.KERNEL_GROUP)
-    assert "group" in kname
-    idx = np.arange(0, B, 4)
-    ref = osc_oracle.generate_batch(lay.as_oracle_dict(), gains, g32["M"], g32["J"], g32["dq"], g32["bias"],
-                                    g32["ee_pose"], g32["tgt_pose"], g32.get("wrench"), g32.get("tgt_vel"), idx=idx)
-    cond = np.array([np.linalg.cond(osc_oracle.task_inertia(g32["J"][b], g32["M"][b])[2]) for b in idx])
-    err = rel_err(u[idx], ref[idx])
-    well = cond <= 1e3
-    assert well.sum() > 20
-    print(f"{kname}: fp32 rel err median {np.median(err):.2e}, max(cond<=1e3) {err[well].max():.2e}, max {err.max():.2e}")
-    assert err[well].max() <= 2e-3
-    assert np.median(err) <= 5e-4
-
-
 def test_per_instance_gains_and_branch_b_batch():
     lay, gains, g = synth.make_batch("k13_branch_b", 512, seed=5, per_instance_gains=True)
     u, fl, _ = run_gpu(lay, gains, g, np.float64)
@@ -347,109 +322,17 @@ def lay_admit(cfg):
 
 
 # ------------------------------------------------------------------------------------------------
-# Throughput (group) path specifics
-# ------------------------------------------------------------------------------------------------
-# k13_gimbal is deliberately absent: within 1e-5 rad of gimbal lock the sxyz angles are computed from matrix
-# entries of size ~1e-7, below float32 resolution; that fixture is an fp64 test (test_fp64_matches_reference_outputs).
-@pytest.mark.parametrize("name", ["k13_xyz_abg", "k13_pinv_regime", "k12_admittance", "k7_gain_test"])
-def test_fp32_group_path_on_reference_goldens(name):
-    """The fp32 two-stage group path on the reference-minted fixtures (32 or fewer instances, so this
-    also exercises the ragged-tail hand-over to the generic kernel).  Tolerance scales with
-    eps32 * cond(Mx_inv); instances whose smallest singular value sits within 30 % of the pinv cut are
-    excluded (fp32 cannot resolve that decision), as are those outside the fp64 parity domain."""
-    g = load_golden(name)
-    lay = OSCLayout.from_dict(g["layout"])
-    g32 = {k: (v.astype(np.float32).astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float64 else v)
-           for k, v in g.items()}
-    u, fl, kname = run_gpu(lay, golden_gains(g), g32, np.float32, _lib.KERNEL_GROUP)
-    assert "group" in kname
-    ref = osc_oracle.generate_batch(g["layout"], golden_gains(g), g32["M"], g32["J"], g32["dq"], g32["bias"],
-                                    g32["ee_pose"], g32["tgt_pose"], g32["wrench"], g32["tgt_vel"])
-    ok, tol = [], []
-    for b in range(g["M"].shape[0]):
-        Mx, Minv, Mxi, det = osc_oracle.task_inertia(g32["J"][b], g32["M"][b])
-        s = np.linalg.svd(Mxi, compute_uv=False)
-        r = s / s[0]
-        near_cut = abs(det) < 1e-4 and np.any(np.abs(r / 1e-5 - 1.0) < 0.3)
-        ok.append(in_parity_domain(Mxi, det) and not near_cut)
-        kept = r[r > 1e-5] if abs(det) < 1e-4 else r
-        tol.append(max(2e-4, 4e-6 / kept.min()))          # ~ 30 * eps32 * effective condition number
-    ok, tol = np.array(ok), np.array(tol)
-    err = rel_err(u, ref)
-    assert ok.sum() >= 0.6 * len(ok)
-    assert np.all(err[ok] <= np.minimum(tol[ok], 0.5)), (kname, name, float((err[ok] / tol[ok]).max()))
-    assert not np.any(fl & _lib.FLAG_NONFINITE)
-    # fp32 branch decisions (osc.py:52): the PINV flag must agree with the reference's det test outside a band around
-    # the 1e-4 threshold (the fp32 product of k pivots carries ~k * eps32 * cond of relative error)
-    det = np.array([osc_oracle.task_inertia(g32["J"][b], g32["M"][b])[3] for b in range(g["M"].shape[0])])
-    clear = ok & ((np.abs(det) < 0.5e-4) | (np.abs(det) > 2e-4))
-    assert np.array_equal((fl[clear] & _lib.FLAG_PINV_BRANCH) != 0, np.abs(det[clear]) < 1e-4)
-
-
-def test_fp32_group_path_has_no_gross_errors_beyond_the_straddling_pairs():
-    """The opt-in fp32-ARITHMETIC group kernel (IRLOSC_KERNEL_GROUP, bench --with-f32; AUTO never picks it) keeps its regression
-    guard: float32 arithmetic cannot meet 1e-5 (error ~ eps32 * cond), but it must take the reference's BRANCH
-    wherever float32 can tell -- the bench batch against the generic kernel in float64 on the same rounded records, errors over
-    0.1 counted outside a 5 % band around the pinv cut (and around the |det| = 1e-4 switch).  What is left are pairs of
-    eigenvalues straddling the cut within ~35 %: 4 per 65 536."""
-    B = 65536
-    lay, gains, g = synth.make_batch("k13", B, seed=777000, dtype=np.float32)
-    g64 = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in g.items()}
-    u, fl, kname = run_gpu(lay, gains, g, np.float32, kernel=_lib.KERNEL_GROUP)
-    ug, flg, gname = run_gpu(lay, gains, g64, np.float64, kernel=_lib.KERNEL_GENERIC)
-    assert "group" in kname and "generic_f64" in gname
-    err = rel_err(u.astype(np.float64), ug)
-    n_in = 0
-    for b in np.nonzero(~(err <= 0.1))[0]:
-        Mx, Minv, Mxi, det = osc_oracle.task_inertia(g64["J"][b], g64["M"][b])
-        s = np.linalg.svd(Mxi, compute_uv=False)
-        near = np.any(np.abs(s / s[0] / 1e-5 - 1.0) < 0.05) or 0.5e-4 < abs(det) < 2e-4
-        n_in += not near
-    assert n_in <= 10, n_in
-    assert np.median(err) < 1e-4
-
-
-@pytest.mark.parametrize("B", [1, 15, 16, 17, 33, 100])
-def test_group_path_ragged_batches(B):
-    """Batch sizes around the 16-instance tile: full tiles go to the group kernel, the tail to the generic
-    kernel; every instance must equal what a large batch gives for the same data (bit-identical for the
-    tile part because a tile's result does not depend on its neighbours)."""
-    lay, gains, g = synth.make_batch("k13", 256, seed=21, dtype=np.float32)
-    full, _, _ = run_gpu(lay, gains, g, np.float32, _lib.KERNEL_GROUP)
-    sub = {k: (v[:B] if isinstance(v, np.ndarray) else v) for k, v in g.items()}
-    part, fl, _ = run_gpu(lay, gains, sub, np.float32, _lib.KERNEL_GROUP)
-    nt = (B // 16) * 16
-    assert np.array_equal(part[:nt], full[:nt])
-    if B > nt:          # tail instances: generic kernel, same math in another order
-        d = np.abs(part[nt:] - full[nt:B]).max(axis=1) / np.abs(full[nt:B]).max(axis=1)
-        assert np.all(np.isfinite(part[nt:])) and np.median(d) < 1e-3
-
-
-def test_group_vs_generic_fp32_kernels_agree():
-    lay, gains, g = synth.make_batch("k13", 2048, seed=5, dtype=np.float32)
-    ug, fg, ng = run_gpu(lay, gains, g, np.float32, _lib.KERNEL_GROUP)
-    ue, fe, ne = run_gpu(lay, gains, g, np.float32, _lib.KERNEL_GENERIC)
-    assert "group" in ng and "generic" in ne
-    d = np.abs(ug - ue).max(axis=1) / np.abs(ue).max(axis=1)
-    assert np.median(d) < 1e-4
-    # both must flag the same M / pinv-branch status on all but borderline instances
-    same = ((fg ^ fe) & (_lib.FLAG_M_NOT_PD | _lib.FLAG_PINV_BRANCH)) == 0
-    assert same.mean() > 0.995
-    # truncation decisions agree except within the fp32 resolution band of the cut
-    assert (((fg ^ fe) & _lib.FLAG_TRUNCATED) != 0).mean() < 0.02
-
-
-@pytest.mark.parametrize("dtype,kernel", [(np.float32, _lib.KERNEL_GROUP), (np.float32, _lib.KERNEL_AUTO), (np.float64, _lib.KERNEL_AUTO)])
+@pytest.mark.parametrize("dtype,kernel", [(np.float32, _lib.KERNEL_AUTO), (np.float64, _lib.KERNEL_AUTO)])
 @pytest.mark.parametrize("iters", [1, 2, 7, 8, 9, 17, 24])
 def test_step_resident_trains_equal_single_steps(iters, dtype, kernel):
-    """irlosc_step_resident chains several steps (8) per launch on both throughput paths (fp32 group: the eigen-path stage
-    rides in the next launch; fp64 row16: blockIdx.y = step, one give-up pass per train); whatever the train split, the
+    """irlosc_step_resident chains several steps (8) per launch on the row16 path (blockIdx.y = step, one give-up pass per train),
+    float64 and float32 records; whatever the train split, the
     outputs left behind are bit-for-bit those of a plain single step on the last slot visited (n_slots = 3 distinct
     batches, truncation-heavy data so that the eigen stage has work in every step)."""
     nslots, B = 3, 1024 + 16
     lay = synth.make_layout("k13")
     osc = BatchedOSC(lay, B, dtype=dtype, n_slots=nslots, kernel=kernel)
-    assert ("group" if kernel == _lib.KERNEL_GROUP else "row16") in osc.kernel_name      # AUTO: fp64 arithmetic on either record type
+    assert "row16" in osc.kernel_name      # AUTO: fp64 arithmetic on either record type
     batches = []
     for sl in range(nslots):
         _, gains, g = synth.make_batch("k13", B, seed=100 + sl, dtype=dtype)
@@ -477,21 +360,6 @@ def test_step_resident_trains_equal_single_steps(iters, dtype, kernel):
     osc.close()
 
 
-def test_stage2_many_flagged_per_span():
-    """Every instance rank-deficient by one (a duplicated Jacobian row): all 384 instances of a stage-2 span are
-    flagged, so a stage-2 block needs several rounds of 64; the truncated solve must agree with the generic kernel."""
-    B = 1024
-    lay, gains, g = synth.make_batch("k13", B, seed=71, dtype=np.float32)
-    g["J"][:, 12] = g["J"][:, 0] * np.float32(1.0)
-    g["J"][:, 7] = g["J"][:, 3]
-    ref, fref, _ = run_gpu(lay, gains, g, np.float32, _lib.KERNEL_GENERIC)
-    u, fl, name = run_gpu(lay, gains, g, np.float32, _lib.KERNEL_GROUP)
-    assert "group" in name
-    assert np.all(fl & _lib.FLAG_EIGEN_PATH) and np.all(fl & _lib.FLAG_TRUNCATED) and np.all(fref & _lib.FLAG_TRUNCATED)
-    d = np.abs(u - ref).max(axis=1) / np.abs(ref).max(axis=1)
-    assert np.all(np.isfinite(u)) and np.median(d) < 1e-3 and np.quantile(d, 0.95) < 5e-2, (float(np.median(d)), float(d.max()))
-
-
 def test_give_up_instances_inside_trains():
     """Instances whose task Jacobian loses FIVE ranks exceed what stage 2 deflates (three vectors): they must come out
     of the give-up list -> generic kernel path also when steps are chained in trains, and agree with the generic kernel
@@ -501,7 +369,7 @@ def test_give_up_instances_inside_trains():
     bad = np.arange(0, B, 9)
     g["J"][bad, 8:13] = g["J"][bad, 0:5]                       # rows 8..12 duplicate rows 0..4: rank k - 5
     ref, fref, _ = run_gpu(lay, gains, g, np.float32, _lib.KERNEL_GENERIC)
-    osc = BatchedOSC(lay, B, dtype=np.float32, n_slots=2, kernel=_lib.KERNEL_GROUP)
+    osc = BatchedOSC(lay, B, dtype=np.float32, n_slots=2, kernel=_lib.KERNEL_AUTO)
     osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
     for sl in range(2):
         osc.upload(g["M"], g["J"], g["dq"], g["bias"], g["ee_pose"], g.get("wrench"), slot=sl)
@@ -509,7 +377,7 @@ def test_give_up_instances_inside_trains():
     osc.step_resident(11)
     u, fl = osc.download(B)
     osc.close()
-    assert "group" in osc.kernel_name or True
+    assert "row16" in osc.kernel_name
     assert np.all(fl[bad] & _lib.FLAG_TRUNCATED) and np.all(fref[bad] & _lib.FLAG_TRUNCATED)
     assert np.all(np.isfinite(u[bad]))
     d = np.abs(u[bad].astype(np.float64) - ref[bad]).max(axis=1) / np.abs(ref[bad]).max(axis=1)
@@ -736,8 +604,8 @@ def test_call_order_and_argument_errors():
         osc.step()
     with pytest.raises(ValueError):
         osc.upload(g["M"][:, :24], g["J"], g["dq"], g["bias"], g["ee_pose"])      # wrong shape
-    with pytest.raises(_lib.IrloscError):
-        BatchedOSC(lay, 32, dtype=np.float64, kernel=_lib.KERNEL_GROUP)            # no fp64 group kernel
+    with pytest.raises(_lib.IrloscError, match="removed in ABI version 3"):
+        BatchedOSC(lay, 32, dtype=np.float32, kernel=2)            # the fp32-ARITHMETIC kernel of ABI versions 1-2: gone (it missed 1e-5)
     osc.close()
 
 
@@ -1378,7 +1246,7 @@ def test_step_refuses_more_instances_than_the_slot_holds():
     osc.close()
 
 
-@pytest.mark.parametrize("dtype,kernel", [(np.float64, _lib.KERNEL_AUTO), (np.float32, _lib.KERNEL_AUTO), (np.float32, _lib.KERNEL_GROUP)])
+@pytest.mark.parametrize("dtype,kernel", [(np.float64, _lib.KERNEL_AUTO), (np.float32, _lib.KERNEL_AUTO)])
 def test_library_refuses_an_asymmetric_M_on_the_throughput_paths(dtype, kernel):
     """The throughput kernels read row j of M as column j; the reference uses M as given (osc.py:49,151).  Records that
     come from the host are probed ON THE DEVICE (irlosc_upload, irlosc_tick): an asymmetric M is IRLOSC_ERR_ARG naming the
@@ -1407,8 +1275,7 @@ def test_library_refuses_an_asymmetric_M_on_the_throughput_paths(dtype, kernel):
     with pytest.raises(_lib.IrloscError, match="M of instance 3 is not symmetric"):
         osc.upload(Masym[sl], g["J"][sl], g["dq"][sl], g["bias"][sl], g["ee_pose"][sl])
     u6 = osc.tick(g["M"][sl], g["J"][sl], g["dq"][sl], g["bias"][sl], g["ee_pose"][sl], g["tgt_pose"][sl])
-    if "row16" in osc.kernel_name:                     # (a fp32 group batch under 16 instances runs on the generic kernel)
-        assert np.array_equal(u6, u[sl])
+    assert np.array_equal(u6, u[sl])
     assert np.all(np.isfinite(u6))
     osc.close()
     gen = BatchedOSC(lay, B, dtype=dtype, kernel=_lib.KERNEL_GENERIC)
