@@ -37,7 +37,7 @@ from irl_control_amd import fakesim  # noqa: E402
 
 assert ref.__file__.startswith("/root/reference"), ref.__file__
 CFG_DIR = os.path.join(ROOT, "irl_control_amd", "robot_configs")
-OUT_DIR = os.path.join(ROOT, "tests", "golden")
+OUT_DIR = os.environ.get("IRLOSC_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")      # (another directory: tests/test_golden_remint.py)
 
 
 def load_cfg(name):
@@ -557,7 +557,9 @@ def make_teleop_golden(name, kind, seed, ticks, rate=0.08, button_every=4):
         state["stop"] = True
         go.release()
     # cross-check of the headless counterpart's LOGIC: examples/teleop_loops.py driven with the reference's classes on the same
-    # set-up must reproduce the reference's own loop bit for bit (the GPU tests then swap in the HIP path)
+    # set-up must reproduce the reference's own loop (the GPU tests then swap in the HIP path) -- to rounding, not bit for bit: the
+    # reference's loop body computes its rotations through oracle/shims/transforms3d (SciPy), the headless counterpart through the
+    # product's own restatement (irl_control_amd/transforms.py); a LOGIC slip (a trigger, a mask, a waypoint) moves ctrl by O(1)
     dyn2 = fakesim.ToyDynamics(rate=rate)
     sim2 = fakesim.randomize(fakesim.FakeSim(dynamics=dyn2, mocap_names=mocaps), np.random.default_rng(seed))
     robot2, osc2 = build_reference(load_cfg("default_xyz_abg.yaml"), sim2, G_TELEOP, True, True, False)
@@ -577,7 +579,7 @@ def make_teleop_golden(name, kind, seed, ticks, rate=0.08, button_every=4):
                                advance=lambda t: tl.apply_script_row(ms, script2[t + 1]), button_every=button_every)
     _d = np.abs(mine["ctrl"] - np.asarray(rec["ctrl"]))
     print("   self-check:", _d.max(), "first tick differing:", int(np.argmax(_d.max(axis=1) > 0)), "cols", np.nonzero(_d.max(axis=0) > 0)[0])
-    assert np.array_equal(mine["ctrl"], np.asarray(rec["ctrl"])), "examples/teleop_loops.py does not reproduce the reference's loop"
+    assert _d.max() <= 1e-9 * max(1.0, float(np.abs(np.asarray(rec["ctrl"])).max())), "examples/teleop_loops.py does not reproduce the reference's loop"
     meta = dict(kind=kind, seed=seed, ticks=ticks, rate=rate, button_every=button_every, mocaps=list(mocaps))
     arrays = dict(ctrl=np.asarray(rec["ctrl"]), layout_json=np.array(json.dumps(meta)))
     path = os.path.join(OUT_DIR, f"{name}.npz")

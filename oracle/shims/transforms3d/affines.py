@@ -1,1 +1,1 @@
-from irl_control_amd.transforms import compose  # noqa: F401
+from ._impl import compose  # noqa: F401

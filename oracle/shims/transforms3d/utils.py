@@ -1,1 +1,1 @@
-from irl_control_amd.transforms import normalized_vector  # noqa: F401
+from ._impl import normalized_vector  # noqa: F401
