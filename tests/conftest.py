@@ -165,3 +165,72 @@ class HipBuffers:
         for p in self._ptrs:
             self.hip.hipFree(p)
         self._ptrs = []
+
+
+# ---- the oracle on EVERY instance of a large batch: forked workers over the usable host cores (the arrays are inherited, not pickled) ----
+_ORACLE_JOB = {}
+
+
+def _oracle_chunk(span):
+    import numpy as np
+    from oracle import osc_oracle
+    j = _ORACLE_JOB
+    lo, hi = span
+    r = {k: np.ascontiguousarray(v[lo:hi], dtype=np.float64) for k, v in j["rec"].items()}
+    ref = osc_oracle.generate_batch(j["lay"], j["gains"], r["M"], r["J"], r["dq"], r["bias"], r["ee_pose"], r["tgt_pose"],
+                                    r.get("wrench"), r.get("tgt_vel"))
+    dom, pinv, trunc, dets = np.zeros(hi - lo, bool), np.zeros(hi - lo, bool), np.zeros(hi - lo, bool), np.zeros(hi - lo)
+    for b in range(hi - lo):
+        Mx, Minv, Mxi, det = osc_oracle.task_inertia(r["J"][b], r["M"][b])
+        sv = np.linalg.svd(Mxi, compute_uv=False)
+        if abs(det) >= 1e-4:
+            dom[b] = sv[-1] > 1e-12 * sv[0]
+        else:
+            dom[b] = not np.any(np.abs(sv / sv[0] / 1e-5 - 1.0) < 1e-2)
+        pinv[b] = abs(det) < 1e-4
+        dets[b] = det
+        trunc[b] = abs(det) < 1e-4 and sv[-1] <= 1e-5 * sv[0]
+    return lo, ref, dom, pinv, trunc, dets
+
+
+def oracle_on_all(lay_dict, gains, rec):
+    """-> (ref[B, n], in_parity_domain[B], pinv_branch[B], truncates[B], det[B]): oracle/osc_oracle.generate_batch + the reference's branch
+    (osc.py:51-55) for every instance of `rec` (C-ABI arrays incl. tgt_pose), over the cores this process may use."""
+    import multiprocessing as mp
+    import os
+
+    import numpy as np
+    B = rec["M"].shape[0]
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+            if q != "max":
+                cores = max(1, min(cores, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    nw = max(1, min(cores, 32))
+    _ORACLE_JOB.update(lay=lay_dict, gains=gains, rec=rec)
+    step = max(64, -(-B // (nw * 8)))
+    spans = [(lo, min(B, lo + step)) for lo in range(0, B, step)]
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=1)
+    except ImportError:
+        import contextlib
+        ctx = contextlib.nullcontext()
+    with ctx:
+        if nw == 1:
+            parts = [_oracle_chunk(sp) for sp in spans]
+        else:
+            with mp.get_context("fork").Pool(nw) as pool:
+                parts = pool.map(_oracle_chunk, spans)
+    _ORACLE_JOB.clear()
+    n = parts[0][1].shape[1]
+    ref, dom, pinv, trunc, det = np.zeros((B, n)), np.zeros(B, bool), np.zeros(B, bool), np.zeros(B, bool), np.zeros(B)
+    for lo, r, d, p_, t, dt in parts:
+        ref[lo:lo + len(d)], dom[lo:lo + len(d)], pinv[lo:lo + len(d)], trunc[lo:lo + len(d)], det[lo:lo + len(d)] = r, d, p_, t, dt
+    return ref, dom, pinv, trunc, det

@@ -12,6 +12,7 @@ import pytest
 
 from irl_control_amd import BatchedOSC, _lib, synth
 from oracle import osc_oracle
+from conftest import oracle_on_all
 from test_gpu_parity import _from_q_setup, in_parity_domain, rel_err, run_gpu
 
 pytestmark = pytest.mark.gpu
@@ -41,11 +42,8 @@ def test_every_reachable_layout_runs_on_a_row16_kernel_and_matches_the_oracle(cf
                                  return_flags=True)
     u = u.astype(np.float64)
     g64 = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in g.items()}
-    idx = np.arange(0, B, 8)
-    ref = _oracle(lay, gains, g64, idx)
-    ti = [osc_oracle.task_inertia(g64["J"][b], g64["M"][b]) for b in idx]
-    dom = np.array([in_parity_domain(t[2], t[3]) for t in ti])
-    det = np.array([t[3] for t in ti])
+    idx = np.arange(B)                                   # the oracle on EVERY instance (forked over the host cores)
+    ref, dom, _, _, det = oracle_on_all(lay.as_oracle_dict(), gains, g64)
     assert dom.mean() > 0.8, dom.mean()
     err = rel_err(u[idx], ref[idx])
     tol = TOL64 if dtype == np.float64 else 2e-5        # float32 OUTPUT words: a large component next to a small one

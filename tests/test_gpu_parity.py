@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from conftest import (HipBuffers, app_from_e2e, golden_expected_u, golden_gains, golden_names, load_e2e,
-                      load_golden)
+                      load_golden, oracle_on_all)
 from irl_control_amd import BatchedOSC, OSCLayout, _lib
 from oracle import osc_oracle
 from irl_control_amd import synth
@@ -249,8 +249,8 @@ def test_row16_tree_full_size(cfg, dtype):
     """The headline kernel at the headline size (BASELINE configs[2]; configs[4] with the admittance term): osc_row16, fp64
     arithmetic, tree-structured factorisation, on 65 536 dense records of physical robot states -- float64 records, float32 records
     (the mixed path: what KERNEL_AUTO gives float32 storage), k12 + wrench.
-    (1) the oracle on EVERY instance of a stratified sample of 8 192 (every 8th instance; ~15 % of them go through the in-kernel
-        eigen stage, ~12 % truncate): <= 1e-5 in the parity domain, PINV / TRUNCATED flags = the reference's branch;
+    (1) the oracle on EVERY one of the 65 536 instances (~15 % of them go through the in-kernel eigen stage, ~12 % truncate):
+        <= 1e-5 in the parity domain, PINV / TRUNCATED flags = the reference's branch;
     (2) size-independent properties on ALL 65 536: u is affine in the bias forces with unit slope (osc.py:191), affine in the
         wrench (osc.py:184-185), and the second half of the batch run alone is bit-identical (sharding changes no bit)."""
     B = 65536
@@ -293,25 +293,15 @@ def test_row16_tree_full_size(cfg, dtype):
     uh, fh = osc.step(return_flags=True)
     assert np.array_equal(uh, u0[h:]) and np.array_equal(fh, fl0[h:])
     osc.close()
-    # (1) the oracle on every instance of the stratified sample
-    idx = np.arange(5, B, 8)
-    r64 = {k: np.ascontiguousarray(v[idx], dtype=np.float64) for k, v in rec.items()}
-    ref = osc_oracle.generate_batch(lay.as_oracle_dict(), gains, r64["M"], r64["J"], r64["dq"], r64["bias"], r64["ee_pose"],
-                                    r64["tgt_pose"], r64.get("wrench"), None)
-    dom, pinv, trunc = [], [], []
-    for b in range(len(idx)):
-        Mx, Minv, Mxi, det = osc_oracle.task_inertia(r64["J"][b], r64["M"][b])
-        sv = np.linalg.svd(Mxi, compute_uv=False)
-        dom.append(in_parity_domain(Mxi, det))
-        pinv.append(abs(det) < 1e-4)
-        trunc.append(abs(det) < 1e-4 and sv[-1] <= 1e-5 * sv[0])
-    dom, pinv, trunc = np.array(dom), np.array(pinv), np.array(trunc)
+    # (1) the oracle on EVERY instance (forked over the host cores: ~20 core-seconds)
+    idx = np.arange(B)
+    ref, dom, pinv, trunc, _ = oracle_on_all(lay.as_oracle_dict(), gains, rec)
     err = rel_err(u0[idx].astype(np.float64), ref)
     fs = fl0[idx]
     n_eig = int(((fs & _lib.FLAG_EIGEN_PATH) != 0).sum())
     print(f"{kname}+tree, {B} physical records: oracle on {len(idx)} instances ({n_eig} through the eigen stage, "
           f"{int(trunc.sum())} truncating, {int((~dom).sum())} outside the parity domain): max rel err in the domain {err[dom].max():.2e}")
-    assert len(idx) >= 8192 and dom.mean() > 0.97 and n_eig >= (800 if k13 else 100) and trunc.sum() >= (400 if k13 else 30)
+    assert len(idx) == B and dom.mean() > 0.97 and n_eig >= (6400 if k13 else 800) and trunc.sum() >= (3200 if k13 else 240)
     assert err[dom].max() <= TOL64, float(err[dom].max())
     assert np.array_equal((fs[dom] & _lib.FLAG_PINV_BRANCH) != 0, pinv[dom])
     assert np.array_equal((fs[dom] & _lib.FLAG_TRUNCATED) != 0, trunc[dom])
