@@ -89,3 +89,25 @@ def test_train_summary_reconciles_span_period_and_events():
     assert s["trains"] == 4 and s["steps_per_train"] == 8
     assert s["period_us"]["median"] == 850.0 and 895.0 <= s["kernel_span_us"]["median"] <= 910.0
     assert 45.0 <= s["overlap_us_median"] <= 60.0 and 990.0 <= s["event_pair_us"]["median"] <= 1010.0 and s["sclk_mhz"]["median"] == 1600.0
+
+
+def test_evidence_scalars_lead_the_line():
+    """The driver's record of the bench line keeps the first 24 keys of `config` and of `roofline` (from_q_value and
+    frac_rocprof were appended behind the cap and lost).  Whatever order the legs fill the dicts in, the evidence scalars lead."""
+    assert len(bench.CONFIG_FIRST) <= 24 and len(bench.ROOFLINE_FIRST) <= 24
+    prose = {"sharding": "x", "records": "float64", "arithmetic": "f64", "preroll_steps": 1000, "records_from": "physical", "admittance": False,
+             "ndev": 3, "steps_per_launch": 8, "slices_per_rank": 1, "sustained_steps": 1, "sustained_ms_per_step": 0.1, "parity_tolerance": 1e-5,
+             "from_q_ms_per_step": 0.1, "secondary_mixed_parity_n_over_tol": 0, "synthetic_dense_roofline_frac": 0.5}
+    cfg = dict(prose)
+    cfg.update({k: 1 for k in bench.CONFIG_FIRST})                       # filled LAST, as bench.py's flat copies are
+    got = list(bench.ordered_first(cfg, bench.CONFIG_FIRST))
+    assert got[:len(bench.CONFIG_FIRST)] == bench.CONFIG_FIRST and set(got) == set(cfg)
+    for must in ("workload", "from_q_value", "from_q_roofline_frac_fp64_valu", "secondary_mixed_value", "secondary_mixed_roofline_frac",
+                 "synthetic_dense_value", "end_to_end_host_arrays_value", "parity_n_outside_domain", "sustained_value", "rccl_ranks"):
+        assert got.index(must) < 24, must
+    roof = {"untraced": {}, "committed_profile": {}, "note": "x"}
+    roof.update({k: 1 for k in bench.ROOFLINE_FIRST})
+    got = list(bench.ordered_first(roof, bench.ROOFLINE_FIRST))
+    for must in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_rocprof", "untraced_kernel_span_us", "untraced_period_us"):
+        assert got.index(must) < 24, must
+    assert got.index("untraced") >= len(bench.ROOFLINE_FIRST)            # the nested dicts trail

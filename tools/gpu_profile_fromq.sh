@@ -17,6 +17,13 @@ fdb=$(find gpurun_out/fq_fetch_$tag -name "*.db" | head -1); wdb=$(find gpurun_o
 if [ -n "$fdb" ] && [ -n "$wdb" ]; then
   (python tools/pmc_dump.py "$fdb" osc_; python tools/pmc_dump.py "$wdb" osc_) > gpurun_out/fromq_pmc_fetch_write_$tag.txt
   cat gpurun_out/fromq_pmc_fetch_write_$tag.txt
-  python tools/pmc_traffic.py "$fdb" "$wdb" osc_frontend_lane_compact "osc_frontend_lane_compact_dual_ur5" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8
-  python tools/pmc_traffic.py "$fdb" "$wdb" "25, true" "osc_row16_f64_n25_k13_fromq" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8
+  if grep -q osc_lane_kernel gpurun_out/fromq_kernel_stats_$tag.txt; then      # round 6: the OSC step one lane per robot + its eigen pass
+    python tools/pmc_traffic.py "$fdb" "$wdb" osc_frontend_lane_compact "fromq_lane:walk" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8
+    python tools/pmc_traffic.py "$fdb" "$wdb" osc_task_rows_fromq "fromq_lane:task_pass" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8
+    python tools/pmc_traffic.py "$fdb" "$wdb" osc_lane_kernel "fromq_lane:osc_lane" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8
+    python tools/pmc_traffic.py "$fdb" "$wdb" osc_lane_eigen_kernel "fromq_lane:eigen_pass" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8
+  else
+    python tools/pmc_traffic.py "$fdb" "$wdb" osc_frontend_lane_compact "osc_frontend_lane_compact_dual_ur5" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8
+    python tools/pmc_traffic.py "$fdb" "$wdb" "25, true" "osc_row16_f64_n25_k13_fromq" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8
+  fi
 fi
