@@ -142,7 +142,12 @@ IRLOSC_API const char* irlosc_kernel_name(const irlosc_ctx* ctx); /* name of the
  * kernel: IRLOSC_CLASS_GENERIC means the one-wavefront-per-instance kernel (any n <= 32: ~25x slower per instance at large batches;
  * AUTO only lands there when n != 25).  ROW16 = an instantiation for exactly this (k, ndev); ROW16_PADDED = the row16 kernel of the
  * smallest tier KMAX in {4, 7, 10, 13, 16} >= k, with k and ndev as run-time arguments (same results bit for bit, a few per cent to
- * a third slower than an exact instantiation would be; the name then ends in "_ndev<d>_pad<KMAX>"). */
+ * a third slower than an exact instantiation would be; the name then ends in "_ndev<d>_pad<KMAX>").
+ * One difference in HOW a result is reached, not in the result: a task row no joint can move (an exact zero row of J) is taken out of
+ * the k x k factorisation up front by the padded kernels and by the lane-per-robot step of the fused path (PINV and TRUNCATED set, no
+ * eigen stage needed for it), while the four exact instantiations find it in their eigen stage (three such directions at most, then the
+ * give-up list -> generic kernel).  Torques agree to rounding and the flags PINV / TRUNCATED agree; irlosc_giveup_counts and the
+ * throughput on such inputs differ.  No layout of the shipped examples has such a row. */
 #define IRLOSC_CLASS_GENERIC      0
 #define IRLOSC_CLASS_ROW16        1
 #define IRLOSC_CLASS_ROW16_PADDED 2

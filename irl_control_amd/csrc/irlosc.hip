@@ -71,7 +71,9 @@ struct irlosc_ctx {
     FeCompactTables* dtables = nullptr;
     size_t fe_xentries = 0;
     double* fe_xside[R16_TRAIN] = {};
-    double* dtrows[R16_TRAIN] = {};        // row16 path on dense records: task rows of each step of a train (osc_task_rows_dense_kernel)
+    double* dtrows[R16_TRAIN] = {};        // row16 path on dense records: task rows of each step of a train (osc_task_rows_dense_kernel);
+                                           // allocated by the first train that needs them (ensure_trows)
+    int task_pass = 1;                     // IRLOSC_TASK_PASS=0: part 1 of the task signal in the row16 kernel (A/B, tests)
     int fused = 0;
     int fused_train = R16_TRAIN;
     // the OSC step of the fused path in lane-per-robot form (osc_lane.hpp): the instantiation that holds the layout (-1: none: the row16
@@ -254,10 +256,10 @@ static int create_impl(irlosc_ctx* c) {
         HIPCHK(nullptr, hipMemsetAsync(c->dzeros, 0, ZB, c->stream));
         for (int k2 = 0; k2 < R16_TRAIN; ++k2) HIPCHK(nullptr, hipMalloc((void**)&c->dr16_list[k2], B * sizeof(int32_t)));
         HIPCHK(nullptr, hipMalloc((void**)&c->dr16_count, R16_TRAIN * sizeof(int32_t)));
-        {   // part 1 of the task signal runs as a pass ahead of the row16 kernel (IRLOSC_TASK_PASS=0: in the kernel; A/B, tests)
+        {   // part 1 of the task signal runs as a pass ahead of the row16 kernel (IRLOSC_TASK_PASS=0: in the kernel; A/B, tests); its
+            // rows buffers are allocated by the first train that needs them (ensure_trows)
             const char* e = getenv("IRLOSC_TASK_PASS");
-            if (!(e && !strcmp(e, "0")))
-                for (int k2 = 0; k2 < R16_TRAIN; ++k2) HIPCHK(nullptr, hipMalloc((void**)&c->dtrows[k2], (size_t)B * 16 * sizeof(double)));
+            c->task_pass = !(e && !strcmp(e, "0"));
         }
         HIPCHK(nullptr, hipMemsetAsync(c->dr16_count, 0, R16_TRAIN * sizeof(int32_t), c->stream));
     }
@@ -481,6 +483,7 @@ extern "C" int irlosc_upload(irlosc_ctx* c, int32_t slot, int32_t B, const void*
     if (wrench) HIPCHK(c, hipMemcpyAsync(c->dwrench[slot], wrench, b * nd * 6 * e, hipMemcpyHostToDevice, c->stream));
     c->has_wrench[slot] = wrench != nullptr;
     c->uploaded[slot] = 0;                              // nothing usable in the slot until the records are accepted
+    if (!c->fused_away.empty()) c->fused_away[slot] = 0;      // (and if they are refused, that is why the slot is empty -- not an earlier fused step)
     if (sym_applies(c)) {
         int rcs;
         if (B <= SYM_HOST_MAX_B) {
@@ -499,6 +502,7 @@ extern "C" int irlosc_upload(irlosc_ctx* c, int32_t slot, int32_t B, const void*
     int rcp = structure_probe(c, slot, B);
     if (rcp) return rcp;
     c->uploaded[slot] = B;
+    if (!c->fused_away.empty()) c->fused_away[slot] = 0;
     return IRLOSC_OK;
 }
 
@@ -588,6 +592,7 @@ extern "C" int irlosc_upload_raw(irlosc_ctx* c, int32_t slot, int32_t B, const i
     rc = structure_probe(c, slot, B);
     if (rc) return rc;
     c->uploaded[slot] = B;
+    if (!c->fused_away.empty()) c->fused_away[slot] = 0;
     return IRLOSC_OK;
 }
 
@@ -612,6 +617,7 @@ extern "C" int irlosc_assemble_device(irlosc_ctx* c, int32_t slot, int32_t B, co
     c->has_wrench[slot] = 1;
     c->tree_ok[slot] = 0;          // enqueued on the caller's stream: no synchronous look at what it writes
     c->uploaded[slot] = B;
+    if (!c->fused_away.empty()) c->fused_away[slot] = 0;
     return IRLOSC_OK;
 }
 
@@ -661,6 +667,22 @@ static void fill_params(const irlosc_ctx* c, KParams<T>& p, int B, const void* M
 // type T of the records.  All instances run on the row16 kernel, the truncated pseudo-inverse included; the few it gives
 // up on (net of eigen-candidates full, degenerate A) are recomputed by the generic kernel (Jacobi, fp64 arithmetic) from
 // the lists it leaves behind.
+// The rows buffers of the task pass, steps 0 .. n - 1 of a train: allocated on first use (8 MB per step at 65 536 instances; a context
+// that only runs the fused path or single ticks never pays for all eight).  Out of memory: that train computes part 1 of the task signal
+// in the row16 kernel (trows = nullptr), same results.
+static bool ensure_trows(irlosc_ctx* c, int n) {
+    if (!c->task_pass) return false;
+    for (int i = 0; i < n; ++i) {
+        if (c->dtrows[i]) continue;
+        if (hipMalloc((void**)&c->dtrows[i], (size_t)c->cfg.max_batch * 16 * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            c->dtrows[i] = nullptr;
+            return false;
+        }
+    }
+    return true;
+}
+
 template <typename T>
 static int row16_train(irlosc_ctx* c, const KParams<T>* ps, int n, bool tree, hipStream_t st, const int* pos = nullptr,
                        bool reset = true) {
@@ -671,10 +693,11 @@ static int row16_train(irlosc_ctx* c, const KParams<T>* ps, int n, bool tree, hi
     Row16Train<T> tr;
     memset(&tr, 0, sizeof tr);
     if (reset) HIPCHK(c, hipMemsetAsync(c->dr16_count, 0, R16_TRAIN * sizeof(int32_t), st));
+    const bool rows = ensure_trows(c, n);
     for (int i = 0; i < n; ++i) {
         const int o = pos ? pos[i] : i;
         tr.p[i] = ps[i];
-        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[o], c->dr16_count + o, nullptr, nullptr, nullptr, c->span_next, c->dtrows[i]};
+        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[o], c->dr16_count + o, nullptr, nullptr, nullptr, c->span_next, rows ? c->dtrows[i] : nullptr};
     }
     if (c->tev_begin) HIPCHK(c, hipEventRecord(c->tev_begin, st));
     int rc = launch_row16<T>(tr, n, tree, st);
@@ -1158,6 +1181,7 @@ static int frontend_launch(irlosc_ctx* c, int slot, int B) {
     // The records of this slot are now those of B robots: an earlier, larger upload must not vouch for instances the front
     // end did not write (the wrench of the slot stays what the last irlosc_upload / irlosc_upload_raw put there).
     c->uploaded[slot] = B;
+    if (!c->fused_away.empty()) c->fused_away[slot] = 0;
     c->tree_ok[slot] = c->fe_lane;     // the lane kernel walks the compiled tree: its records carry the tree's zeros by construction
     return IRLOSC_OK;
 }

@@ -15,7 +15,11 @@ int launch_row16(const Row16Train<TIN>& tr, int nsteps, bool tree, hipStream_t s
     if (p.B <= 0 || nsteps <= 0) return 0;
     const dim3 grid((p.B + 3) / 4, nsteps);
     // part 1 of the task signal as a pass of its own (osc_task_rows_dense_kernel; no rows buffer: computed in the kernel)
-    if (tr.x[0].trows) hipLaunchKernelGGL((osc_task_rows_dense_kernel<TIN>), dim3((p.B + 63) / 64, nsteps), dim3(64 * p.ndev), 0, st, tr);
+    if (tr.x[0].trows) {
+        hipLaunchKernelGGL((osc_task_rows_dense_kernel<TIN>), dim3((p.B + 63) / 64, nsteps), dim3(64 * p.ndev), 0, st, tr);
+        const int rc = (int)hipGetLastError();      // (not left to the sticky last-error: the main launch below would be queued behind a failed pass)
+        if (rc) return rc;
+    }
     if (p.padded)      // every other n = 25 layout: the KMAX-padded variants (tu_row16_pad_impl.hpp)
         return tree ? launch_row16_pad_tree<TIN>(tr, nsteps, st) : launch_row16_pad_dense<TIN>(tr, nsteps, st);
     if (tree) {
