@@ -433,6 +433,21 @@ def measure_end_to_end(BatchedOSC, lay, gains, arr, dt, kern, local_rank):
                                     "what": "BatchedOSC.generate_batched from pageable host arrays: irlosc_upload (records + device-side symmetry / "
                                             "structure probes) + irlosc_set_targets + irlosc_step with the torques and flags copied back"}}
         osc.close()
+        if esz == 8:      # the same boundary with float32 records (fp64 arithmetic: the mixed path): half the bytes over the link
+            a32 = tuple(None if x is None else np.ascontiguousarray(x, dtype=np.float32) for x in a)
+            osc = BatchedOSC(lay, B, dtype=np.float32, hip_device=local_rank)
+            osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+            for _ in range(2):
+                osc.generate_batched(*a32)
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter(); osc.generate_batched(*a32); ts.append(time.perf_counter() - t0)
+            el32 = float(np.median(ts))
+            nb32 = sum(x.nbytes for x in a32 if x is not None) + B * lay.n * 4 + 4 * B
+            out["generate_batched_float32"] = {"value": B / el32, "unit": "steps/s", "ms_per_tick": el32 * 1e3, "instances": B,
+                                               "pcie_GBps": nb32 / el32 / 1e9, "bytes_per_instance": nb32 // B, "kernel": osc.kernel_name,
+                                               "what": "generate_batched from float32 host arrays (float32 records, fp64 arithmetic)"}
+            osc.close()
         # B = 1: what OSC.generate costs per tick (irlosc_tick: pack, one H2D, the step, one D2H, one synchronisation)
         one = {k: (v[:1] if isinstance(v, np.ndarray) else v) for k, v in arr.items()}
         osc = BatchedOSC(lay, 1, dtype=dt, hip_device=local_rank, kernel=kern)
@@ -477,7 +492,34 @@ def measure_end_to_end(BatchedOSC, lay, gains, arr, dt, kern, local_rank):
             out["upload_raw_step"] = {"value": B / el, "unit": "steps/s", "ms_per_tick": el * 1e3, "pcie_GBps": rb / el / 1e9,
                                       "what": "raw simulator arrays (mj_fullM, jacp / jacr, qvel, qfrc_bias, xpos / xquat; nv = 25) from the host, "
                                               "state assembly on the GPU (irlosc_upload_raw), targets, one step, torques back"}
+            # the same with M as MuJoCo holds it (mjData.qM, nM = 155 entries per robot: irlosc_upload_raw_sparse expands it on the GPU --
+            # robot.py:68-72 has mj_fullM do that on the host), float64 and float32 arrays: the best case of the host-fed deployment
+            from irl_control_amd import raw as rawmod
+            PARENT = [-1, 0, 1, 2, 3, 4, 5, 6, 7, 6, 6, 10, 6, 0, 13, 14, 15, 16, 17, 18, 19, 18, 18, 22, 18]      # dof_parentid of the Dual-UR5
+            ql = rawmod.qm_layout(PARENT)
+            tree_ok = bool(np.all(rawmod.pack_qM(arr["M"][:64], ql).sum() != 0)) and bool(osc.slot_structure(0))
             osc.close()
+            if tree_ok:                               # (records with the tree's zeros: the physical workload; a synthetic dense M has no sparse form)
+                for tag, dts in (("upload_raw_sparse_step", dt), ("upload_raw_sparse_step_float32", np.float32)):
+                    rs = {k: np.ascontiguousarray(v, dtype=dts) for k, v in raw.items() if k != "qM"}
+                    qs = np.ascontiguousarray(rawmod.pack_qM(arr["M"], ql), dtype=dts)
+                    tg = np.ascontiguousarray(arr["tgt_pose"], dtype=dts)
+                    osc = BatchedOSC(lay, B, dtype=dts, hip_device=local_rank)
+                    osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+                    ts = []
+                    for it in range(5):
+                        t0 = time.perf_counter()
+                        osc.upload_raw(d, qs, qm_layout=ql, **rs)
+                        osc.set_targets(tg)
+                        osc.step()
+                        ts.append(time.perf_counter() - t0)
+                    el = float(np.median(ts[1:]))
+                    es2 = np.dtype(dts).itemsize
+                    rb = qs.nbytes + sum(x.nbytes for x in rs.values()) + tg.nbytes + B * lay.n * es2 + 4 * B
+                    out[tag] = {"value": B / el, "unit": "steps/s", "ms_per_tick": el * 1e3, "pcie_GBps": rb / el / 1e9, "bytes_per_instance": rb // B,
+                                "kernel": osc.kernel_name,
+                                "what": "as upload_raw_step, with mjData.qM in MuJoCo's sparse form (nM = 155 values per robot) expanded on the GPU"}
+                    osc.close()
         out["note"] = ("host arrays cross PCIe every tick: the link bounds these figures, not the kernel; `value` (inputs resident in HBM) "
                        "is the headline, and from_q (568 B per robot in) is the path that needs no dense records at all")
         return out
@@ -916,6 +958,11 @@ def main():
         cfgd.update(end_to_end_host_arrays_value=e2e["generate_batched"]["value"], end_to_end_pcie_GBps=e2e["generate_batched"].get("pcie_GBps"))
     if isinstance(e2e.get("tick_b1_us"), dict):
         cfgd["end_to_end_tick_b1_us"] = e2e["tick_b1_us"].get("median")
+    for key, flat in (("generate_batched_float32", "end_to_end_host_arrays_f32_value"), ("upload_raw_sparse_step", "end_to_end_raw_sparse_qM_value"),
+                      ("upload_raw_sparse_step_float32", "end_to_end_raw_sparse_qM_f32_value")):
+        if isinstance(e2e.get(key), dict) and "value" in e2e[key]:
+            cfgd[flat] = e2e[key]["value"]
+            cfgd[flat.replace("_value", "_pcie_GBps")] = e2e[key].get("pcie_GBps")
     # The driver's record keeps the first 24 keys of `config` and of `roofline`: the evidence scalars go first, the prose last
     # (tests/test_bench_host.py::test_evidence_scalars_lead_the_line).
     out["config"] = ordered_first(cfgd, CONFIG_FIRST)

@@ -246,6 +246,21 @@ IRLOSC_API int irlosc_upload_raw(irlosc_ctx* ctx, int32_t slot, int32_t B, const
                       const void* qvel, const void* qfrc_bias, const void* jacp, const void* jacr,
                       const void* ee_xpos, const void* ee_xquat, const void* site_xmat, const void* sensordata);
 
+/* The same with M as MuJoCo itself holds it: mjData.qM, the sparse lower triangle over the kinematic tree -- nM values per instance,
+ * dof i's run starts at dof_Madr[i] and walks UP the tree: M[i][i], M[i][parent(i)], M[i][parent(parent(i))], ... with parent =
+ * mjModel.dof_parentid (-1 ends the run).  The expansion mj_fullM does on the host (robot.py:68-72 calls it for every robot and tick)
+ * runs on the GPU instead, inside the assembly kernel: 1.4 KB instead of 5 KB (nv = 25) or 11 KB (nv = 37) per robot cross PCIe.
+ * qM_sparse[B][nM] in the context's dtype; everything else as irlosc_upload_raw. */
+#define IRLOSC_MAX_NV 128
+typedef struct irlosc_qm_layout {
+    int32_t nM;                               /* mjModel.nM */
+    int32_t dof_Madr[IRLOSC_MAX_NV];          /* mjModel.dof_Madr[0 .. nv) */
+    int32_t dof_parentid[IRLOSC_MAX_NV];      /* mjModel.dof_parentid[0 .. nv) */
+} irlosc_qm_layout;
+IRLOSC_API int irlosc_upload_raw_sparse(irlosc_ctx* ctx, int32_t slot, int32_t B, const irlosc_raw_desc* desc, const irlosc_qm_layout* qml,
+                             const void* qM_sparse, const void* qvel, const void* qfrc_bias, const void* jacp, const void* jacr,
+                             const void* ee_xpos, const void* ee_xquat, const void* site_xmat, const void* sensordata);
+
 /* Same assembly for simulators whose state already lives in HBM: every array pointer is a DEVICE pointer (layouts
  * as above), hip_stream a hipStream_t (NULL = the context's stream).  No copies; the call returns after enqueueing the
  * kernel, and steps of this context issued on the same stream see the assembled slot. */

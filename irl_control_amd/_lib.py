@@ -19,7 +19,7 @@ EXPORTS = ["irlosc_abi_version", "irlosc_device_count", "irlosc_create", "irlosc
            "irlosc_last_error", "irlosc_kernel_name", "irlosc_frontend_name", "irlosc_set_gains", "irlosc_upload",
            "irlosc_set_targets", "irlosc_step", "irlosc_step_resident", "irlosc_download",
            "irlosc_sync", "irlosc_step_device", "irlosc_time_dominant_kernel",
-           "irlosc_steps_per_launch", "irlosc_upload_raw", "irlosc_assemble_device", "irlosc_device_sync",
+           "irlosc_steps_per_launch", "irlosc_upload_raw", "irlosc_upload_raw_sparse", "irlosc_assemble_device", "irlosc_device_sync",
            "irlosc_tick", "irlosc_comm_unique_id", "irlosc_comm_create", "irlosc_comm_destroy",
            "irlosc_comm_last_error", "irlosc_bench_allreduce", "irlosc_comm_allgather_u64", "irlosc_set_model",
            "irlosc_upload_q", "irlosc_frontend", "irlosc_step_resident_from_q", "irlosc_download_records",
@@ -34,6 +34,14 @@ class RawDesc(C.Structure):
     """struct irlosc_raw_desc (include/irlosc.h)."""
     _fields_ = [("nv", C.c_int32), ("n_sensor", C.c_int32), ("joint_ids", C.c_int32 * 32),
                 ("dq_src", C.c_int32 * 32), ("ft_force0", C.c_int32 * 4), ("ft_torque0", C.c_int32 * 4)]
+
+
+MAX_NV = 128
+
+
+class QmLayout(C.Structure):
+    """struct irlosc_qm_layout (include/irlosc.h): MuJoCo's sparse form of M -- mjModel.nM, dof_Madr, dof_parentid."""
+    _fields_ = [("nM", C.c_int32), ("dof_Madr", C.c_int32 * MAX_NV), ("dof_parentid", C.c_int32 * MAX_NV)]
 
 
 class Model(C.Structure):
@@ -99,6 +107,7 @@ def load():
     lib.irlosc_time_trains.argtypes = [vp, i32, i32, i32, i32, vp]
     lib.irlosc_giveup_counts.argtypes = [vp, vp]
     lib.irlosc_upload_raw.argtypes = [vp, i32, i32, C.POINTER(RawDesc)] + [vp] * 9
+    lib.irlosc_upload_raw_sparse.argtypes = [vp, i32, i32, C.POINTER(RawDesc), C.POINTER(QmLayout)] + [vp] * 9
     lib.irlosc_assemble_device.argtypes = [vp, i32, i32, C.POINTER(RawDesc)] + [vp] * 10
     lib.irlosc_download.argtypes = [vp, i32, vp, vp]
     lib.irlosc_sync.argtypes = [vp]

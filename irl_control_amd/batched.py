@@ -115,12 +115,22 @@ class BatchedOSC:
         self._B[slot] = B
 
     def upload_raw(self, desc, qM, qvel, qfrc_bias, jacp, jacr, ee_xpos, ee_xquat, site_xmat=None, sensordata=None,
-                   slot: int = 0):
+                   slot: int = 0, qm_layout=None):
         """Raw simulator arrays in, state assembly on the GPU (see raw.py / irlosc_upload_raw).  `desc` from
         raw.raw_desc(); arrays batch-major: qM[B,nv,nv], qvel[B,nv], qfrc_bias[B,nv], jacp/jacr[B,ndev,3,nv],
-        ee_xpos[B,ndev,3], ee_xquat[B,ndev,4], site_xmat[B,ndev,9], sensordata[B,n_sensor]."""
+        ee_xpos[B,ndev,3], ee_xquat[B,ndev,4], site_xmat[B,ndev,9], sensordata[B,n_sensor].
+        With `qm_layout` (raw.qm_layout(dof_parentid[, dof_Madr])) qM is mjData.qM as MuJoCo holds it, [B, nM]: mj_fullM's expansion
+        (robot.py:68-72) then runs on the GPU (irlosc_upload_raw_sparse)."""
         L = self.layout
         B, nv, ns = int(np.shape(qM)[0]), int(desc.nv), int(desc.n_sensor)
+        if qm_layout is not None:
+            a = [self._arr(qM, (B, int(qm_layout.nM)), "qM (sparse)"), self._arr(qvel, (B, nv), "qvel"), self._arr(qfrc_bias, (B, nv), "qfrc_bias"),
+                 self._arr(jacp, (B, L.ndev, 3, nv), "jacp"), self._arr(jacr, (B, L.ndev, 3, nv), "jacr"),
+                 self._arr(ee_xpos, (B, L.ndev, 3), "ee_xpos"), self._arr(ee_xquat, (B, L.ndev, 4), "ee_xquat"),
+                 self._arr(site_xmat, (B, L.ndev, 9), "site_xmat"), self._arr(sensordata, (B, ns), "sensordata")]
+            self._chk(self.lib.irlosc_upload_raw_sparse(self._h, slot, B, C.byref(desc), C.byref(qm_layout), *[_lib.ptr(x) for x in a]))
+            self._B[slot] = B
+            return
         a = [self._arr(qM, (B, nv, nv), "qM"), self._arr(qvel, (B, nv), "qvel"), self._arr(qfrc_bias, (B, nv), "qfrc_bias"),
              self._arr(jacp, (B, L.ndev, 3, nv), "jacp"), self._arr(jacr, (B, L.ndev, 3, nv), "jacr"),
              self._arr(ee_xpos, (B, L.ndev, 3), "ee_xpos"), self._arr(ee_xquat, (B, L.ndev, 4), "ee_xquat"),

@@ -508,9 +508,16 @@ extern "C" int irlosc_upload(irlosc_ctx* c, int32_t slot, int32_t B, const void*
 
 // Enqueue the assembly kernel: dptr = device pointers {qM, qvel, qfrc_bias, jacp, jacr, ee_xpos, ee_xquat, site_xmat, sensordata}.
 template <typename T>
-static int assemble_launch(irlosc_ctx* c, int slot, int B, const irlosc_raw_desc* rd, const void* const* dptr, hipStream_t st) {
+static int assemble_launch(irlosc_ctx* c, int slot, int B, const irlosc_raw_desc* rd, const void* const* dptr, hipStream_t st,
+                           const irlosc_qm_layout* qml = nullptr) {
     RawDesc d;
     memset(&d, 0, sizeof d);
+    if (qml) {
+        d.nM = qml->nM;
+        for (int j = 0; j < IRLOSC_MAX_NV; ++j) d.pos[j] = -1;
+        for (int j = 0; j < rd->nv; ++j) { d.madr[j] = (int16_t)qml->dof_Madr[j]; d.par[j] = (int16_t)qml->dof_parentid[j]; }
+        for (int i = 0; i < c->cfg.n; ++i) d.pos[rd->joint_ids[i]] = (int16_t)i;
+    }
     d.nv = rd->nv; d.n_sensor = rd->n_sensor; d.n = c->cfg.n; d.k = c->k; d.ndev = c->cfg.ndev;
     for (int i = 0; i < c->cfg.n; ++i) { d.joint_ids[i] = rd->joint_ids[i]; d.dq_src[i] = rd->dq_src[i]; }
     for (int dv = 0; dv < c->cfg.ndev; ++dv) {
@@ -545,11 +552,11 @@ static int check_raw_desc(irlosc_ctx* c, const irlosc_raw_desc* rd) {
 template <typename T>
 static int upload_raw_t(irlosc_ctx* c, int slot, int B, const irlosc_raw_desc* rd, const void* qM, const void* qvel,
                         const void* qfrc_bias, const void* jacp, const void* jacr, const void* ee_xpos,
-                        const void* ee_xquat, const void* site_xmat, const void* sensordata) {
+                        const void* ee_xquat, const void* site_xmat, const void* sensordata, const irlosc_qm_layout* qml = nullptr) {
     const size_t b = (size_t)B, nv = (size_t)rd->nv, nd = (size_t)c->cfg.ndev, ns = (size_t)rd->n_sensor, e = sizeof(T);
     const bool ft = site_xmat && sensordata && ns > 0;
-    // staging layout: qM | qvel | qfrc_bias | jacp | jacr | ee_xpos | ee_xquat | site_xmat | sensordata
-    const size_t sz[9] = {b * nv * nv * e, b * nv * e, b * nv * e, b * nd * 3 * nv * e, b * nd * 3 * nv * e,
+    // staging layout: qM (dense nv x nv, or MuJoCo's nM-entry form) | qvel | qfrc_bias | jacp | jacr | ee_xpos | ee_xquat | site_xmat | sensordata
+    const size_t sz[9] = {qml ? b * (size_t)qml->nM * e : b * nv * nv * e, b * nv * e, b * nv * e, b * nd * 3 * nv * e, b * nd * 3 * nv * e,
                           b * nd * 3 * e, b * nd * 4 * e, ft ? b * nd * 9 * e : 0, ft ? b * ns * e : 0};
     const void* src[9] = {qM, qvel, qfrc_bias, jacp, jacr, ee_xpos, ee_xquat, site_xmat, sensordata};
     size_t off[9], total = 0;
@@ -565,9 +572,47 @@ static int upload_raw_t(irlosc_ctx* c, int slot, int B, const irlosc_raw_desc* r
         if (sz[i]) HIPCHK(c, hipMemcpyAsync(base + off[i], src[i], sz[i], hipMemcpyHostToDevice, c->stream));
     const void* dptr[9];
     for (int i = 0; i < 9; ++i) dptr[i] = sz[i] ? (const void*)(base + off[i]) : nullptr;
-    int rc = assemble_launch<T>(c, slot, B, rd, dptr, c->stream);
+    int rc = assemble_launch<T>(c, slot, B, rd, dptr, c->stream, qml);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return IRLOSC_OK;
+}
+
+// MuJoCo's own form of M: validate the layout (every run stays inside [0, nM), the tree is a forest numbered parents first)
+static int check_qm_layout(irlosc_ctx* c, const irlosc_raw_desc* rd, const irlosc_qm_layout* q) {
+    if (rd->nv > IRLOSC_MAX_NV) return fail(c, IRLOSC_ERR_ARG, "nv=%d exceeds IRLOSC_MAX_NV=%d", rd->nv, IRLOSC_MAX_NV);
+    if (q->nM < rd->nv || q->nM > 32767) return fail(c, IRLOSC_ERR_ARG, "nM=%d out of range for nv=%d", q->nM, rd->nv);
+    for (int i = 0; i < rd->nv; ++i) {
+        if (q->dof_parentid[i] >= i || q->dof_parentid[i] < -1) return fail(c, IRLOSC_ERR_ARG, "dof_parentid[%d]=%d: a parent precedes its child (or is -1)", i, q->dof_parentid[i]);
+        int len = 0;
+        for (int j = i; j >= 0; j = q->dof_parentid[j]) ++len;
+        if (q->dof_Madr[i] < 0 || q->dof_Madr[i] + len > q->nM) return fail(c, IRLOSC_ERR_ARG, "dof_Madr[%d]=%d + %d entries exceeds nM=%d", i, q->dof_Madr[i], len, q->nM);
+    }
+    return IRLOSC_OK;
+}
+
+extern "C" int irlosc_upload_raw_sparse(irlosc_ctx* c, int32_t slot, int32_t B, const irlosc_raw_desc* rd, const irlosc_qm_layout* qml,
+                                        const void* qM, const void* qvel, const void* qfrc_bias, const void* jacp, const void* jacr,
+                                        const void* ee_xpos, const void* ee_xquat, const void* site_xmat, const void* sensordata) {
+    if (!c) return IRLOSC_ERR_ARG;
+    int rc = check_slot(c, slot, B);
+    if (rc) return rc;
+    if (B == 0) { c->uploaded[slot] = -1; return IRLOSC_OK; }
+    if (!rd || !qml || !qM || !qvel || !qfrc_bias || !jacp || !jacr || !ee_xpos || !ee_xquat)
+        return fail(c, IRLOSC_ERR_ARG, "desc, qm layout, qM, qvel, qfrc_bias, jacp, jacr, ee_xpos and ee_xquat are required");
+    rc = check_raw_desc(c, rd);
+    if (!rc) rc = check_qm_layout(c, rd, qml);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->cfg.hip_device));
+    rc = c->cfg.dtype == IRLOSC_F64
+             ? upload_raw_t<double>(c, slot, B, rd, qM, qvel, qfrc_bias, jacp, jacr, ee_xpos, ee_xquat, site_xmat, sensordata, qml)
+             : upload_raw_t<float>(c, slot, B, rd, qM, qvel, qfrc_bias, jacp, jacr, ee_xpos, ee_xquat, site_xmat, sensordata, qml);
+    if (rc) return rc;
+    c->has_wrench[slot] = 1;
+    rc = structure_probe(c, slot, B);      // (symmetric by construction: the expansion mirrors every entry)
+    if (rc) return rc;
+    c->uploaded[slot] = B;
+    if (!c->fused_away.empty()) c->fused_away[slot] = 0;
     return IRLOSC_OK;
 }
 

@@ -21,6 +21,10 @@ struct RawDesc {
     int32_t ft_force0[IRLOSC_MAX_DEV];
     int32_t ft_torque0[IRLOSC_MAX_DEV];
     uint32_t dofmask[IRLOSC_MAX_DEV];
+    // qM as MuJoCo keeps it (irlosc_upload_raw_sparse): nM > 0 -- r.qM is then [B][nM], the run of raw dof i starts at madr[i] and walks
+    // up the tree through par[] (mj_fullM's loop, robot.py:68-72); pos[j] = position of raw dof j in the robot's n-vector, -1: none
+    int32_t nM;
+    int16_t madr[IRLOSC_MAX_NV], par[IRLOSC_MAX_NV], pos[IRLOSC_MAX_NV];
 };
 
 template <typename T>
@@ -35,10 +39,26 @@ __global__ __launch_bounds__(64) void osc_assemble_kernel(const RawDesc d, const
     const int lane = threadIdx.x;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         const int n = d.n, nv = d.nv, ndev = d.ndev;
-        const T* qM = r.qM + (size_t)b * nv * nv;
-        for (int e = lane; e < n * n; e += 64) {
-            const int i = e / n, j = e - i * n;
-            r.M[(size_t)b * n * n + e] = qM[(size_t)d.joint_ids[i] * nv + d.joint_ids[j]];
+        if (d.nM > 0) {
+            // mj_fullM on the device: zeros, then row i's run up the tree, mirrored (lane = robot position; a pair (p, ancestor) is
+            // written by lane p only)
+            T* Mo = r.M + (size_t)b * n * n;
+            for (int e = lane; e < n * n; e += 64) Mo[e] = T(0);
+            __syncthreads();
+            if (lane < n) {
+                const T* q = r.qM + (size_t)b * d.nM;
+                int adr = d.madr[d.joint_ids[lane]];
+                for (int j = d.joint_ids[lane]; j >= 0; j = d.par[j], ++adr) {
+                    const int pj = d.pos[j];
+                    if (pj >= 0) { const T v = q[adr]; Mo[lane * n + pj] = v; Mo[pj * n + lane] = v; }
+                }
+            }
+        } else {
+            const T* qM = r.qM + (size_t)b * nv * nv;
+            for (int e = lane; e < n * n; e += 64) {
+                const int i = e / n, j = e - i * n;
+                r.M[(size_t)b * n * n + e] = qM[(size_t)d.joint_ids[i] * nv + d.joint_ids[j]];
+            }
         }
         if (lane < n) {
             const int src = d.dq_src[lane];

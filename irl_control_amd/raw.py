@@ -66,3 +66,41 @@ def collect_raw(sims: List, robots: List[Robot], names: Sequence[str], dtype=np.
             if ent is not None:
                 out["site_xmat"][b, i] = np.asarray(sim.data.get_site_xmat(ent[0])).reshape(9)
     return out
+
+
+def qm_layout(dof_parentid: Sequence[int], dof_Madr: Sequence[int] = None) -> _lib.QmLayout:
+    """`struct irlosc_qm_layout` for `BatchedOSC.upload_raw(..., qm_layout=...)`: MuJoCo's sparse form of the joint-space inertia
+    (mjData.qM with mjModel.dof_Madr / dof_parentid / nM; the reference expands it on the host for every robot and tick, robot.py:68-72).
+    With the official bindings: qm_layout(m.dof_parentid, m.dof_Madr).  Without dof_Madr the runs are laid out back to back in dof
+    order, which is what MuJoCo does."""
+    par = [int(p) for p in dof_parentid]
+    nv = len(par)
+    if nv > _lib.MAX_NV:
+        raise ValueError(f"nv = {nv} exceeds {_lib.MAX_NV}")
+    q = _lib.QmLayout()
+    adr = 0
+    for i in range(nv):
+        q.dof_parentid[i] = par[i]
+        q.dof_Madr[i] = int(dof_Madr[i]) if dof_Madr is not None else adr
+        j, ln = i, 0
+        while j >= 0:
+            ln += 1
+            j = par[j]
+        adr = q.dof_Madr[i] + ln
+        q.nM = max(q.nM, adr)
+    return q
+
+
+def pack_qM(M: np.ndarray, layout: "_lib.QmLayout") -> np.ndarray:
+    """Dense [B, nv, nv] -> MuJoCo's sparse [B, nM] (the inverse of mj_fullM; entries outside the tree's pattern are dropped -- a
+    simulator holds the sparse form to begin with, this is for tests and the bench)."""
+    M = np.asarray(M)
+    B, nv = M.shape[0], M.shape[1]
+    out = np.zeros((B, int(layout.nM)), dtype=M.dtype)
+    for i in range(nv):
+        adr, j = int(layout.dof_Madr[i]), i
+        while j >= 0:
+            out[:, adr] = M[:, i, j]
+            adr += 1
+            j = int(layout.dof_parentid[j])
+    return out

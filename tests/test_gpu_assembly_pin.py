@@ -269,3 +269,78 @@ def test_upload_raw_full_size_properties_nv37():
     mid = 0.5 * (u + outs[0])
     scale = np.maximum(np.abs(u).max(axis=1), np.abs(outs[0]).max(axis=1))
     assert (np.abs(outs[1] - mid).max(axis=1) / scale).max() <= 1e-9
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("free_dofs", [0, 12])
+def test_qM_in_mujocos_sparse_form_gives_the_records_of_the_dense_form(dtype, free_dofs):
+    """irlosc_upload_raw_sparse: mjData.qM as MuJoCo holds it (nM entries per robot: every dof's run up the tree through dof_parentid,
+    starting at dof_Madr) expanded ON THE GPU -- what robot.py:68-72 has mj_fullM do on the host for every robot and tick.  Physical M
+    of random Dual-UR5 states (tree pattern), optionally behind `free_dofs` dofs of free bodies in front of the robot's (the
+    admit_test scene: nv = 37): the slot's records and the step's torques equal those of the dense raw upload bit for bit."""
+    from irl_control_amd import synth
+    from irl_control_amd.rigid_body import RigidBodyModel
+    B, n = 300, 25
+    lay = synth.make_layout("k13")
+    model = RigidBodyModel.load("dual_ur5")
+    rng = np.random.default_rng(11)
+    fe = BatchedOSC(lay, B, dtype=np.float64)
+    fe.set_model(model)
+    fe.upload_q(*model.random_state(rng, B))
+    fe.frontend()
+    rec = fe.download_records(0)
+    fe.close()
+    _, gains, g = synth.make_batch("k13", B, seed=12, dtype=dtype)
+    nv, f = n + free_dofs, free_dofs
+    # the robot's dofs come after the free bodies' (MuJoCo numbers dofs in body order: world.xml's free bodies first)
+    qM = np.zeros((B, nv, nv))
+    qM[:, f:, f:] = rec["M"]
+    for k in range(f):
+        qM[:, k, k] = 1.0 + k
+    PARENT = [-1, 0, 1, 2, 3, 4, 5, 6, 7, 6, 6, 10, 6, 0, 13, 14, 15, 16, 17, 18, 19, 18, 18, 22, 18]      # hinge tree (SURVEY appendix A)
+    par = [(k - 1 if k % 6 else -1) for k in range(f)] + [(p + f if p >= 0 else -1) for p in PARENT]        # a free body: a chain of six dofs
+    d = _lib.RawDesc()
+    d.nv, d.n_sensor = nv, 0
+    for p_ in range(32):
+        d.joint_ids[p_] = p_ + f if p_ < n else 0
+        d.dq_src[p_] = p_ + f if p_ < n else -1
+    for i in range(4):
+        d.ft_force0[i] = d.ft_torque0[i] = -1
+    jacp, jacr = np.zeros((B, 3, 3, nv)), np.zeros((B, 3, 3, nv))
+    jacp[:, 0, :, f:], jacr[:, 0, :, f:] = rec["J"][:, 0:3], rec["J"][:, 3:6]
+    jacp[:, 1, :, f:], jacr[:, 1, :, f:] = rec["J"][:, 6:9], rec["J"][:, 9:12]
+    jacr[:, 2, 2, f:] = rec["J"][:, 12]
+    qvel, qb = np.zeros((B, nv)), np.zeros((B, nv))
+    qvel[:, f:], qb[:, f:] = rec["dq"], rec["bias"]
+    common = dict(qvel=qvel, qfrc_bias=qb, jacp=jacp, jacr=jacr, ee_xpos=np.ascontiguousarray(rec["ee_pose"][:, :, :3]),
+                  ee_xquat=np.ascontiguousarray(rec["ee_pose"][:, :, 3:]))
+    common = {k: v.astype(dtype) for k, v in common.items()}
+    ql = raw.qm_layout(par)
+    def run_len(i):
+        ln = 0
+        while i >= 0:
+            ln, i = ln + 1, par[i]
+        return ln
+    assert ql.nM == sum(run_len(i) for i in range(nv)) == 155 + 21 * (f // 6)      # the Dual-UR5's 155 + 21 per free body
+    sparse = raw.pack_qM(qM, ql).astype(dtype)
+    assert sparse.shape[1] == ql.nM and ql.nM < nv * nv / 3
+    osc = BatchedOSC(lay, B, dtype=dtype, n_slots=2)
+    osc.set_gains(gains["kp"], gains["kv"], gains["ko"], gains["k"], gains["d"], gains["max_vel"], gains["null_kv"])
+    osc.upload_raw(d, qM.astype(dtype), slot=0, **common)
+    osc.upload_raw(d, sparse, slot=1, qm_layout=ql, **common)
+    r0, r1 = osc.download_records(0), osc.download_records(1)
+    for k in ("M", "J", "dq", "bias", "ee_pose"):
+        assert np.array_equal(r0[k], r1[k]), k
+    assert np.array_equal(r1["M"].astype(np.float64), rec["M"].astype(dtype).astype(np.float64))
+    assert osc.slot_structure(0) and osc.slot_structure(1)
+    for s in (0, 1):
+        osc.set_targets(g["tgt_pose"], slot=s)
+    u0, f0 = osc.step(slot=0, return_flags=True)
+    u1, f1 = osc.step(slot=1, return_flags=True)
+    assert np.array_equal(u0, u1) and np.array_equal(f0, f1) and np.all(np.isfinite(u1))
+    # a layout that runs past nM, or a child before its parent, is refused
+    bad = raw.qm_layout(par)
+    bad.nM = ql.nM - 1
+    with pytest.raises(_lib.IrloscError, match="exceeds nM"):
+        osc.upload_raw(d, sparse[:, :-1].copy(), slot=1, qm_layout=bad, **common)
+    osc.close()
