@@ -1353,7 +1353,7 @@ static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, hipStream_
     HIPCHK(c, (hipError_t)(c->fe_lane_s ? launch_frontend_lane_compact_dual_ur5_s(c->dmodel, ft, n, st)
                                         : launch_frontend_lane_compact_dual_ur5(c->dmodel, ft, n, st)));
     if (use_lane) {
-        HIPCHK(c, (hipError_t)launch_row16_fromq<T>(tr, n, st, 1));                 // the task pass
+        if (!lane_task_in_kernel()) HIPCHK(c, (hipError_t)launch_row16_fromq<T>(tr, n, st, 1));      // the task pass (A/B builds: the lane kernel computes the rows itself)
         static const int eig_blocks = [] { const char* e = getenv("IRLOSC_LANE_EIG_BLOCKS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 65536 ? v : 1024; }();
         HIPCHK(c, (hipError_t)launch_lane_osc<T>(tr, lt, n, c->lane_tier, eig_blocks, st));
     } else {

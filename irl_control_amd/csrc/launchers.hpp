@@ -38,6 +38,7 @@ template <> int launch_row16_pad_fromq<float>(const Row16Train<float>&, int, hip
 namespace lane { struct LaneTrain; struct RowMap; }
 struct FeModel;
 int lane_plan(const FeModel& h, lane::RowMap* map);      // -> tier, or -1: no instantiation for this layout
+int lane_task_in_kernel();                              // 1: the lane kernel computes part 1 of the task signal itself (no task pass)
 template <typename TIN>
 int launch_lane_osc(const Row16Train<TIN>& tr, const lane::LaneTrain& lt, int nsteps, int tier, int eig_blocks, hipStream_t st);
 template <> int launch_lane_osc<double>(const Row16Train<double>&, const lane::LaneTrain&, int, int, int, hipStream_t);

@@ -209,6 +209,51 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
 #endif
     constexpr int PFD = IRLOSC_LANE_PFD;
     static_for<0, PFD>([&](auto dc) { constexpr int j = NJ - 1 - decltype(dc)::value; if constexpr (j >= 0) fetch(std::integral_constant<int, (j >= 0 ? j : 0)>{}); });
+#ifndef IRLOSC_LANE_TASK_IN
+#define IRLOSC_LANE_TASK_IN 1
+#endif
+    if constexpr (IRLOSC_LANE_TASK_IN) {
+        // Part 1 of the task signal -- calc_error, velocity limit, gains, stiffness (osc.py:101-118,70-99,160-168) [+ the wrench,
+        // osc.py:184-185] -- computed HERE, device by device, while the first rows of M are on their way: this wave has nothing else to do
+        // until they arrive (one wave per SIMD), so the ~450 instructions per device are free, and the task pass (58 us per train, 230 MB
+        // of traffic) is not launched at all.  Same formulas in the same order as osc_task_rows_fromq_kernel (task_rot, atan2,
+        // apply_gains6_fast).  The rows go to their CANONICAL positions in LDS (padding rows: zero).
+#pragma unroll
+        for (int r = 0; r < K; ++r) s_w[r * 64 + lane] = 0.0;
+#pragma unroll 1
+        for (int dv = 0; dv < nd; ++dv) {
+            const DevMeta dm = p.dev[dv];
+            const int e0 = lt.map.ee_e0[dv];
+            const TIN* __restrict__ tgp = p.tgt + ((size_t)bc * nd + dv) * 7;
+            const TIN* __restrict__ gp = p.gains + (p.gains_per_instance ? (size_t)bc * nd * IRLOSC_GAIN_WORDS : 0) + dv * IRLOSC_GAIN_WORDS;
+            const TIN* __restrict__ wp = wbase + wsel * (((size_t)bc * nd + dv) * 6);
+            double ee[7], tg[7], g[IRLOSC_GAIN_WORDS], wr6[6];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) ee[i] = col[(size_t)(unsigned)(e0 + i) * 64];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) tg[i] = (double)tgp[i];
+#pragma unroll
+            for (int i = 0; i < IRLOSC_GAIN_WORDS; ++i) g[i] = (double)gp[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) wr6[i] = (double)wp[wsel * i];
+            double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (dm.calc & 1u) { e[0] = ee[0] - tg[0]; e[1] = ee[1] - tg[1]; e[2] = ee[2] - tg[2]; }
+            if (dm.calc & 2u) {
+                const r16::TaskRot R = r16::task_rot(ee, tg);
+#pragma unroll
+                for (int a2 = 0; a2 < 3; ++a2) {
+                    double ay, ax;
+                    R.angle_args(a2, ay, ax);
+                    e[3 + a2] = atan2(ay, ax);
+                }
+            }
+            r16::apply_gains6_fast(g, e);
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if (dm.dofmask & (1u << i)) { s_w[lt.map.canon[dm.row0 + cnt] * 64 + lane] = e[i] + wr6[i]; ++cnt; }
+        }
+    } else
     {   // Part 1 of the task signal [+ the wrench]: u_task_all + ext_f (osc.py:184-185), canonical order (padding: the entry of zeros;
         // device 0, component 0 -- a valid address, times zero).  Requested behind the first rows of M -- one round trip for all of it --
         // and parked in LDS: the values are next needed behind the k x k stage, and any register they held on the way was spilled, load

@@ -13,6 +13,8 @@ struct RowMap {
     int32_t comp[IRLOSC_MAX_K];     // component 0..5 of (jacp, jacr) the row takes (device.py:131-132); 0 for padding
     int32_t ext[IRLOSC_MAX_K];      // its row in targets order (the task pass's row, osc.py:134-138); 0 for padding
     int32_t dev[IRLOSC_MAX_K];      // its target device; 0 for padding
+    int32_t canon[IRLOSC_MAX_K];    // the other way round: task row (targets order) -> canonical row
+    int32_t ee_e0[IRLOSC_MAX_DEV];  // target device -> first entry of its end effector's pose in the exchange block (x y z qw qx qy qz)
 };
 
 // Records of the robots handed to the eigen pass, in doubles

@@ -44,6 +44,9 @@ int launch_lane_osc<IRLOSC_LANE_TIN>(const Row16Train<IRLOSC_LANE_TIN>& tr, cons
 }
 
 #ifdef IRLOSC_LANE_PLAN
+// does the lane kernel compute part 1 of the task signal itself (then no task pass is launched ahead of it)?
+int lane_task_in_kernel() { return IRLOSC_LANE_TASK_IN; }
+
 // Which instantiation takes a layout, and its row map: the task rows grouped by end-effector body (candidates of the compiled tree in
 // body order), each group padded to the tier's rows.  -1: no instantiation (an EE body that is not a candidate cannot happen on a
 // model that matched the tree; more rows on one body than any tier holds can: e.g. a base asked for three rotations) -- the fused
@@ -73,7 +76,11 @@ int lane_plan(const FeModel& h, lane::RowMap* map) {
     int r = 0;
     for (int ci = 0; ci < 3; ++ci)
         for (int s = 0; s < lane::TIER_ROWS[tier][ci]; ++s, ++r)
-            if (s < cnt[ci]) { map->real |= 1u << r; map->comp[r] = comp[ci][s]; map->ext[r] = ext[ci][s]; map->dev[r] = dev[ci][s]; }
+            if (s < cnt[ci]) {
+                map->real |= 1u << r; map->comp[r] = comp[ci][s]; map->ext[r] = ext[ci][s]; map->dev[r] = dev[ci][s];
+                map->canon[ext[ci][s]] = r;
+            }
+    for (int d = 0; d < h.ndev; ++d) map->ee_e0[d] = FeTopo<TopoDualUr5>::ee_index(h.ee_body[d]);
     return tier;
 }
 #endif
