@@ -9,8 +9,8 @@ shift; shift; shift
 export TMPDIR=/tmp
 # The bench command itself at its default length (1 000 untimed + 200 warm-up + 2 000 timed steps = 400 trains): a short command
 # (round 3: 168 steps) is over before the clocks have settled and its per-dispatch average is not the steady state.
-B="python bench.py --no-cpu-baseline --no-secondary --no-from-q --no-end-to-end $*"
-BP="python bench.py --steps 256 --warmup 64 --preroll 480 --no-cpu-baseline --no-secondary --no-from-q --no-end-to-end $*"   # PMC passes (slow under counters)
+B="python bench.py --sustained-steps 8000 --no-cpu-baseline --no-secondary --no-from-q --no-end-to-end $*"      # (the sustained leg as in rounds 4-5: 100 000 steps are 12 500 traced dispatches)
+BP="python bench.py --steps 256 --warmup 64 --preroll 480 --sustained-steps 0 --no-cpu-baseline --no-secondary --no-from-q --no-end-to-end $*"   # PMC passes (slow under counters)
 rm -rf gpurun_out/prof_$tag gpurun_out/pmc_fetch_$tag gpurun_out/pmc_write_$tag
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o prof -- $B > gpurun_out/bench_prof_$tag.log 2>&1
 grep -a "^{\"metric\"" gpurun_out/bench_prof_$tag.log | tail -1 > gpurun_out/bench_under_rocprof_$tag.json
