@@ -78,6 +78,25 @@ struct irlosc_ctx {
     int fused_train = R16_TRAIN;
     // the OSC step of the fused path in lane-per-robot form (osc_lane.hpp): the instantiation that holds the layout (-1: none: the row16
     // FROMQ kernel stays), its row map, the records + counters of the eigen pass behind it (allocated by the first fused step)
+    // Consecutive trains of irlosc_step_resident_from_q alternate between two BANKS of buffers (exchange buffers, eigen-pass records,
+    // counters, give-up lists, output sets) on two streams: the walk and the lane kernel run one wave per SIMD, eight waves deep per train,
+    // so every kernel boundary leaves SIMDs idle for up to a wave's lifetime (~50 us) -- measured as a fixed ~126 us per train of 990 us
+    // (trains of 8 / 4 / 2 steps: 124 / 140 / 163 us per step).  With the NEXT train independent and on another stream its first waves
+    // fill those tails.  Bank 0 = the buffers above on `stream`; bank 1 is allocated by the first call that chains more than one train.
+    struct Bank {
+        hipStream_t st = nullptr;
+        hipEvent_t done = nullptr;
+        double* xside[R16_TRAIN] = {};
+        double* lane_rec[R16_TRAIN] = {};
+        int32_t* lane_count = nullptr;
+        int32_t* list[R16_TRAIN] = {};
+        int32_t* count = nullptr;
+        void* u[R16_TRAIN] = {};
+        uint32_t* flags[R16_TRAIN] = {};
+    } bank1;
+    hipEvent_t ev_join = nullptr;
+    int fq_overlap = 1;                    // IRLOSC_FQ_OVERLAP=0: one bank, one stream (A/B measurements, tests)
+    int32_t* count_cur = nullptr;          // give-up counters of the most recent train (irlosc_giveup_counts)
     int lane_tier = -1;
     lane::RowMap lane_map{};
     double* lane_rec[R16_TRAIN] = {};
@@ -191,6 +210,18 @@ static void free_all(irlosc_ctx* c) {
     for (int k = 0; k < R16_TRAIN; ++k) if (c->fe_xside[k]) (void)hipFree(c->fe_xside[k]);
     for (int k = 0; k < R16_TRAIN; ++k) if (c->dtrows[k]) (void)hipFree(c->dtrows[k]);
     for (int k = 0; k < R16_TRAIN; ++k) if (c->lane_rec[k]) (void)hipFree(c->lane_rec[k]);
+    for (int k = 0; k < R16_TRAIN; ++k) {
+        if (c->bank1.xside[k]) (void)hipFree(c->bank1.xside[k]);
+        if (c->bank1.lane_rec[k]) (void)hipFree(c->bank1.lane_rec[k]);
+        if (c->bank1.list[k]) (void)hipFree(c->bank1.list[k]);
+        if (c->bank1.u[k]) (void)hipFree(c->bank1.u[k]);
+        if (c->bank1.flags[k]) (void)hipFree(c->bank1.flags[k]);
+    }
+    if (c->bank1.lane_count) (void)hipFree(c->bank1.lane_count);
+    if (c->bank1.count) (void)hipFree(c->bank1.count);
+    if (c->bank1.done) (void)hipEventDestroy(c->bank1.done);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->bank1.st) (void)hipStreamDestroy(c->bank1.st);
     if (c->dlane_count) (void)hipFree(c->dlane_count);
     for (double* p : c->dqpos) if (p) (void)hipFree(p);
     for (double* p : c->dqvel) if (p) (void)hipFree(p);
@@ -738,6 +769,7 @@ static int row16_train(irlosc_ctx* c, const KParams<T>* ps, int n, bool tree, hi
     Row16Train<T> tr;
     memset(&tr, 0, sizeof tr);
     if (reset) HIPCHK(c, hipMemsetAsync(c->dr16_count, 0, R16_TRAIN * sizeof(int32_t), st));
+    c->count_cur = c->dr16_count;
     const bool rows = ensure_trows(c, n);
     for (int i = 0; i < n; ++i) {
         const int o = pos ? pos[i] : i;
@@ -1037,7 +1069,7 @@ extern "C" int irlosc_giveup_counts(irlosc_ctx* c, int32_t* out) {
     for (int i = 0; i < R16_TRAIN; ++i) out[i] = 0;
     if (c->kernel != IRLOSC_KERNEL_ROW16) return IRLOSC_OK;
     HIPCHK(c, hipSetDevice(c->cfg.hip_device));
-    HIPCHK(c, hipMemcpyAsync(out, c->dr16_count, R16_TRAIN * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, c->count_cur ? c->count_cur : c->dr16_count, R16_TRAIN * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return IRLOSC_OK;
 }
@@ -1134,6 +1166,8 @@ extern "C" int irlosc_set_model(irlosc_ctx* c, const irlosc_model* m) {
         // two-kernel path through dense records (A/B measurements).
         const char* e = getenv("IRLOSC_FUSED");
         c->fused = c->fe_lane && c->kernel == IRLOSC_KERNEL_ROW16 && !(e && !strcmp(e, "0"));
+        const char* ov = getenv("IRLOSC_FQ_OVERLAP");      // "0": consecutive fused trains on one stream (A/B measurements, tests)
+        c->fq_overlap = !(ov && !strcmp(ov, "0"));
         const char* t = getenv("IRLOSC_FUSED_TRAIN");      // steps per launch pair of the fused path (A/B measurements)
         if (t && atoi(t) >= 1 && atoi(t) <= R16_TRAIN) c->fused_train = atoi(t);
     }
@@ -1307,15 +1341,16 @@ static int ensure_xside(irlosc_ctx* c, int n) {
 // eigen stage hands over get their dense records from the wave-per-robot front end (worklist form) and go through the
 // generic kernel like on the record path.  Dense M / J exist in HBM for those robots only.
 template <typename T>
-static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, hipStream_t st) {
+static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, const irlosc_ctx::Bank& bk) {
     if (n < 1 || n > R16_TRAIN) return fail(c, IRLOSC_ERR_STATE, "train of %d steps", n);
+    const hipStream_t st = bk.st;
     FeLaneTrain ft;
     memset(&ft, 0, sizeof ft);
     Row16Train<T> tr;
     memset(&tr, 0, sizeof tr);
     FeGenericArgs<T> ga;
     memset(&ga, 0, sizeof ga);
-    HIPCHK(c, hipMemsetAsync(c->dr16_count, 0, R16_TRAIN * sizeof(int32_t), st));
+    HIPCHK(c, hipMemsetAsync(bk.count, 0, R16_TRAIN * sizeof(int32_t), st));
     ft.B = ga.B = B;
     for (int i = 0; i < n; ++i) {
         const int sl = slots[i];
@@ -1326,13 +1361,13 @@ static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, hipStream_
             HIPCHK(c, (hipError_t)launch_q_layout(c->dqpos[sl], c->dqvel[sl], c->dqt[sl], std::max(1, c->has_q[sl]), c->cfg.n, st));
         }
         ft.qt[i] = c->dqt[sl];
-        ft.side[i] = c->fe_xside[i];
+        ft.side[i] = bk.xside[i];
         fill_params<T>(c, tr.p[i], B, c->dM[sl], c->dJ[sl], c->ddq[sl], c->dbias[sl], c->dee[sl], c->dtgt[sl],
-                       c->has_tvel[sl] ? c->dtvel[sl] : nullptr, c->has_wrench[sl] ? c->dwrench[sl] : nullptr, c->du_set[i], c->dflags_set[i]);
-        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[i], c->dr16_count + i, c->fe_xside[i], c->dqvel[sl], c->dtables, c->span_next};
+                       c->has_tvel[sl] ? c->dtvel[sl] : nullptr, c->has_wrench[sl] ? c->dwrench[sl] : nullptr, bk.u[i], bk.flags[i]);
+        tr.x[i] = Row16Extra{c->dzeros, bk.list[i], bk.count + i, bk.xside[i], c->dqvel[sl], c->dtables, c->span_next};
         ga.out[i] = FeOut<T>{(T*)c->dM[sl], (T*)c->dJ[sl], (T*)c->ddq[sl], (T*)c->dbias[sl], (T*)c->dee[sl]};
-        ga.list[i] = c->dr16_list[i];
-        ga.count[i] = c->dr16_count + i;
+        ga.list[i] = bk.list[i];
+        ga.count[i] = bk.count + i;
     }
     // lane form of the OSC step: not with target velocities (branch B of osc.py:173-177 reads dx between the two halves of the task
     // signal: the row16 FROMQ kernel keeps those trains)
@@ -1340,14 +1375,14 @@ static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, hipStream_
     lane::LaneTrain lt;
     memset(&lt, 0, sizeof lt);
     for (int i = 0; i < n && use_lane; ++i) {
-        if (c->has_tvel[slots[i]] || !c->lane_rec[i]) use_lane = false;
+        if (c->has_tvel[slots[i]] || !bk.lane_rec[i] || !bk.lane_count) use_lane = false;
         lt.qt[i] = c->dqt[slots[i]];
-        lt.rec[i] = c->lane_rec[i];
-        lt.rec_count[i] = c->dlane_count + i;
+        lt.rec[i] = bk.lane_rec[i];
+        lt.rec_count[i] = bk.lane_count + i;
     }
     if (use_lane) {
         lt.map = c->lane_map;
-        HIPCHK(c, hipMemsetAsync(c->dlane_count, 0, R16_TRAIN * sizeof(int32_t), st));
+        HIPCHK(c, hipMemsetAsync(bk.lane_count, 0, R16_TRAIN * sizeof(int32_t), st));
     }
     if (c->tev_begin) HIPCHK(c, hipEventRecord(c->tev_begin, st));
     HIPCHK(c, (hipError_t)(c->fe_lane_s ? launch_frontend_lane_compact_dual_ur5_s(c->dmodel, ft, n, st)
@@ -1370,8 +1405,52 @@ static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, hipStream_
     return IRLOSC_OK;
 }
 
+// bank 0 = the context's own buffers on its stream
+static irlosc_ctx::Bank bank0_of(irlosc_ctx* c) {
+    irlosc_ctx::Bank b;
+    b.st = c->stream;
+    for (int i = 0; i < R16_TRAIN; ++i) {
+        b.xside[i] = c->fe_xside[i]; b.lane_rec[i] = c->lane_rec[i]; b.list[i] = c->dr16_list[i];
+        b.u[i] = c->du_set[i]; b.flags[i] = c->dflags_set[i];
+    }
+    b.lane_count = c->dlane_count;
+    b.count = c->dr16_count;
+    return b;
+}
+
+// The second bank (see irlosc_ctx::Bank): same sizes as the first.  -> 0, or 1: not available (out of memory: one bank, no overlap)
+static int ensure_bank1(irlosc_ctx* c, int n) {
+    irlosc_ctx::Bank& b = c->bank1;
+    const size_t Bm = (size_t)c->cfg.max_batch, waves = (Bm + 63) / 64;
+    auto get = [](void** p, size_t bytes) { return *p || hipMalloc(p, bytes) == hipSuccess; };
+    bool ok = true;
+    if (!b.st) ok = ok && hipStreamCreateWithFlags(&b.st, hipStreamNonBlocking) == hipSuccess;
+    if (!b.done) ok = ok && hipEventCreateWithFlags(&b.done, hipEventDisableTiming) == hipSuccess;
+    if (!c->ev_join) ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
+    ok = ok && get((void**)&b.count, R16_TRAIN * sizeof(int32_t)) && get((void**)&b.lane_count, R16_TRAIN * sizeof(int32_t));
+    for (int i = 0; ok && i < n && i < R16_TRAIN; ++i) {
+        ok = ok && get((void**)&b.xside[i], waves * c->fe_xentries * 64 * sizeof(double)) && get((void**)&b.list[i], Bm * sizeof(int32_t)) &&
+             get(&b.u[i], Bm * c->cfg.n * c->esz) && get((void**)&b.flags[i], Bm * sizeof(uint32_t));
+        if (ok && c->lane_tier >= 0 && !b.lane_rec[i]) {
+            const size_t bytes = Bm * lane::REC_DOUBLES * sizeof(double);
+            ok = hipMalloc((void**)&b.lane_rec[i], bytes) == hipSuccess && hipMemsetAsync(b.lane_rec[i], 0, bytes, c->stream) == hipSuccess;
+            if (!ok) b.lane_rec[i] = nullptr;
+        }
+    }
+    if (!ok) { (void)hipGetLastError(); return 1; }
+    return 0;
+}
+
 static int fused_resident(irlosc_ctx* c, int first_slot, int B, int iters) {
-    int done = 0;
+    int done = 0, t = 0;
+    const irlosc_ctx::Bank b0 = bank0_of(c);
+    // more than one train: alternate banks / streams so that a train's first waves fill the tails of the one before (irlosc_ctx::Bank)
+    const bool two = c->fq_overlap && iters > c->fused_train && ensure_bank1(c, c->fused_train) == 0;
+    if (two) {
+        HIPCHK(c, hipEventRecord(c->ev_join, c->stream));              // bank 1's stream starts behind whatever the main stream holds
+        HIPCHK(c, hipStreamWaitEvent(c->bank1.st, c->ev_join, 0));
+    }
+    const irlosc_ctx::Bank* last = &b0;
     while (done < iters) {
         const int n = std::min(c->fused_train, iters - done);
         int slots[R16_TRAIN];
@@ -1380,13 +1459,21 @@ static int fused_resident(irlosc_ctx* c, int first_slot, int B, int iters) {
             int rc = check_slot_q(c, slots[i], B);
             if (rc) return rc;
         }
-        int rc = c->cfg.dtype == IRLOSC_F64 ? fused_train<double>(c, slots, n, B, c->stream) : fused_train<float>(c, slots, n, B, c->stream);
+        const irlosc_ctx::Bank& bk = (two && (t & 1)) ? c->bank1 : b0;
+        int rc = c->cfg.dtype == IRLOSC_F64 ? fused_train<double>(c, slots, n, B, bk) : fused_train<float>(c, slots, n, B, bk);
         if (rc) return rc;
+        last = &bk;
         c->cur = n - 1;
         done += n;
+        ++t;
     }
-    c->du = c->du_set[c->cur];
-    c->dflags = c->dflags_set[c->cur];
+    if (two) {                                                         // and the main stream continues behind both
+        HIPCHK(c, hipEventRecord(c->bank1.done, c->bank1.st));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->bank1.done, 0));
+    }
+    c->du = last->u[c->cur];
+    c->dflags = last->flags[c->cur];
+    c->count_cur = last->count;
     return IRLOSC_OK;
 }
 
