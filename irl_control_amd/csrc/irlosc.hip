@@ -93,9 +93,11 @@ struct irlosc_ctx {
         int32_t* count = nullptr;
         void* u[R16_TRAIN] = {};
         uint32_t* flags[R16_TRAIN] = {};
+        double* trows[R16_TRAIN] = {};     // (dense-record trains: rows of the task pass)
     } bank1;
     hipEvent_t ev_join = nullptr;
     int fq_overlap = 1;                    // IRLOSC_FQ_OVERLAP=0: one bank, one stream (A/B measurements, tests)
+    int r16_overlap = 1;                   // IRLOSC_R16_OVERLAP=0: the same switch for the trains of irlosc_step_resident on dense records
     int32_t* count_cur = nullptr;          // give-up counters of the most recent train (irlosc_giveup_counts)
     int lane_tier = -1;
     lane::RowMap lane_map{};
@@ -216,6 +218,7 @@ static void free_all(irlosc_ctx* c) {
         if (c->bank1.list[k]) (void)hipFree(c->bank1.list[k]);
         if (c->bank1.u[k]) (void)hipFree(c->bank1.u[k]);
         if (c->bank1.flags[k]) (void)hipFree(c->bank1.flags[k]);
+        if (c->bank1.trows[k]) (void)hipFree(c->bank1.trows[k]);
     }
     if (c->bank1.lane_count) (void)hipFree(c->bank1.lane_count);
     if (c->bank1.count) (void)hipFree(c->bank1.count);
@@ -291,6 +294,8 @@ static int create_impl(irlosc_ctx* c) {
             // rows buffers are allocated by the first train that needs them (ensure_trows)
             const char* e = getenv("IRLOSC_TASK_PASS");
             c->task_pass = !(e && !strcmp(e, "0"));
+            const char* ov = getenv("IRLOSC_R16_OVERLAP");
+            c->r16_overlap = !(ov && !strcmp(ov, "0"));
         }
         HIPCHK(nullptr, hipMemsetAsync(c->dr16_count, 0, R16_TRAIN * sizeof(int32_t), c->stream));
     }
@@ -759,22 +764,26 @@ static bool ensure_trows(irlosc_ctx* c, int n) {
     return true;
 }
 
+static int ensure_bank1(irlosc_ctx* c, int n, bool fused);
+
 template <typename T>
 static int row16_train(irlosc_ctx* c, const KParams<T>* ps, int n, bool tree, hipStream_t st, const int* pos = nullptr,
-                       bool reset = true) {
+                       bool reset = true, const irlosc_ctx::Bank* bk = nullptr) {
     // pos[i] = step of the whole train that sub-train step i is (a train that mixes tree-form and dense slots goes out as two
     // sub-trains): give-up list and counter are those of the ORIGINAL step, and only the first sub-train zeroes the counters, so
     // that irlosc_giveup_counts reports every step of the train at its own index.
     if (n < 1 || n > R16_TRAIN) return fail(c, IRLOSC_ERR_STATE, "train of %d steps", n);
     Row16Train<T> tr;
     memset(&tr, 0, sizeof tr);
-    if (reset) HIPCHK(c, hipMemsetAsync(c->dr16_count, 0, R16_TRAIN * sizeof(int32_t), st));
-    c->count_cur = c->dr16_count;
-    const bool rows = ensure_trows(c, n);
+    int32_t* cnt = bk ? bk->count : c->dr16_count;      // (bk: the second bank of an overlapped train, see irlosc_ctx::Bank)
+    if (reset) HIPCHK(c, hipMemsetAsync(cnt, 0, R16_TRAIN * sizeof(int32_t), st));
+    c->count_cur = cnt;
+    const bool rows = bk ? (c->task_pass && bk->trows[n - 1] != nullptr) : ensure_trows(c, n);
     for (int i = 0; i < n; ++i) {
         const int o = pos ? pos[i] : i;
         tr.p[i] = ps[i];
-        tr.x[i] = Row16Extra{c->dzeros, c->dr16_list[o], c->dr16_count + o, nullptr, nullptr, nullptr, c->span_next, rows ? c->dtrows[i] : nullptr};
+        tr.x[i] = Row16Extra{c->dzeros, bk ? bk->list[o] : c->dr16_list[o], cnt + o, nullptr, nullptr, nullptr, c->span_next,
+                             rows ? (bk ? bk->trows[i] : c->dtrows[i]) : nullptr};
     }
     if (c->tev_begin) HIPCHK(c, hipEventRecord(c->tev_begin, st));
     int rc = launch_row16<T>(tr, n, tree, st);
@@ -891,8 +900,17 @@ template <typename T>
 static int row16_resident(irlosc_ctx* c, int first_slot, int B, int iters, const std::vector<hipEvent_t>* evs, int skip) {
     int done = 0, launch_no = 0;
     const hipEvent_t outer_b = c->tev_begin, outer_e = c->tev_end;      // irlosc_time_trains brackets a one-train call itself
+    // more than one train, untimed: odd trains on the second bank / stream, so that their first waves fill the tail of the train before
+    // (a call of exactly one full train already allocates the second bank: a caller's warm-up then pays for it, not its timed loop)
+    const bool two = c->r16_overlap && !evs && iters >= R16_TRAIN && ensure_bank1(c, R16_TRAIN, false) == 0;
+    if (two) {
+        HIPCHK(c, hipEventRecord(c->ev_join, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->bank1.st, c->ev_join, 0));
+    }
+    const irlosc_ctx::Bank* last_bank = nullptr;
     while (done < iters) {
         const int n = std::min((int)R16_TRAIN, iters - done);
+        const irlosc_ctx::Bank* bk = (two && (launch_no & 1)) ? &c->bank1 : nullptr;
         KParams<T> ps[2][R16_TRAIN];        // [1]: steps whose slot qualifies for the tree form, [0]: the others
         int pos[2][R16_TRAIN];              // step of the train each sub-train step is
         int cnt[2] = {0, 0};
@@ -904,7 +922,7 @@ static int row16_resident(irlosc_ctx* c, int first_slot, int B, int iters, const
             pos[kind][cnt[kind]] = i;
             fill_params<T>(c, ps[kind][cnt[kind]++], B, c->dM[slot], c->dJ[slot], c->ddq[slot], c->dbias[slot], c->dee[slot], c->dtgt[slot],
                            c->has_tvel[slot] ? c->dtvel[slot] : nullptr, c->has_wrench[slot] ? c->dwrench[slot] : nullptr,
-                           c->du_set[i], c->dflags_set[i]);
+                           bk ? bk->u[i] : c->du_set[i], bk ? bk->flags[i] : c->dflags_set[i]);
         }
         const bool timed = evs && launch_no >= skip && 2 * (launch_no - skip) + 1 < (int)evs->size();
         hipEvent_t eb = timed ? (*evs)[2 * (launch_no - skip)] : outer_b, ee = timed ? (*evs)[2 * (launch_no - skip) + 1] : outer_e;
@@ -913,16 +931,21 @@ static int row16_resident(irlosc_ctx* c, int first_slot, int B, int iters, const
             if (!cnt[kind]) continue;
             c->tev_begin = kind == first ? eb : nullptr;              // the event pair brackets the whole train
             c->tev_end = kind == last ? ee : nullptr;
-            int rc = row16_train<T>(c, ps[kind], cnt[kind], kind == 1, c->stream, pos[kind], kind == first);
+            int rc = row16_train<T>(c, ps[kind], cnt[kind], kind == 1, bk ? bk->st : c->stream, pos[kind], kind == first, bk);
             c->tev_begin = c->tev_end = nullptr;
             if (rc) return rc;
         }
+        last_bank = bk;
         c->cur = n - 1;
         done += n;
         ++launch_no;
     }
-    c->du = c->du_set[c->cur];
-    c->dflags = c->dflags_set[c->cur];
+    if (two) {
+        HIPCHK(c, hipEventRecord(c->bank1.done, c->bank1.st));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->bank1.done, 0));
+    }
+    c->du = last_bank ? last_bank->u[c->cur] : c->du_set[c->cur];
+    c->dflags = last_bank ? last_bank->flags[c->cur] : c->dflags_set[c->cur];
     return IRLOSC_OK;
 }
 
@@ -1419,7 +1442,7 @@ static irlosc_ctx::Bank bank0_of(irlosc_ctx* c) {
 }
 
 // The second bank (see irlosc_ctx::Bank): same sizes as the first.  -> 0, or 1: not available (out of memory: one bank, no overlap)
-static int ensure_bank1(irlosc_ctx* c, int n) {
+static int ensure_bank1(irlosc_ctx* c, int n, bool fused) {
     irlosc_ctx::Bank& b = c->bank1;
     const size_t Bm = (size_t)c->cfg.max_batch, waves = (Bm + 63) / 64;
     auto get = [](void** p, size_t bytes) { return *p || hipMalloc(p, bytes) == hipSuccess; };
@@ -1429,8 +1452,9 @@ static int ensure_bank1(irlosc_ctx* c, int n) {
     if (!c->ev_join) ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     ok = ok && get((void**)&b.count, R16_TRAIN * sizeof(int32_t)) && get((void**)&b.lane_count, R16_TRAIN * sizeof(int32_t));
     for (int i = 0; ok && i < n && i < R16_TRAIN; ++i) {
-        ok = ok && get((void**)&b.xside[i], waves * c->fe_xentries * 64 * sizeof(double)) && get((void**)&b.list[i], Bm * sizeof(int32_t)) &&
-             get(&b.u[i], Bm * c->cfg.n * c->esz) && get((void**)&b.flags[i], Bm * sizeof(uint32_t));
+        ok = ok && get((void**)&b.list[i], Bm * sizeof(int32_t)) && get(&b.u[i], Bm * c->cfg.n * c->esz) && get((void**)&b.flags[i], Bm * sizeof(uint32_t));
+        if (!fused) { if (ok && c->task_pass) ok = get((void**)&b.trows[i], Bm * 16 * sizeof(double)); continue; }
+        ok = ok && get((void**)&b.xside[i], waves * c->fe_xentries * 64 * sizeof(double));
         if (ok && c->lane_tier >= 0 && !b.lane_rec[i]) {
             const size_t bytes = Bm * lane::REC_DOUBLES * sizeof(double);
             ok = hipMalloc((void**)&b.lane_rec[i], bytes) == hipSuccess && hipMemsetAsync(b.lane_rec[i], 0, bytes, c->stream) == hipSuccess;
@@ -1445,7 +1469,7 @@ static int fused_resident(irlosc_ctx* c, int first_slot, int B, int iters) {
     int done = 0, t = 0;
     const irlosc_ctx::Bank b0 = bank0_of(c);
     // more than one train: alternate banks / streams so that a train's first waves fill the tails of the one before (irlosc_ctx::Bank)
-    const bool two = c->fq_overlap && iters > c->fused_train && ensure_bank1(c, c->fused_train) == 0;
+    const bool two = c->fq_overlap && iters >= c->fused_train && c->fused_train > 1 && !c->tev_begin && ensure_bank1(c, c->fused_train, true) == 0;
     if (two) {
         HIPCHK(c, hipEventRecord(c->ev_join, c->stream));              // bank 1's stream starts behind whatever the main stream holds
         HIPCHK(c, hipStreamWaitEvent(c->bank1.st, c->ev_join, 0));
