@@ -690,7 +690,7 @@ def _bench_line(extra_args, env_extra, launcher):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     args = ["bench.py", "--steps", "16", "--warmup", "8", "--preroll", "0", "--batch", "2048", "--no-cpu-baseline",
-            "--no-secondary", "--no-from-q"] + extra_args
+            "--no-secondary", "--no-from-q", "--sustained-steps", "4000"] + extra_args
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
     env.update(env_extra)
     cmd = [sys.executable] + (launcher or []) + args
@@ -739,7 +739,7 @@ def test_bench_line_with_the_cpu_legs_on_the_physical_workload(fail_hand_over):
     if fail_hand_over:
         env["IRLOSC_BENCH_FAIL_MINT"] = "1"
     cmd = [sys.executable, "bench.py", "--steps", "16", "--warmup", "8", "--preroll", "0", "--batch", "4096", "--cpu-seconds", "0.5",
-           "--no-secondary", "--no-from-q"]
+           "--no-secondary", "--no-from-q", "--sustained-steps", "4000"]
     p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
@@ -1682,6 +1682,8 @@ def _bench_run(args, env_extra, timeout=1500):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
     env.update(env_extra)
+    if "--sustained-steps" not in args:      # (bench.py's default long leg is ~10 s at the headline batch: the tests ask for a short one)
+        args = list(args) + ["--sustained-steps", "8000"]
     p = subprocess.run([sys.executable, "bench.py"] + args, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     return p.returncode, (json.loads(lines[-1]) if lines else None), len(lines), p.stderr
@@ -1746,7 +1748,7 @@ def test_bench_line_end_to_end_and_untraced_roofline():
     assert 5 < e["tick_b1_us"]["median"] < 2000 and e["upload_raw_step"]["value"] > 0
     assert line["data"].startswith("synthetic")
     su = line["sustained"]
-    assert su["steps"] == 100000 and su["value"] > 0 and 0.5 < su["value"] / line["value"] < 2.0      # (default: ~10 s at the headline batch)
+    assert su["steps"] == 8000 and su["value"] > 0 and 0.5 < su["value"] / line["value"] < 2.0
     # what the round claims sits inside the first 24 keys of the two dicts the driver's record truncates (bench.CONFIG_FIRST / ROOFLINE_FIRST)
     ck, rk = list(c)[:24], list(r)[:24]
     for must in ("workload", "sustained_value", "parity_n_outside_domain", "end_to_end_host_arrays_value", "end_to_end_pcie_GBps", "rccl_ranks"):
