@@ -377,7 +377,7 @@ def _fromq_traffic(name, B):
     path, FETCH_SIZE x2 + WRITE_SIZE; an upper bound for the gathered 8-byte loads), or None."""
     if "fused" not in name:
         return None
-    keys = (["fromq_lane:walk", "fromq_lane:task_pass", "fromq_lane:osc_lane", "fromq_lane:eigen_pass"] if "osc_lane" in name
+    keys = (["fromq_lane:walk", "fromq_lane:osc_lane", "fromq_lane:eigen_pass"] if "osc_lane" in name
             else ["osc_frontend_lane_compact_dual_ur5", "osc_row16_f64_n25_k13_fromq"])
     ents = [measured_profile(k) for k in keys]
     if not all(e and e.get("instances") == B and e.get("steps_per_launch") == ents[0].get("steps_per_launch") for e in ents):

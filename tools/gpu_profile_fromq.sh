@@ -19,7 +19,6 @@ if [ -n "$fdb" ] && [ -n "$wdb" ]; then
   cat gpurun_out/fromq_pmc_fetch_write_$tag.txt
   if grep -q osc_lane_kernel gpurun_out/fromq_kernel_stats_$tag.txt; then      # round 6: the OSC step one lane per robot + its eigen pass
     python tools/pmc_traffic.py "$fdb" "$wdb" osc_frontend_lane_compact "fromq_lane:walk" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8
-    python tools/pmc_traffic.py "$fdb" "$wdb" osc_task_rows_fromq "fromq_lane:task_pass" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8
     python tools/pmc_traffic.py "$fdb" "$wdb" osc_lane_kernel "fromq_lane:osc_lane" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8
     python tools/pmc_traffic.py "$fdb" "$wdb" osc_lane_eigen_kernel "fromq_lane:eigen_pass" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8
   else
