@@ -985,6 +985,43 @@ def test_fused_from_q_against_the_chained_oracles():
     assert dom.sum() >= B // 2 and rel_err(u, ref)[dom].max() <= TOL64
 
 
+@pytest.mark.parametrize("cfg", ["k13", "k12_admit", "k7"])
+def test_fused_lane_path_full_size_oracle_on_every_robot(cfg):
+    """The fused path (lane-per-robot walk -> exchange buffer -> lane-per-robot OSC step -> eigen pass on compact records) at the
+    headline size: 65 536 robots from (qpos, qvel), a seventh of them with stretched / folded arms.  The oracle runs on EVERY robot:
+    oracle/osc_oracle.generate_batch on the dense records of the same states (GPU front end, itself held to oracle/rigid_body.py at
+    1e-10 by test_frontend_records_themselves and chained end to end by the test above): <= 1e-5 in the parity domain, PINV /
+    TRUNCATED flags = the reference's branch (osc.py:51-55).  Tiers (1, 6, 6) [k13, k12 + admittance] and (1, 3, 3) [k7]."""
+    B = 65536
+    lay, gains, g, model, osc, states = _from_q_setup(cfg, B, np.float64, seed=611, singular_every=7)
+    if lay.admittance:
+        osc.frontend()
+        rec0 = osc.download_records(0)
+        osc.upload(rec0["M"], rec0["J"], rec0["dq"], rec0["bias"], rec0["ee_pose"], g["wrench"])   # the wrench only arrives with records ...
+        osc.upload_q(*states[0])                                                                  # ... and stays with the slot
+        osc.set_targets(g["tgt_pose"])
+    assert "osc_lane" in osc.from_q_name, osc.from_q_name
+    u, fl = osc.step_q(return_flags=True)
+    assert np.all(np.isfinite(u)) and not np.any(fl & (_lib.FLAG_NONFINITE | _lib.FLAG_M_NOT_PD))
+    osc.frontend()
+    rec = osc.download_records(0)
+    osc.close()
+    rec["tgt_pose"] = g["tgt_pose"]
+    if lay.admittance:
+        rec["wrench"] = g["wrench"]
+    ref, dom, pinv, trunc, _ = oracle_on_all(lay.as_oracle_dict(), gains, rec)
+    err = rel_err(u.astype(np.float64), ref)
+    n_eig = int(((fl & _lib.FLAG_EIGEN_PATH) != 0).sum())
+    print(f"{osc.from_q_name if False else cfg}: oracle on {B} robots ({n_eig} through the eigen pass, {int(trunc.sum())} truncating, "
+          f"{int((~dom).sum())} outside the parity domain): max rel err in the domain {err[dom].max():.2e}")
+    assert dom.mean() > 0.97
+    if cfg != "k7":
+        assert n_eig >= 800 and trunc.sum() >= 240
+    assert err[dom].max() <= TOL64, float(err[dom].max())
+    assert np.array_equal((fl[dom] & _lib.FLAG_PINV_BRANCH) != 0, pinv[dom])
+    assert np.array_equal((fl[dom] & _lib.FLAG_TRUNCATED) != 0, trunc[dom])
+
+
 def test_structural_walk_equals_the_shape_only_walk(monkeypatch):
     """The fused path's walk exists twice: with the structural constants of the Dual-UR5's MJCF compiled in (TopoDualUr5S: frames not
     rotated against / coincident with their parent's, hinges about coordinate axes through their body's origin, diagonal body-frame
