@@ -1456,7 +1456,7 @@ static int ensure_bank1(irlosc_ctx* c, int n, bool fused) {
         if (!fused) { if (ok && c->task_pass) ok = get((void**)&b.trows[i], Bm * 16 * sizeof(double)); continue; }
         ok = ok && get((void**)&b.xside[i], waves * c->fe_xentries * 64 * sizeof(double));
         if (ok && c->lane_tier >= 0 && !b.lane_rec[i]) {
-            const size_t bytes = Bm * lane::REC_DOUBLES * sizeof(double);
+            const size_t bytes = (Bm + 63) / 64 * 64 * lane::REC_DOUBLES * sizeof(double);
             ok = hipMalloc((void**)&b.lane_rec[i], bytes) == hipSuccess && hipMemsetAsync(b.lane_rec[i], 0, bytes, c->stream) == hipSuccess;
             if (!ok) b.lane_rec[i] = nullptr;
         }

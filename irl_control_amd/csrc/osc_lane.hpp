@@ -84,11 +84,56 @@ __device__ __forceinline__ void pin(double& v) { asm volatile("" : "+v"(v)); }
 // two doubles with one 16-byte store (a record is written by the few flagged lanes of a wave, every lane to a region of its own: such a
 // store costs its issue slot per LANE ADDRESS, not per byte -- the 267 eight-byte stores of a record were a third of the kernel's cycles)
 __device__ __forceinline__ void st2(double* p, const double a, const double b) { *reinterpret_cast<double2*>(p) = make_double2(a, b); }
+// uniform base (scalar registers, constant offsets folded into it / the instruction) + one 32-bit BYTE offset per lane: the address form
+// that needs no 64-bit address arithmetic per access -- and leaves the compiler no per-access address to keep (it spilled 91 of them)
+// (the base laundered through scalar registers: left visible, the compiler folds base + lane offset into ONE vector address first and
+//  then keeps -- and spills -- a 64-bit vector address per constant offset beyond the instruction's 4 KB)
+typedef const __attribute__((address_space(1))) double* gcptr;      // (explicitly global: an address that went through an asm statement is
+typedef __attribute__((address_space(1))) double* gptr;             //  otherwise a FLAT one, and its loads flat loads)
+__device__ __forceinline__ gcptr sgpr_ptr(const double* p) { gcptr q = (gcptr)p; asm volatile("" : "+s"(q)); return q; }
+__device__ __forceinline__ gptr sgpr_ptr(double* p) { gptr q = (gptr)p; asm volatile("" : "+s"(q)); return q; }
+__device__ __forceinline__ double ld_su(gcptr ubase, const uint32_t voff) {
+    return *reinterpret_cast<gcptr>(reinterpret_cast<const __attribute__((address_space(1))) char*>(ubase) + voff);
+}
+__device__ __forceinline__ double ld_su(const double* ubase, const uint32_t voff) { return ld_su((gcptr)ubase, voff); }
+__device__ __forceinline__ void st_su(gptr ubase, const uint32_t voff, const double v) {
+    *reinterpret_cast<gptr>(reinterpret_cast<__attribute__((address_space(1))) char*>(ubase) + voff) = v;
+}
+__device__ __forceinline__ void st_su(double* ubase, const uint32_t voff, const double v) { st_su((gptr)ubase, voff, v); }
 // rank among the EE hinges -> hinge (or -1)
 template <class L>
 constexpr int hinge_of_rank(int cr) { for (int j = 0; j < L::NJ; ++j) if (L::hinge_ee(j) && L::ee_rank(j) == cr) return j; return -1; }
 using r16::rsq_refined;
 using r16::rcp_refined;
+
+#ifndef IRLOSC_LANE_EIG_FORM      // 1: the eigen pass one lane per flagged robot on TRANSPOSED records; 0: four records per wave in the row16 layout
+#define IRLOSC_LANE_EIG_FORM 1
+#endif
+// Records of the flagged robots, transposed: [group of 64 records][entry][64] doubles -- what a lane writes and what a lane of the eigen
+// pass reads sits next to its neighbours' (slots of a wave's flagged lanes are consecutive: coalesced both ways).  Entries: the lower
+// triangle of A (tri(r, c)), w, the entries of J that can be non-zero (row by row, hinges ascending), the robot's index and the mask of
+// rows that are padding or exact zero rows (integers in the doubles' bits).
+template <class L>
+struct Rec {
+    static constexpr int K = L::K, NJ = L::NJ;
+    static constexpr int NA = K * (K + 1) / 2;
+    static constexpr int OW = NA;
+    static constexpr int OJ = NA + K;
+    static constexpr int jslot(int r, int j) {      // position of J[r][j] among the movable entries (-1: structurally zero)
+        if (!L::row_moved(r, j)) return -1;
+        int n = 0;
+        for (int r2 = 0; r2 < K; ++r2)
+            for (int j2 = 0; j2 < NJ; ++j2) {
+                if (r2 == r && j2 == j) return n;
+                n += L::row_moved(r2, j2) ? 1 : 0;
+            }
+        return -1;
+    }
+    static constexpr int n_j() { int n = 0; for (int r = 0; r < K; ++r) for (int j = 0; j < NJ; ++j) n += L::row_moved(r, j) ? 1 : 0; return n; }
+    static constexpr int OM = OJ + n_j();
+    static constexpr int E = OM + 2;
+    static_assert(E <= REC_DOUBLES, "the host allocates REC_DOUBLES per robot");
+};
 
 template <class TOPO, class SH, typename TIN>
 __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> tr, const LaneTrain lt) {
@@ -476,23 +521,31 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
     const bool hand = !plain && live;
     const unsigned long long hm = __ballot(hand);
     double* __restrict__ rec = nullptr;
+    uint32_t ro = 0u;                  // (transposed records: uniform base + a 32-bit BYTE offset per lane -- one address register, not one per store)
     if (hm != 0ull) {
         const int first = (int)__builtin_ctzll(hm);
         int base = 0;
         if (lane == first) base = atomicAdd(lt.rec_count[blockIdx.y], (int)__builtin_popcountll(hm));
         base = __builtin_amdgcn_readlane(base, first);
         const int slot = base + (int)__builtin_popcountll(hm & ((1ull << lane) - 1ull));
-        rec = lt.rec[blockIdx.y] + (size_t)(hand ? slot : 0) * REC_DOUBLES;
+        if constexpr (IRLOSC_LANE_EIG_FORM) { rec = lt.rec[blockIdx.y]; ro = ((uint32_t)((hand ? slot : 0) >> 6) * (uint32_t)(Rec<L>::E * 64) + (uint32_t)((hand ? slot : 0) & 63)) * 8u; }
+        else rec = lt.rec[blockIdx.y] + (size_t)(hand ? slot : 0) * REC_DOUBLES;
     }
     if (hand) {
         uint32_t nrm = 0u;
         static_for<0, K>([&](auto rc) { constexpr int r = decltype(rc)::value; nrm |= nr[r] ? (1u << r) : 0u; });
-        static_for<0, (K + 1) / 2>([&](auto pc) {
-            constexpr int r = 2 * decltype(pc)::value;
-            if constexpr (r + 1 < K) st2(rec + REC_W + r, w[r], w[r + 1]);
-            else st2(rec + REC_W + r, w[r], 0.0);
-        });
-        st2(rec + REC_META, __builtin_bit_cast(double, (long long)b), __builtin_bit_cast(double, (long long)nrm));
+        if constexpr (IRLOSC_LANE_EIG_FORM) {
+            static_for<0, K>([&](auto rc) { constexpr int eo = (Rec<L>::OW + decltype(rc)::value) * 64; st_su(rec + eo, ro, w[decltype(rc)::value]); });
+            st_su(rec + Rec<L>::OM * 64, ro, __builtin_bit_cast(double, (long long)b));
+            st_su(rec + (Rec<L>::OM + 1) * 64, ro, __builtin_bit_cast(double, (long long)nrm));
+        } else {
+            static_for<0, (K + 1) / 2>([&](auto pc) {
+                constexpr int r = 2 * decltype(pc)::value;
+                if constexpr (r + 1 < K) st2(rec + REC_W + r, w[r], w[r + 1]);
+                else st2(rec + REC_W + r, w[r], 0.0);
+            });
+            st2(rec + REC_META, __builtin_bit_cast(double, (long long)b), __builtin_bit_cast(double, (long long)nrm));
+        }
         // A = L~ D' L~^T - diag(d' - d), row by row and straight into the record (no second triangle in registers: with the factor's 91
         // entries that is what spilled): Ldr[j] = L~[r][j] d'_j, A[r][c] = sum_{j < c} Ldr[j] L~[c][j] + Ldr[c], the true pivot on the diagonal
         double dpr[K];
@@ -510,7 +563,10 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
                 static_for<0, c>([&](auto jc) { constexpr int j = decltype(jc)::value; acc = fma(Ldr[j], Lf[L::tri(c, j)], acc); });
                 arow[c] = acc;
             });
-            static_for<0, r / 2 + 1>([&](auto pc) { constexpr int c = 2 * decltype(pc)::value; st2(rec + REC_A + r * 16 + c, arow[c], arow[c + 1]); });
+            if constexpr (IRLOSC_LANE_EIG_FORM)
+                static_for<0, r + 1>([&](auto cc) { constexpr int c = decltype(cc)::value; { constexpr int eo = L::tri(r, c) * 64; st_su(rec + eo, ro, arow[c]); } });
+            else
+                static_for<0, r / 2 + 1>([&](auto pc) { constexpr int c = 2 * decltype(pc)::value; st2(rec + REC_A + r * 16 + c, arow[c], arow[c + 1]); });
         });
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -531,6 +587,17 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
             jt[j] = s;
         }
     });
+    if constexpr (IRLOSC_LANE_EIG_FORM) {
+        if (hand) {
+            static_for<0, K>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                static_for<0, NJ>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if constexpr (L::row_moved(r, j)) { constexpr int eo = (Rec<L>::OJ + Rec<L>::jslot(r, j)) * 64; st_su(rec + eo, ro, Jt[r][j]); }
+                });
+            });
+        }
+    } else
     if (hand) {
         static_for<0, K>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
@@ -595,6 +662,352 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
 }
 
 
+#if IRLOSC_LANE_EIG_FORM
+// The eigen pass behind the lane kernel, ONE LANE PER FLAGGED ROBOT: 64 records per wave (transposed records: every load and store of the
+// record is a run of neighbouring words), the algorithm of r16::eigen16 (osc_row16.hpp: t = pinv(A, rcond 1e-5) w by deflated inverse
+// iteration through L~ D L~^T, Rayleigh-Ritz on several candidates, the cut decided by the inertia of (1e5 theta) I - A; osc.py:55)
+// restated on per-lane arrays -- a dot product is thirteen FMAs of a lane instead of a 16-lane butterfly, a solve is the same chain of
+// FMAs without the broadcasts -- so 64 robots cost ~13 k instructions where four-per-wave cost 16 x 2.5 k.  Every decision is per lane
+// and frozen at the lane's own convergence (branches are wave-uniform `__any` tests around masked updates): a robot's result does not
+// depend on its wave-mates.  A is not held across the iteration (the factor's 91 doubles, four candidate vectors and the iterate are
+// the register file): the rare blocks that need it again -- Rayleigh-Ritz, the inertia tests, the shifted refactorisation -- reload it
+// from the record and factor once more behind them.  Then u -= J^T t on the torques the lane kernel left without the task term.
+template <class TOPO, class SH, typename TIN>
+__global__ __launch_bounds__(64, 1) void osc_lane_eigen_kernel(const EigTrain et) {
+    using L = LT<TOPO, SH>;
+    using R = Rec<L>;
+    constexpr int NJ = L::NJ, K = L::K, NA = R::NA;
+    constexpr int NV = 4;
+    const EigStep& es = et.s[blockIdx.y];
+    const int n = __builtin_amdgcn_readfirstlane(min(*es.rec_count, et.B));
+    const int lane = threadIdx.x;
+    for (int g = blockIdx.x; g * 64 < n; g += gridDim.x) {
+        const bool live = g * 64 + lane < n;
+        const double* __restrict__ rg = es.rec + (size_t)g * (R::E * 64);      // (uniform; the lane adds a 32-bit word offset)
+        const uint32_t lo32 = (uint32_t)(live ? lane : n - 1 - g * 64);
+        const uint32_t vo = lo32 * 8u;
+        const long long bid = __builtin_bit_cast(long long, ld_su(rg + R::OM * 64, vo));
+        const uint32_t zrow = (uint32_t)__builtin_bit_cast(long long, ld_su(rg + (R::OM + 1) * 64, vo));
+        bool nr[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) nr[r] = ((zrow >> r) & 1u) != 0;
+        double Lf[NA], invd[K];
+        auto load_A = [&](double (&dst)[NA]) {
+            static_for<0, (NA + 7) / 8>([&](auto bc2) {
+                constexpr int e0 = 8 * decltype(bc2)::value;
+                const gcptr bp = sgpr_ptr(rg + e0 * 64);              // (eight entries within the instruction's offset field)
+                static_for<0, 8>([&](auto ec) { constexpr int e = e0 + decltype(ec)::value; if constexpr (e < NA) dst[e] = ld_su(bp + (e - e0) * 64, vo); });
+            });
+        };
+        // in place: L~ below the diagonal, pivots not kept (invd); a pivot of a padded / zero row, or a non-positive one, is taken as 1
+        auto factor = [&](double (&F)[NA], const double sigma, bool& pd) {
+            pd = true;
+            static_for<0, K>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                double d = F[L::tri(j, j)] + sigma;
+                const bool npd = !nr[j] && !(d > 0.0);
+                pd = pd && !npd;
+                d = (npd || nr[j]) ? 1.0 : d;
+                const double iv = rcp_refined(d);
+                invd[j] = iv;
+                double f[K];
+                static_for<j + 1, K>([&](auto ic) { constexpr int i = decltype(ic)::value; f[i] = F[L::tri(i, j)] * iv; });
+                static_for<j + 1, K>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    static_for<j + 1, i + 1>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        F[L::tri(i, c)] = fma(-f[i], F[L::tri(c, j)], F[L::tri(i, c)]);
+                    });
+                });
+                static_for<j + 1, K>([&](auto ic) { constexpr int i = decltype(ic)::value; F[L::tri(i, j)] = f[i]; });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        auto solve = [&](double (&z)[K]) {      // z <- (L~ D L~^T)^-1 z: the FMA chains of r16::solve16, per lane
+            static_for<0, K - 1>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                static_for<j + 1, K>([&](auto cc) { constexpr int c = decltype(cc)::value; z[c] = fma(-z[j], Lf[L::tri(c, j)], z[c]); });
+            });
+#pragma unroll
+            for (int c = 0; c < K; ++c) z[c] *= invd[c];
+            static_for_down<1, K>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                static_for<0, i>([&](auto cc) { constexpr int c = decltype(cc)::value; z[c] = fma(-z[i], Lf[L::tri(i, c)], z[c]); });
+            });
+        };
+        auto dot = [&](const double (&a)[K], const double (&b2)[K]) -> double {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int c = 0; c < K; ++c) { if (c & 1) s1 = fma(a[c], b2[c], s1); else s0 = fma(a[c], b2[c], s0); }
+            return s0 + s1;
+        };
+        load_A(Lf);
+        double nA2 = 0.0, lo = 0.0;
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+#pragma unroll
+            for (int c = 0; c <= r; ++c) { const double a = Lf[L::tri(r, c)]; nA2 = fma(a, r == c ? a : 2.0 * a, nA2); }
+            lo = fmax(lo, Lf[L::tri(r, r)]);
+        }
+        bool pdA;
+        factor(Lf, 0.0, pdA);
+        double trA = 0.0;      // trace(A^-1) over the real rows: columns of L~^-1
+        static_for<0, K>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            double xw[K];
+            xw[m] = 1.0;
+            double acc = nr[m] ? 0.0 : invd[m];
+            static_for<m + 1, K>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                double s2 = -Lf[L::tri(c, m)];
+                static_for<m + 1, c>([&](auto qc) { constexpr int q2 = decltype(qc)::value; s2 = fma(-Lf[L::tri(c, q2)], xw[q2], s2); });
+                xw[c] = s2;
+                acc = fma(s2 * s2, nr[c] ? 0.0 : invd[c], acc);
+            });
+            trA += acc;
+            if constexpr (m % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+        });
+        // ---- r16::eigen16, per lane ------------------------------------------------------------------------------------------------
+        const double hi = sqrt(nA2);
+        double sigma = 0.0;
+        bool giveup = live && !(hi > 0.0 && t_finite(hi));
+        const bool broken = !pdA || !(trA * hi < 1e11);
+        if (__any(live && broken)) {          // (that robot with sigma = 2^-40 ||A||_F on the diagonal, the others with 0: their factors again)
+            const bool use = live && broken;
+            sigma = use ? hi * 0x1p-40 : 0.0;
+            bool pd2;
+            load_A(Lf);
+            factor(Lf, sigma, pd2);
+            giveup = giveup || (use && !pd2);
+        }
+        lo = (lo > 0.0 && lo <= hi) ? lo : hi * 0.25;
+        const double net = 4e-5 * hi;
+        double v[NV][K], th[NV] = {0.0, 0.0, 0.0, 0.0};
+        bool has[NV] = {false, false, false, false};
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+#pragma unroll
+            for (int c = 0; c < K; ++c) v[i][c] = 0.0;
+        }
+        int m = 0;
+        bool active = live && !giveup;
+        double rem = (pdA && sigma == 0.0 && trA > 0.0) ? trA : -1.0;
+        bool go = true;
+        static_for<0, NV>([&](auto sc) {
+            constexpr int slot = decltype(sc)::value;
+            go = go && __any(active);
+            if (go) {
+                double x[K];
+#pragma unroll
+                for (int c = 0; c < K; ++c) x[c] = nr[c] ? 0.0 : 0.3 + 0.1 * (double)(((c + 3 * slot) * 5) % 7) - 0.05 * (double)slot;
+                double lam = 0.0, lam_prev = -1.0;
+                bool fin = !active;
+                auto deflate = [&](double (&y)[K]) {
+                    static_for<0, slot>([&](auto s0c) {
+                        constexpr int s0 = decltype(s0c)::value;
+                        const double pr = -dot(v[s0], y);
+#pragma unroll
+                        for (int c = 0; c < K; ++c) y[c] = fma(pr, v[s0][c], y[c]);
+                    });
+                };
+                for (int it = 0; it < IRLOSC_EIG_MAXIT; ++it) {
+                    double xn[K];
+#pragma unroll
+                    for (int c = 0; c < K; ++c) xn[c] = x[c];
+                    deflate(xn);
+                    solve(xn);
+                    const double n2 = dot(xn, xn);
+                    const double rn = rsq_refined(n2 > 0.0 ? n2 : 1.0);
+                    const double lamn = rn - sigma;
+                    const bool settled = fabs(lamn - lam_prev) <= 1e-10 * fabs(lamn) || lamn > 4.0 * net;
+#pragma unroll
+                    for (int c = 0; c < K; ++c) x[c] = fin ? x[c] : xn[c] * rn;
+                    lam = fin ? lam : lamn;
+                    lam_prev = lam;
+                    fin = fin || (it >= IRLOSC_EIG_FLOOR && settled);
+                    if (!__any(!fin)) break;
+                }
+#pragma unroll
+                for (int ex = 0; ex < IRLOSC_EIG_EXTRA; ++ex) {
+                    double xn[K];
+#pragma unroll
+                    for (int c = 0; c < K; ++c) xn[c] = x[c];
+                    deflate(xn);
+                    solve(xn);
+                    const double n2 = dot(xn, xn);
+                    const double rn = rsq_refined(n2 > 0.0 ? n2 : 1.0);
+                    const bool ok = n2 > 0.0 && t_finite(rn);
+#pragma unroll
+                    for (int c = 0; c < K; ++c) x[c] = ok ? xn[c] * rn : x[c];
+                    lam = (ok && lam <= 4.0 * net) ? rn - sigma : lam;
+                }
+                const bool cand = active && (lam <= net);
+                deflate(x);
+                {
+                    const double n2 = dot(x, x);
+                    const double rn = rsq_refined(n2 > 0.0 ? n2 : 1.0);
+#pragma unroll
+                    for (int c = 0; c < K; ++c) v[slot][c] = cand ? x[c] * rn : 0.0;
+                }
+                th[slot] = cand ? lam : 0.0;
+                has[slot] = cand;
+                m += cand ? 1 : 0;
+                rem = (cand && rem > 0.0 && lam > 0.0) ? rem - rcp_refined(lam) : (cand ? -1.0 : rem);
+                const bool exhausted = rem > 1e-7 * trA && rem * net < 1.0;
+                active = cand && !exhausted;
+            }
+        });
+        giveup = giveup || (m == NV);
+        // which candidates sit inside the bracket of the cut (decided by inertia below)
+        bool below[NV], ask[NV], anyask = false;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { below[i] = false; ask[i] = false; }
+        const bool rr = __any(m >= 2);
+        // (without Rayleigh-Ritz the Ritz values are final here; with it they change below, so the bracket test follows it)
+        if (rr) {
+            // Rayleigh-Ritz on the span of the candidates: H = V^T A V (4 x 4; unused vectors are zero), cyclic Jacobi, rotations applied to V
+            double (&At)[NA] = Lf;              // (the factor is rebuilt behind this block: its registers hold A meanwhile)
+            double h[NV][NV];
+            load_A(At);
+            static_for<0, NV>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                double av[K];
+                static_for<0, K>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    double s2 = 0.0;
+                    static_for<0, K>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        s2 = fma(At[r >= c ? L::tri(r, c) : L::tri(c, r)], v[j][c], s2);
+                    });
+                    av[r] = s2;
+                });
+                static_for<0, j + 1>([&](auto ic) { constexpr int i = decltype(ic)::value; h[i][j] = dot(v[i], av); h[j][i] = h[i][j]; });
+            });
+            for (int sweep = 0; sweep < 6; ++sweep) {
+                bool turned = false;
+#pragma unroll
+                for (int p2 = 0; p2 < NV - 1; ++p2) {
+#pragma unroll
+                    for (int q2 = p2 + 1; q2 < NV; ++q2) {
+                        const double hpq = h[p2][q2], hpp = h[p2][p2], hqq = h[q2][q2];
+                        const bool rot = has[p2] && has[q2] && fabs(hpq) > 1e-300 && fabs(hpq) > 1e-18 * (fabs(hpp) + fabs(hqq));
+                        turned = turned || rot;
+                        double theta = (hqq - hpp) * rcp_refined(rot ? 2.0 * hpq : 1.0);
+                        theta = fmin(fmax(theta, -1e100), 1e100);
+                        const double tq = (theta >= 0.0 ? 1.0 : -1.0) * rcp_refined(fabs(theta) + r16::sqrt_fast(theta * theta + 1.0));
+                        const double cs = rot ? rsq_refined(tq * tq + 1.0) : 1.0;
+                        const double sn = rot ? tq * cs : 0.0;
+                        h[p2][p2] = rot ? hpp - tq * hpq : hpp;
+                        h[q2][q2] = rot ? hqq + tq * hpq : hqq;
+                        h[p2][q2] = rot ? 0.0 : hpq;
+                        h[q2][p2] = h[p2][q2];
+#pragma unroll
+                        for (int r = 0; r < NV; ++r) {
+                            if (r != p2 && r != q2) {
+                                const double hrp = h[r][p2], hrq = h[r][q2];
+                                h[r][p2] = cs * hrp - sn * hrq; h[p2][r] = h[r][p2];
+                                h[r][q2] = sn * hrp + cs * hrq; h[q2][r] = h[r][q2];
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < K; ++c) {
+                            const double vp = v[p2][c], vq = v[q2][c];
+                            v[p2][c] = cs * vp - sn * vq;
+                            v[q2][c] = sn * vp + cs * vq;
+                        }
+                    }
+                }
+                if (!__any(turned)) break;
+            }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) th[i] = (m >= 2 && has[i]) ? h[i][i] - 0.0 : th[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            below[i] = has[i] && th[i] <= 1e-5 * lo;
+            ask[i] = has[i] && !below[i] && th[i] <= 1e-5 * hi;
+            anyask = anyask || ask[i];
+        }
+        // The pinv cut (osc.py:55): at or under 1e-5 lo is cut, over 1e-5 hi is kept, in between "theta <= 1e-5 lambda_max" is "(1e5
+        // theta) I - A is not positive definite" -- one L D L^T of that matrix in the Lf registers (the factor is rebuilt behind it).
+        bool cut[NV];
+        const bool wave_ask = __any(anyask);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            cut[i] = below[i];
+            if (__any(ask[i])) {
+                load_A(Lf);
+#pragma unroll
+                for (int e = 0; e < NA; ++e) Lf[e] = -Lf[e];
+                bool pdt;
+                factor(Lf, ask[i] ? th[i] * 1e5 : 4.0 * hi, pdt);
+                cut[i] = cut[i] || (ask[i] && !pdt);
+            }
+        }
+        if (rr || wave_ask) {
+            bool pd3;
+            load_A(Lf);
+            factor(Lf, sigma, pd3);
+        }
+        int ncut = 0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+#pragma unroll
+            for (int c = 0; c < K; ++c) v[i][c] = cut[i] ? v[i][c] : 0.0;
+            ncut += cut[i] ? 1 : 0;
+        }
+        // t = P (A + sigma)^-1 P w
+        // (the tail's loads go through an opaque copy of the lane offset: nothing of the record is requested ahead of the iteration and
+        //  carried through it in registers)
+        uint32_t vo2 = vo;
+        asm volatile("" : "+v"(vo2));
+        double tt[K];
+#pragma unroll
+        for (int c = 0; c < K; ++c) tt[c] = ld_su(sgpr_ptr(rg + (R::OW + c) * 64), vo2);
+        bool lv[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) lv[i] = __any(cut[i]);
+        auto project = [&]() {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                if (lv[i]) {
+                    const double pr = -dot(v[i], tt);
+#pragma unroll
+                    for (int c = 0; c < K; ++c) tt[c] = fma(pr, v[i][c], tt[c]);
+                }
+            }
+        };
+        project();
+        solve(tt);
+        project();
+        const uint32_t f2 = ncut > 0 ? IRLOSC_FLAG_TRUNCATED : 0u;
+        // ---- u -= J^T t ---------------------------------------------------------------------------------------------------------------
+        bool bad = false;
+        TIN* __restrict__ ub = reinterpret_cast<TIN*>(es.u) + (size_t)bid * NJ;
+        static_for<0, NJ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (L::hinge_ee(j)) {
+                double s2 = 0.0;
+                static_for<0, K>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    if constexpr (L::row_moved(r, j)) { constexpr int eo = (R::OJ + R::jslot(r, j)) * 64; s2 = fma(ld_su(sgpr_ptr(rg + eo), vo2), tt[r], s2); }
+                });
+                if (live) {
+                    const double u = (double)ub[j] - s2;
+                    bad = bad || !t_finite(u);
+                    ub[j] = (TIN)u;
+                }
+            }
+        });
+        if (live) {
+            uint32_t fl = es.flags[bid] | f2;
+            if (bad) fl |= IRLOSC_FLAG_NONFINITE;
+            es.flags[bid] = fl;
+            if (giveup) es.worklist[atomicAdd(es.workcount, 1)] = (int32_t)bid;
+        }
+    }
+}
+#else
 // The eigen pass behind the lane kernel: the records of a step's flagged robots, FOUR per wave in the row16 layout (16 lanes per robot,
 // lane c = column c of A) -- the factorisation, the certificate's numbers and eigen16 exactly as the row16 kernel runs them in place
 // (osc_row16.hpp), then u -= J^T t on the torques the lane kernel left without the task term.  Persistent blocks, blockIdx.y = step.
@@ -692,6 +1105,7 @@ __global__ __launch_bounds__(64, IRLOSC_LANE_EIG_WAVES) void osc_lane_eigen_kern
         }
     }
 }
+#endif
 
 }  // namespace lane
 }  // namespace irlosc
