@@ -360,7 +360,7 @@ def measure_from_q(BatchedOSC, synth, args, B, local_rank, state0=None, ref_u=No
                    note="per step: rigid-body front end (FK, EE Jacobians, CRBA, RNEA) from resident (qpos, qvel) and the OSC step on "
                         "what it leaves behind (fused path: a compact exchange buffer of the structural non-zeros, 2.6 KB per robot, "
                         "instead of 8.5 KB of dense records; round 6: the OSC step too runs one lane per robot on that buffer, the ~15 % of "
-                        "robots whose solve is a truncated pseudo-inverse finish in an eigen pass, four to a wave); nothing crosses PCIe")
+                        "robots whose solve is a truncated pseudo-inverse finish in an eigen pass, again one lane per robot); nothing crosses PCIe")
         if ref_u is not None:                          # front end + step on slot 0 against the chained oracles
             u = osc.step_q(slot=0)
             res["parity_sample"] = _parity_plain(u, ref_u, 1e-5,

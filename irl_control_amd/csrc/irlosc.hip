@@ -1206,7 +1206,7 @@ extern "C" int irlosc_set_model(irlosc_ctx* c, const irlosc_model* m) {
         HIPCHK(c, hipStreamSynchronize(c->stream));      // t lives on this stack frame
         // (the exchange buffers themselves are allocated by the first fused step: ensure_xside)
         // The OSC step behind the walk: lane-per-robot form when an instantiation holds this layout (IRLOSC_LANE=0: the row16 FROMQ
-        // kernel, A/B measurements and tests); its records are laid out by the row map, so another layout starts from zeroed ones
+        // kernel, A/B measurements and tests); its record buffers are sized for the instantiation's entries and start over with a new layout
         const char* le = getenv("IRLOSC_LANE");
         lane::RowMap map;
         const int tier = (le && !strcmp(le, "0")) ? -1 : lane_plan(h, &map);
@@ -1340,13 +1340,13 @@ static int ensure_xside(irlosc_ctx* c, int n) {
             return 1;
         }
     }
-    // lane form of the OSC step: one record per robot and step for the eigen pass (all of a batch may be flagged), zeroed once -- the
-    // kernels never write the structural zeros of a record.  Out of memory here only switches the lane form off.
+    // lane form of the OSC step: one record per robot and step for the eigen pass (all of a batch may be flagged), in whole groups of
+    // 64 (transposed records; every entry of a record is written by the lane that owns it).  Out of memory here only switches the lane form off.
     if (c->lane_tier >= 0) {
         if (!c->dlane_count && hipMalloc((void**)&c->dlane_count, R16_TRAIN * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); c->lane_tier = -1; }
         for (int k2 = 0; c->lane_tier >= 0 && k2 < n && k2 < R16_TRAIN; ++k2) {
             if (c->lane_rec[k2]) continue;
-            const size_t bytes = (size_t)c->cfg.max_batch * lane::REC_DOUBLES * sizeof(double);
+            const size_t bytes = (size_t)((c->cfg.max_batch + 63) / 64 * 64) * lane::REC_DOUBLES * sizeof(double);      // (whole groups of 64 records)
             if (hipMalloc((void**)&c->lane_rec[k2], bytes) != hipSuccess || hipMemsetAsync(c->lane_rec[k2], 0, bytes, c->stream) != hipSuccess) {
                 (void)hipGetLastError();
                 for (int k3 = 0; k3 < R16_TRAIN; ++k3) if (c->lane_rec[k3]) { (void)hipFree(c->lane_rec[k3]); c->lane_rec[k3] = nullptr; }

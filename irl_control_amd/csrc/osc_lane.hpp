@@ -25,9 +25,10 @@
 // pinv imply).
 //
 // Robots whose solve is not certifiably the reference's inverse branch (15 % of physical states) are NOT finished here: the lane
-// writes A, w and the Jacobian columns into a compact record (slot from one atomic per wave) and osc_lane_eigen_kernel -- four
-// records per wave in the row16 layout, eigen16 unchanged -- computes t = pinv(A) w (osc.py:55) and subtracts J^T t from the
-// torques this kernel left without the task term.  What that stage gives up on goes to the generic kernel as before.
+// writes A, w and the Jacobian columns into a compact record (slot from one atomic per wave; records transposed in groups of 64) and
+// osc_lane_eigen_kernel -- again one lane per robot, 64 flagged robots per wave, r16::eigen16's algorithm on per-lane arrays -- computes
+// t = pinv(A) w (osc.py:55) and subtracts J^T t from the torques this kernel left without the task term.  What that stage gives up on
+// goes to the generic kernel as before.
 #pragma once
 #include "osc_generic.hpp"
 #include "osc_row16.hpp"
@@ -81,9 +82,6 @@ using r16::static_for_down;
 // first and the factorisation afterwards, with everything live in between (1 kB of scratch).  An empty volatile asm is ordered like a
 // side effect: what it touches is computed before the next pin of the schedule.
 __device__ __forceinline__ void pin(double& v) { asm volatile("" : "+v"(v)); }
-// two doubles with one 16-byte store (a record is written by the few flagged lanes of a wave, every lane to a region of its own: such a
-// store costs its issue slot per LANE ADDRESS, not per byte -- the 267 eight-byte stores of a record were a third of the kernel's cycles)
-__device__ __forceinline__ void st2(double* p, const double a, const double b) { *reinterpret_cast<double2*>(p) = make_double2(a, b); }
 // uniform base (scalar registers, constant offsets folded into it / the instruction) + one 32-bit BYTE offset per lane: the address form
 // that needs no 64-bit address arithmetic per access -- and leaves the compiler no per-access address to keep (it spilled 91 of them)
 // (the base laundered through scalar registers: left visible, the compiler folds base + lane offset into ONE vector address first and
@@ -100,15 +98,9 @@ __device__ __forceinline__ void st_su(gptr ubase, const uint32_t voff, const dou
     *reinterpret_cast<gptr>(reinterpret_cast<__attribute__((address_space(1))) char*>(ubase) + voff) = v;
 }
 __device__ __forceinline__ void st_su(double* ubase, const uint32_t voff, const double v) { st_su((gptr)ubase, voff, v); }
-// rank among the EE hinges -> hinge (or -1)
-template <class L>
-constexpr int hinge_of_rank(int cr) { for (int j = 0; j < L::NJ; ++j) if (L::hinge_ee(j) && L::ee_rank(j) == cr) return j; return -1; }
 using r16::rsq_refined;
 using r16::rcp_refined;
 
-#ifndef IRLOSC_LANE_EIG_FORM      // 1: the eigen pass one lane per flagged robot on TRANSPOSED records; 0: four records per wave in the row16 layout
-#define IRLOSC_LANE_EIG_FORM 1
-#endif
 // Records of the flagged robots, transposed: [group of 64 records][entry][64] doubles -- what a lane writes and what a lane of the eigen
 // pass reads sits next to its neighbours' (slots of a wave's flagged lanes are consecutive: coalesced both ways).  Entries: the lower
 // triangle of A (tri(r, c)), w, the entries of J that can be non-zero (row by row, hinges ascending), the robot's index and the mask of
@@ -528,24 +520,15 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
         if (lane == first) base = atomicAdd(lt.rec_count[blockIdx.y], (int)__builtin_popcountll(hm));
         base = __builtin_amdgcn_readlane(base, first);
         const int slot = base + (int)__builtin_popcountll(hm & ((1ull << lane) - 1ull));
-        if constexpr (IRLOSC_LANE_EIG_FORM) { rec = lt.rec[blockIdx.y]; ro = ((uint32_t)((hand ? slot : 0) >> 6) * (uint32_t)(Rec<L>::E * 64) + (uint32_t)((hand ? slot : 0) & 63)) * 8u; }
-        else rec = lt.rec[blockIdx.y] + (size_t)(hand ? slot : 0) * REC_DOUBLES;
+        rec = lt.rec[blockIdx.y];
+        ro = ((uint32_t)((hand ? slot : 0) >> 6) * (uint32_t)(Rec<L>::E * 64) + (uint32_t)((hand ? slot : 0) & 63)) * 8u;
     }
     if (hand) {
         uint32_t nrm = 0u;
         static_for<0, K>([&](auto rc) { constexpr int r = decltype(rc)::value; nrm |= nr[r] ? (1u << r) : 0u; });
-        if constexpr (IRLOSC_LANE_EIG_FORM) {
-            static_for<0, K>([&](auto rc) { constexpr int eo = (Rec<L>::OW + decltype(rc)::value) * 64; st_su(rec + eo, ro, w[decltype(rc)::value]); });
-            st_su(rec + Rec<L>::OM * 64, ro, __builtin_bit_cast(double, (long long)b));
-            st_su(rec + (Rec<L>::OM + 1) * 64, ro, __builtin_bit_cast(double, (long long)nrm));
-        } else {
-            static_for<0, (K + 1) / 2>([&](auto pc) {
-                constexpr int r = 2 * decltype(pc)::value;
-                if constexpr (r + 1 < K) st2(rec + REC_W + r, w[r], w[r + 1]);
-                else st2(rec + REC_W + r, w[r], 0.0);
-            });
-            st2(rec + REC_META, __builtin_bit_cast(double, (long long)b), __builtin_bit_cast(double, (long long)nrm));
-        }
+        static_for<0, K>([&](auto rc) { constexpr int eo = (Rec<L>::OW + decltype(rc)::value) * 64; st_su(rec + eo, ro, w[decltype(rc)::value]); });
+        st_su(rec + Rec<L>::OM * 64, ro, __builtin_bit_cast(double, (long long)b));
+        st_su(rec + (Rec<L>::OM + 1) * 64, ro, __builtin_bit_cast(double, (long long)nrm));
         // A = L~ D' L~^T - diag(d' - d), row by row and straight into the record (no second triangle in registers: with the factor's 91
         // entries that is what spilled): Ldr[j] = L~[r][j] d'_j, A[r][c] = sum_{j < c} Ldr[j] L~[c][j] + Ldr[c], the true pivot on the diagonal
         double dpr[K];
@@ -554,8 +537,7 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
             constexpr int r = decltype(rc)::value;
             double Ldr[K];
             static_for<0, r>([&](auto jc) { constexpr int j = decltype(jc)::value; Ldr[j] = Lf[L::tri(r, j)] * dpr[j]; });
-            double arow[K + 1];              // the LOWER triangle's row r, stored two entries at a time (the eigen pass mirrors the indices)
-            arow[r + 1] = 0.0;
+            double arow[K];                  // the lower triangle's row r
             static_for<0, r + 1>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
                 double acc;
@@ -563,17 +545,13 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
                 static_for<0, c>([&](auto jc) { constexpr int j = decltype(jc)::value; acc = fma(Ldr[j], Lf[L::tri(c, j)], acc); });
                 arow[c] = acc;
             });
-            if constexpr (IRLOSC_LANE_EIG_FORM)
-                static_for<0, r + 1>([&](auto cc) { constexpr int c = decltype(cc)::value; { constexpr int eo = L::tri(r, c) * 64; st_su(rec + eo, ro, arow[c]); } });
-            else
-                static_for<0, r / 2 + 1>([&](auto pc) { constexpr int c = 2 * decltype(pc)::value; st2(rec + REC_A + r * 16 + c, arow[c], arow[c + 1]); });
+            static_for<0, r + 1>([&](auto cc) { constexpr int c = decltype(cc)::value; constexpr int eo = L::tri(r, c) * 64; st_su(rec + eo, ro, arow[c]); });
         });
     }
     __builtin_amdgcn_sched_barrier(0);
     LANE_TS(4);
     // ---- J^T t, hinge by hinge, behind the records' A (the factor is dead by now: its 91 entries and these 85 do not fit the
-    // architectural registers together); the flagged robots leave the entries in their record (columns = the EE hinges in their order; the
-    // structural zeros of that block are never written: the buffer is zeroed when it is allocated)
+    // architectural registers together); the flagged robots leave the entries that can be non-zero in their record
     if constexpr (IRLOSC_LANE_JT_EARLY == 0) load_jt();
     double jt[NJ];
     static_for<0, NJ>([&](auto jc) {
@@ -587,30 +565,12 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
             jt[j] = s;
         }
     });
-    if constexpr (IRLOSC_LANE_EIG_FORM) {
-        if (hand) {
-            static_for<0, K>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                static_for<0, NJ>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    if constexpr (L::row_moved(r, j)) { constexpr int eo = (Rec<L>::OJ + Rec<L>::jslot(r, j)) * 64; st_su(rec + eo, ro, Jt[r][j]); }
-                });
-            });
-        }
-    } else
     if (hand) {
         static_for<0, K>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
-            static_for<0, 8>([&](auto pc) {
-                constexpr int c0 = 2 * decltype(pc)::value;
-                constexpr int j0 = hinge_of_rank<L>(c0), j1 = hinge_of_rank<L>(c0 + 1);
-                constexpr bool m0 = j0 >= 0 && L::row_moved(r, j0 >= 0 ? j0 : 0), m1 = j1 >= 0 && L::row_moved(r, j1 >= 0 ? j1 : 0);
-                if constexpr (m0 || m1) {
-                    double a = 0.0, b2 = 0.0;
-                    if constexpr (m0) a = Jt[r][j0 >= 0 ? j0 : 0];
-                    if constexpr (m1) b2 = Jt[r][j1 >= 0 ? j1 : 0];
-                    st2(rec + REC_J + r * 16 + c0, a, b2);
-                }
+            static_for<0, NJ>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (L::row_moved(r, j)) { constexpr int eo = (Rec<L>::OJ + Rec<L>::jslot(r, j)) * 64; st_su(rec + eo, ro, Jt[r][j]); }
             });
         });
     }
@@ -662,7 +622,6 @@ __global__ __launch_bounds__(64, 1) void osc_lane_kernel(const Row16Train<TIN> t
 }
 
 
-#if IRLOSC_LANE_EIG_FORM
 // The eigen pass behind the lane kernel, ONE LANE PER FLAGGED ROBOT: 64 records per wave (transposed records: every load and store of the
 // record is a run of neighbouring words), the algorithm of r16::eigen16 (osc_row16.hpp: t = pinv(A, rcond 1e-5) w by deflated inverse
 // iteration through L~ D L~^T, Rayleigh-Ritz on several candidates, the cut decided by the inertia of (1e5 theta) I - A; osc.py:55)
@@ -1007,105 +966,6 @@ __global__ __launch_bounds__(64, 1) void osc_lane_eigen_kernel(const EigTrain et
         }
     }
 }
-#else
-// The eigen pass behind the lane kernel: the records of a step's flagged robots, FOUR per wave in the row16 layout (16 lanes per robot,
-// lane c = column c of A) -- the factorisation, the certificate's numbers and eigen16 exactly as the row16 kernel runs them in place
-// (osc_row16.hpp), then u -= J^T t on the torques the lane kernel left without the task term.  Persistent blocks, blockIdx.y = step.
-// Rows that are padding or exact zero rows arrive as a mask and are treated like the KMAX-padded kernels treat them (PAD = true).
-#ifndef IRLOSC_LANE_EIG_WAVES
-#define IRLOSC_LANE_EIG_WAVES 2
-#endif
-template <class TOPO, class SH, typename TIN>
-__global__ __launch_bounds__(64, IRLOSC_LANE_EIG_WAVES) void osc_lane_eigen_kernel(const EigTrain et) {
-    using namespace r16;
-    using L = LT<TOPO, SH>;
-    constexpr int NJ = L::NJ, K = L::K;
-    const EigStep& es = et.s[blockIdx.y];
-    const int n = __builtin_amdgcn_readfirstlane(min(*es.rec_count, et.B));
-    const int lane = threadIdx.x, q = lane >> 4, l = lane & 15;
-    constexpr int NEE = L::n_ee();
-    for (int g = blockIdx.x; g * 4 < n; g += gridDim.x) {
-        const int ri = g * 4 + q;
-        const bool live = ri < n;
-        const double* __restrict__ rec = es.rec + (size_t)(live ? ri : n - 1) * REC_DOUBLES;
-        double Ac[K], A[K];
-#pragma unroll
-        for (int r = 0; r < K; ++r) Ac[r] = rec[REC_A + (r >= l ? r * 16 + l : l * 16 + r)];      // (the lower triangle is stored; lanes >= K read
-                                                                                                    //  rows that are never written: zeros since the allocation)
-        const double w = rec[REC_W + l];
-        const uint32_t zrow = (uint32_t)reinterpret_cast<const long long*>(rec)[REC_META + 1];
-        double nA2 = 0.0;
-#pragma unroll
-        for (int r = 0; r < K; ++r) { nA2 = fma(Ac[r], Ac[r], nA2); A[r] = Ac[r]; }
-        nA2 = row_sum(nA2);
-        double F[K], G[K];
-        double invd_own = 0.0, detA = 1.0;
-        bool pdA = true;
-        ldl16<K, true>(A, l, 0.0, F, G, invd_own, pdA, detA, K, zrow);
-        double X[K];
-#pragma unroll
-        for (int m = 0; m < K; ++m) X[m] = (l == m) ? 1.0 : 0.0;
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<0, K - 1>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            static_for<0, j + 1>([&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                if constexpr (j < 3 || m == 0) fmac_bc_n_nop<j>(X[m], X[m], F[j]);
-                else fmac_bc_n<j>(X[m], X[m], F[j]);
-            });
-        });
-        __builtin_amdgcn_sched_barrier(0);
-        double trA = 0.0;
-#pragma unroll
-        for (int m = 0; m < K; ++m) trA = fma(X[m], X[m], trA);
-        trA = (l < K && !((zrow >> l) & 1u)) ? trA : 0.0;
-        trA = row_sum(trA * invd_own);
-        double t = 0.0;
-        uint32_t f2 = 0;
-        bool giveup = false;
-        eigen16<K, true>(Ac, F, G, invd_own, pdA, nA2, trA, w, l, live, t, f2, giveup, K, zrow);
-        // (everything the tail needs is rebuilt from an opaque copy of the lane id: nothing rides through the eigen stage in registers)
-        int lane2 = threadIdx.x;
-        asm volatile("" : "+v"(lane2));
-        const int q2 = lane2 >> 4, l2 = lane2 & 15;
-        const int ri2 = g * 4 + q2;
-        const bool live2 = ri2 < n;
-        const double* __restrict__ rec2 = et.s[blockIdx.y].rec + (size_t)(live2 ? ri2 : n - 1) * REC_DOUBLES;
-        const long long bid = reinterpret_cast<const long long*>(rec2)[REC_META];
-        double jr[K];
-#pragma unroll
-        for (int r = 0; r < K; ++r) jr[r] = rec2[REC_J + r * 16 + l2];
-        int hinge = 0;
-        static_for<0, NJ>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            if constexpr (L::hinge_ee(j)) { constexpr int cr = L::ee_rank(j); hinge = (l2 == cr) ? j : hinge; }
-        });
-        double jt = 0.0;
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<0, K>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            if constexpr (r == 0) fmac_bc_nop<r>(jt, t, jr[r]);
-            else fmac_bc<r>(jt, t, jr[r]);
-        });
-        __builtin_amdgcn_sched_barrier(0);
-        bool bad = false;
-        if (live2 && l2 < NEE) {
-            TIN* up = reinterpret_cast<TIN*>(et.s[blockIdx.y].u) + (size_t)bid * NJ + hinge;
-            const double u = (double)*up - jt;
-            bad = !t_finite(u);
-            *up = (TIN)u;
-        }
-        const unsigned long long bm = __ballot(bad);
-        if (live2 && l2 == 0) {
-            const EigStep& e2 = et.s[blockIdx.y];
-            uint32_t fl = e2.flags[bid] | f2;
-            if ((bm >> (q2 * 16)) & 0xffffull) fl |= IRLOSC_FLAG_NONFINITE;
-            e2.flags[bid] = fl;
-            if (giveup) e2.worklist[atomicAdd(e2.workcount, 1)] = (int32_t)bid;
-        }
-    }
-}
-#endif
 
 }  // namespace lane
 }  // namespace irlosc

@@ -17,16 +17,14 @@ struct RowMap {
     int32_t ee_e0[IRLOSC_MAX_DEV];  // target device -> first entry of its end effector's pose in the exchange block (x y z qw qx qy qz)
 };
 
-// Records of the robots handed to the eigen pass, in doubles
-constexpr int REC_A = 0;            // [r][16]: A[r][c]
-constexpr int REC_W = 256;          // [16]
-constexpr int REC_J = 272;          // [r][16]: J[r][EE hinge of rank c]
-constexpr int REC_META = 528;       // +0: robot index, +1: bit r = row r is padding or an exact zero row (both as integers in the double's bits)
-constexpr int REC_DOUBLES = 544;
+// Records of the robots handed to the eigen pass: transposed in groups of 64 ([group][entry][64] doubles; lane::Rec in osc_lane.hpp has the
+// entries of an instantiation -- 191 for rows (1, 6, 6): A's lower triangle 91, w 13, J's movable entries 85, robot index, row mask).
+// What the host allocates per robot (whole groups):
+constexpr int REC_DOUBLES = 192;
 
 struct LaneTrain {
     const double* qt[R16_TRAIN];        // walk layout of the coordinates: [walk wave][2 NJ][64 robots] (entry 2 j + 1 = qvel_j)
-    double* rec[R16_TRAIN];             // records of the step's flagged robots, REC_DOUBLES each
+    double* rec[R16_TRAIN];             // records of the step's flagged robots
     int32_t* rec_count[R16_TRAIN];      // zero on entry
     RowMap map;
 };
