@@ -1413,7 +1413,10 @@ static int fused_train(irlosc_ctx* c, const int* slots, int n, int B, const irlo
     if (use_lane) {
         if (!lane_task_in_kernel()) HIPCHK(c, (hipError_t)launch_row16_fromq<T>(tr, n, st, 1));      // the task pass (A/B builds: the lane kernel computes the rows itself)
         static const int eig_blocks = [] { const char* e = getenv("IRLOSC_LANE_EIG_BLOCKS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 65536 ? v : 1024; }();
-        HIPCHK(c, (hipError_t)launch_lane_osc<T>(tr, lt, n, c->lane_tier, eig_blocks, st));
+        // flagged robots of a step from which the eigen pass runs one lane per robot (below: four records per wave, row16 form); the
+        // choice is made on the device, per step, from the count the lane kernel leaves (IRLOSC_LANE_EIG_MIN: A/B measurements)
+        static const int lane_min = [] { const char* e = getenv("IRLOSC_LANE_EIG_MIN"); return e ? atoi(e) : 3000; }();
+        HIPCHK(c, (hipError_t)launch_lane_osc<T>(tr, lt, n, c->lane_tier, eig_blocks, lane_min, st));
     } else {
         HIPCHK(c, (hipError_t)launch_row16_fromq<T>(tr, n, st));
     }

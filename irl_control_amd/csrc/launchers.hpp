@@ -40,9 +40,9 @@ struct FeModel;
 int lane_plan(const FeModel& h, lane::RowMap* map);      // -> tier, or -1: no instantiation for this layout
 int lane_task_in_kernel();                              // 1: the lane kernel computes part 1 of the task signal itself (no task pass)
 template <typename TIN>
-int launch_lane_osc(const Row16Train<TIN>& tr, const lane::LaneTrain& lt, int nsteps, int tier, int eig_blocks, hipStream_t st);
-template <> int launch_lane_osc<double>(const Row16Train<double>&, const lane::LaneTrain&, int, int, int, hipStream_t);
-template <> int launch_lane_osc<float>(const Row16Train<float>&, const lane::LaneTrain&, int, int, int, hipStream_t);
+int launch_lane_osc(const Row16Train<TIN>& tr, const lane::LaneTrain& lt, int nsteps, int tier, int eig_blocks, int lane_min, hipStream_t st);
+template <> int launch_lane_osc<double>(const Row16Train<double>&, const lane::LaneTrain&, int, int, int, int, hipStream_t);
+template <> int launch_lane_osc<float>(const Row16Train<float>&, const lane::LaneTrain&, int, int, int, int, hipStream_t);
 
 // tu_frontend.hip / tu_frontend_lane.hip -- rigid-body front end (osc_frontend.hpp, osc_frontend_lane.hpp); TOUT = record type
 struct FeModel;

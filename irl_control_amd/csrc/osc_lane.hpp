@@ -639,6 +639,7 @@ __global__ __launch_bounds__(64, 1) void osc_lane_eigen_kernel(const EigTrain et
     constexpr int NV = 4;
     const EigStep& es = et.s[blockIdx.y];
     const int n = __builtin_amdgcn_readfirstlane(min(*es.rec_count, et.B));
+    if (n < et.lane_min) return;            // (a thin list: osc_lane_eigen16_kernel below has this step)
     const int lane = threadIdx.x;
     for (int g = blockIdx.x; g * 64 < n; g += gridDim.x) {
         const bool live = g * 64 + lane < n;
@@ -963,6 +964,121 @@ __global__ __launch_bounds__(64, 1) void osc_lane_eigen_kernel(const EigTrain et
             if (bad) fl |= IRLOSC_FLAG_NONFINITE;
             es.flags[bid] = fl;
             if (giveup) es.worklist[atomicAdd(es.workcount, 1)] = (int32_t)bid;
+        }
+    }
+}
+
+
+// The same pass for a THIN list of flagged robots (fewer than EigTrain::lane_min in the step: small batches, layouts whose task spaces
+// seldom degenerate): FOUR records per wave in the row16 layout (16 lanes per robot, lane c = column c of A) -- the factorisation, the
+// certificate's numbers and r16::eigen16 exactly as the row16 kernel runs them in place (osc_row16.hpp).  A wave of the lane-form pass
+// above is one chain of ~16 k instructions (~70 us) whatever it holds; a step with 600 flagged robots is ten such waves on a machine of
+// 1 024 SIMDs, while this form spreads them over 150 short waves (measured: 4 096 robots, k13, from_q 3.9e8 with the lane form alone,
+// 4.8e8 with this one).  Both kernels are launched behind every lane kernel; each looks at the step's count and one of them returns.
+// Reads the transposed records (16 lanes of a robot read 16 different entries: strided, but the list is thin by construction).
+template <class TOPO, class SH, typename TIN>
+__global__ __launch_bounds__(64, 2) void osc_lane_eigen16_kernel(const EigTrain et) {
+    using namespace r16;
+    using L = LT<TOPO, SH>;
+    using R = Rec<L>;
+    constexpr int NJ = L::NJ, K = L::K;
+    const EigStep& es = et.s[blockIdx.y];
+    const int n = __builtin_amdgcn_readfirstlane(min(*es.rec_count, et.B));
+    if (n >= et.lane_min) return;           // (the lane-form pass has this step)
+    const int lane = threadIdx.x, q = lane >> 4, l = lane & 15;
+    constexpr int NEE = L::n_ee();
+    for (int g = blockIdx.x; g * 4 < n; g += gridDim.x) {
+        const int ri = g * 4 + q;
+        const bool live = ri < n;
+        const int sl = live ? ri : n - 1;
+        const double* __restrict__ rec = es.rec + (size_t)(sl >> 6) * (R::E * 64) + (sl & 63);      // entry e of this robot: rec[e * 64]
+        const bool inl = l < K;                // (lanes K .. 15 of a robot hold the zero columns of the padded 16 x 16 problem)
+        const int lc = inl ? l : 0;
+        double Ac[K], A[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) { const double a = rec[(size_t)(r >= lc ? L::tri(r, 0) + lc : L::tri(lc, 0) + r) * 64]; Ac[r] = inl ? a : 0.0; }
+        const double w0 = rec[(size_t)(R::OW + lc) * 64];
+        const double w = inl ? w0 : 0.0;
+        const uint32_t zrow = (uint32_t)__builtin_bit_cast(long long, rec[(size_t)(R::OM + 1) * 64]);
+        double nA2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < K; ++r) { nA2 = fma(Ac[r], Ac[r], nA2); A[r] = Ac[r]; }
+        nA2 = row_sum(nA2);
+        double F[K], G[K];
+        double invd_own = 0.0, detA = 1.0;
+        bool pdA = true;
+        ldl16<K, true>(A, l, 0.0, F, G, invd_own, pdA, detA, K, zrow);
+        double X[K];
+#pragma unroll
+        for (int m = 0; m < K; ++m) X[m] = (l == m) ? 1.0 : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, K - 1>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            static_for<0, j + 1>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                if constexpr (j < 3 || m == 0) fmac_bc_n_nop<j>(X[m], X[m], F[j]);
+                else fmac_bc_n<j>(X[m], X[m], F[j]);
+            });
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        double trA = 0.0;
+#pragma unroll
+        for (int m = 0; m < K; ++m) trA = fma(X[m], X[m], trA);
+        trA = (l < K && !((zrow >> l) & 1u)) ? trA : 0.0;
+        trA = row_sum(trA * invd_own);
+        double t = 0.0;
+        uint32_t f2 = 0;
+        bool giveup = false;
+        eigen16<K, true>(Ac, F, G, invd_own, pdA, nA2, trA, w, l, live, t, f2, giveup, K, zrow);
+        // (everything the tail needs is rebuilt from an opaque copy of the lane id: nothing rides through the eigen stage in registers)
+        int lane2 = threadIdx.x;
+        asm volatile("" : "+v"(lane2));
+        const int q2 = lane2 >> 4, l2 = lane2 & 15;
+        const int ri2 = g * 4 + q2;
+        const bool live2 = ri2 < n;
+        const int sl2 = live2 ? ri2 : n - 1;
+        const double* __restrict__ rec2 = et.s[blockIdx.y].rec + (size_t)(sl2 >> 6) * (R::E * 64) + (sl2 & 63);
+        const long long bid = __builtin_bit_cast(long long, rec2[(size_t)R::OM * 64]);
+        // lane l2 of a robot takes the EE hinge of rank l2: its column of J, entry by entry (-1: structurally zero)
+        int hinge = 0, je[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) je[r] = -1;
+        static_for<0, NJ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (L::hinge_ee(j)) {
+                constexpr int cr = L::ee_rank(j);
+                hinge = (l2 == cr) ? j : hinge;
+                static_for<0, K>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    if constexpr (L::row_moved(r, j)) { constexpr int eo = R::OJ + R::jslot(r, j); je[r] = (l2 == cr) ? eo : je[r]; }
+                });
+            }
+        });
+        double jr[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) { const double a = rec2[(size_t)(je[r] >= 0 ? je[r] : 0) * 64]; jr[r] = je[r] >= 0 ? a : 0.0; }
+        double jt = 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, K>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            if constexpr (r == 0) fmac_bc_nop<r>(jt, t, jr[r]);
+            else fmac_bc<r>(jt, t, jr[r]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        bool bad = false;
+        if (live2 && l2 < NEE) {
+            TIN* up = reinterpret_cast<TIN*>(et.s[blockIdx.y].u) + (size_t)bid * NJ + hinge;
+            const double u = (double)*up - jt;
+            bad = !t_finite(u);
+            *up = (TIN)u;
+        }
+        const unsigned long long bm = __ballot(bad);
+        if (live2 && l2 == 0) {
+            const EigStep& e2 = et.s[blockIdx.y];
+            uint32_t fl = e2.flags[bid] | f2;
+            if ((bm >> (q2 * 16)) & 0xffffull) fl |= IRLOSC_FLAG_NONFINITE;
+            e2.flags[bid] = fl;
+            if (giveup) e2.worklist[atomicAdd(e2.workcount, 1)] = (int32_t)bid;
         }
     }
 }

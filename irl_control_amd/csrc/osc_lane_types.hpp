@@ -42,6 +42,7 @@ struct EigStep {
 struct EigTrain {
     EigStep s[R16_TRAIN];
     int32_t B;
+    int32_t lane_min;                   // flagged robots of a step from which the lane-form pass takes it (below: the row16-form pass)
 };
 
 // tiers of canonical rows per end-effector body of the Dual-UR5 (stand dummy, right EE, left EE): launch_lane_osc's `tier`

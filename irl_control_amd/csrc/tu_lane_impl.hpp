@@ -1,6 +1,7 @@
 #pragma once
 // Body of the translation units of the lane-per-robot OSC step of the fused path (osc_lane.hpp) on double records: the Dual-UR5 shapes with an
 // instantiation (rows per end-effector body: stand, right arm, left arm) and the eigen pass behind them.
+#include <algorithm>
 #include <cstring>
 
 #include "osc_lane.hpp"
@@ -12,7 +13,7 @@ namespace irlosc {
 using lane::Shape;
 
 template <class SH, typename TIN>
-static int lane_launch(const Row16Train<TIN>& tr, const lane::LaneTrain& lt, int nsteps, int eig_blocks, hipStream_t st) {
+static int lane_launch(const Row16Train<TIN>& tr, const lane::LaneTrain& lt, int nsteps, int eig_blocks, int lane_min, hipStream_t st) {
     const KParams<TIN>& p = tr.p[0];
     const int waves = (p.B + 63) / 64;
     hipLaunchKernelGGL((lane::osc_lane_kernel<TopoDualUr5, SH, TIN>), dim3(waves, nsteps), dim3(64), 0, st, tr, lt);
@@ -21,7 +22,15 @@ static int lane_launch(const Row16Train<TIN>& tr, const lane::LaneTrain& lt, int
     et.B = p.B;
     for (int i = 0; i < nsteps; ++i)
         et.s[i] = lane::EigStep{tr.p[i].u, tr.p[i].flags, tr.x[i].worklist, tr.x[i].workcount, lt.rec[i], lt.rec_count[i]};
-    hipLaunchKernelGGL((lane::osc_lane_eigen_kernel<TopoDualUr5, SH, TIN>), dim3(eig_blocks, nsteps), dim3(64), 0, st, et);
+    et.lane_min = lane_min;
+    // both forms of the eigen pass behind every lane kernel; each looks at the step's count of flagged robots and one of them returns
+    // (grids no larger than the lists they can be handed: an idle launch is a few microseconds of a small batch's train)
+    const int g_lane = std::min(eig_blocks, (p.B + 63) / 64);
+    const int g_r16 = std::min(eig_blocks, (std::min(p.B, std::max(lane_min, 1)) + 3) / 4);
+    if (p.B >= lane_min)
+        hipLaunchKernelGGL((lane::osc_lane_eigen_kernel<TopoDualUr5, SH, TIN>), dim3(g_lane, nsteps), dim3(64), 0, st, et);
+    if (lane_min > 0)
+        hipLaunchKernelGGL((lane::osc_lane_eigen16_kernel<TopoDualUr5, SH, TIN>), dim3(g_r16, nsteps), dim3(64), 0, st, et);
     return (int)hipGetLastError();
 }
 
@@ -32,12 +41,12 @@ static int lane_launch(const Row16Train<TIN>& tr, const lane::LaneTrain& lt, int
 // tier = index into lane_tiers(): 0: (1, 6, 6)  1: (1, 3, 3)
 template <>
 int launch_lane_osc<IRLOSC_LANE_TIN>(const Row16Train<IRLOSC_LANE_TIN>& tr, const lane::LaneTrain& lt, int nsteps, int tier, int eig_blocks,
-                                     hipStream_t st) {
+                                     int lane_min, hipStream_t st) {
     if (tr.p[0].B <= 0 || nsteps <= 0) return 0;
     switch (tier) {
-        case 0: return lane_launch<Shape<1, 6, 6>, IRLOSC_LANE_TIN>(tr, lt, nsteps, eig_blocks, st);
+        case 0: return lane_launch<Shape<1, 6, 6>, IRLOSC_LANE_TIN>(tr, lt, nsteps, eig_blocks, lane_min, st);
 #ifndef IRLOSC_LANE_ONLY_TIER0      // (register / ISA experiments on one instantiation)
-        case 1: return lane_launch<Shape<1, 3, 3>, IRLOSC_LANE_TIN>(tr, lt, nsteps, eig_blocks, st);
+        case 1: return lane_launch<Shape<1, 3, 3>, IRLOSC_LANE_TIN>(tr, lt, nsteps, eig_blocks, lane_min, st);
 #endif
         default: return (int)hipErrorNotSupported;
     }
