@@ -21,6 +21,7 @@ if [ -n "$fdb" ] && [ -n "$wdb" ]; then
     python tools/pmc_traffic.py "$fdb" "$wdb" osc_frontend_lane_compact "fromq_lane:walk" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8
     python tools/pmc_traffic.py "$fdb" "$wdb" osc_lane_kernel "fromq_lane:osc_lane" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8
     python tools/pmc_traffic.py "$fdb" "$wdb" osc_lane_eigen_kernel "fromq_lane:eigen_pass" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8
+    # (osc_lane_eigen16_kernel, the form for thin lists, is launched too and returns at once on this workload: see the kernel stats)
   else
     python tools/pmc_traffic.py "$fdb" "$wdb" osc_frontend_lane_compact "osc_frontend_lane_compact_dual_ur5" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8
     python tools/pmc_traffic.py "$fdb" "$wdb" "25, true" "osc_row16_f64_n25_k13_fromq" gpurun_out/hbm_traffic_fq_$tag.json "$db" 65536 8

@@ -14,6 +14,11 @@ find gpurun_out -maxdepth 1 -type d \( -name "prof_*" -o -name "pmc*" \) | xargs
 bash tools/gpu_profile_fromq.sh ${T} > gpurun_out/profile_${T}_fromq.log 2>&1
 bash tools/gpu_pmc_fromq.sh ${T} > /dev/null 2>&1
 find gpurun_out -maxdepth 1 -type d \( -name "fq_*" -o -name "pmc*" \) | xargs rm -rf
+IRLOSC_FQ_OVERLAP=0 bash tools/gpu_profile_fromq.sh ${T}s > gpurun_out/profile_${T}s_fromq.log 2>&1      # every train on ONE stream: each kernel's own cost
+IRLOSC_FQ_OVERLAP=0 bash tools/gpu_pmc_fromq.sh ${T}s > /dev/null 2>&1
+(echo "# IRLOSC_FQ_OVERLAP=0 (every train on one stream)"; IRLOSC_FQ_OVERLAP=0 python tools/fromq_bench.py --steps 8000 --reps 2; echo "# default (consecutive trains on two banks / streams)"; python tools/fromq_bench.py --steps 8000 --reps 2) > gpurun_out/${T}_fromq_one_vs_two_streams.txt 2>&1
+TAG=${T} bash tools/gpu_r6_eigmin.sh > /dev/null 2>&1
+find gpurun_out -maxdepth 1 -type d \( -name "fq_*" -o -name "pmc*" \) | xargs rm -rf
 python tools/train_timing.py --from-q --out gpurun_out/${T}_train_timing_fromq.json > gpurun_out/${T}_train_timing_fromq.log 2>&1
 python tools/train_timing.py --out gpurun_out/${T}_train_timing.json > gpurun_out/${T}_train_timing.log 2>&1
 python bench.py > gpurun_out/${T}_bench_default.json 2> gpurun_out/${T}_bench_default.err
