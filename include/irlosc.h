@@ -354,11 +354,12 @@ IRLOSC_API int irlosc_download_records(irlosc_ctx* ctx, int32_t slot, int32_t B,
  * The OSC step behind the walk (ABI version 3): for a layout whose task rows fit an instantiation -- at most six rows per arm and one on
  * the stand: every layout of the shipped examples -- and a train without target velocities it runs ONE LANE PER ROBOT on the exchange
  * buffer (tree-structured L^T L, Y, A = J M^-1 J^T, the k x k factorisation, certificate, solve and torques, with part 1 of the task signal
- * computed in the same kernel); the robots whose solve is a truncated pseudo-inverse (osc.py:55; ~15 % of physical states) leave a 4.3 KB
- * record and are finished by an eigen pass, what that gives up on goes to the generic kernel as before.  Everything else takes the row16
- * FROMQ kernel (behind a task pass).  Same contract either way (1e-5 on the parity domain, same flags); irlosc_from_q_name says which.
- * The lane form's records -- max_batch x 4 352 bytes per step of a train -- are allocated with the exchange buffers; if that fails only
- * the lane form is switched off.  Environment switch for A/B measurements, read by irlosc_set_model: IRLOSC_LANE=0. */
+ * computed in the same kernel); the robots whose solve is a truncated pseudo-inverse (osc.py:55; ~15 % of physical states) leave a 1.5 KB
+ * record and are finished by an eigen pass -- one lane per robot too where a step flags 3 000 robots or more, four records per wave on
+ * thinner lists, chosen on the device per step --, what that gives up on goes to the generic kernel as before.  Everything else takes
+ * the row16 FROMQ kernel (behind a task pass).  Same contract either way (1e-5 on the parity domain, same flags); irlosc_from_q_name
+ * says which.  The lane form's records -- max_batch (rounded up to 64) x 1 536 bytes per step of a train -- are allocated with the
+ * exchange buffers; if that fails only the lane form is switched off.  Environment switches for A/B measurements: INTEGRATION.md. */
 IRLOSC_API int irlosc_step_from_q(irlosc_ctx* ctx, int32_t slot, int32_t B, void* u_host, uint32_t* flags_host);
 /* What irlosc_step_from_q / irlosc_step_resident_from_q launch ("" before irlosc_set_model). */
 IRLOSC_API const char* irlosc_from_q_name(const irlosc_ctx* ctx);
