@@ -78,11 +78,12 @@ struct irlosc_ctx {
     int fused_train = R16_TRAIN;
     // the OSC step of the fused path in lane-per-robot form (osc_lane.hpp): the instantiation that holds the layout (-1: none: the row16
     // FROMQ kernel stays), its row map, the records + counters of the eigen pass behind it (allocated by the first fused step)
-    // Consecutive trains of irlosc_step_resident_from_q alternate between two BANKS of buffers (exchange buffers, eigen-pass records,
-    // counters, give-up lists, output sets) on two streams: the walk and the lane kernel run one wave per SIMD, eight waves deep per train,
-    // so every kernel boundary leaves SIMDs idle for up to a wave's lifetime (~50 us) -- measured as a fixed ~126 us per train of 990 us
-    // (trains of 8 / 4 / 2 steps: 124 / 140 / 163 us per step).  With the NEXT train independent and on another stream its first waves
-    // fill those tails.  Bank 0 = the buffers above on `stream`; bank 1 is allocated by the first call that chains more than one train.
+    // Consecutive trains of irlosc_step_resident_from_q rotate over BANKS of buffers (exchange buffers, eigen-pass records, counters,
+    // give-up lists, output sets), each on a stream of its own: the walk and the lane kernel run one wave per SIMD, eight waves deep per
+    // train, so every kernel boundary leaves SIMDs idle for up to a wave's lifetime (~50 us) -- measured as a fixed ~126 us per train of
+    // 990 us (trains of 8 / 4 / 2 steps: 124 / 140 / 163 us per step).  With the NEXT trains independent and on other streams their first
+    // waves fill those tails (two banks: 60 us of the 126 left; three: ~45).  Bank 0 = the buffers above on `stream`; the others are
+    // allocated by the first call that chains that many trains.
     struct Bank {
         hipStream_t st = nullptr;
         hipEvent_t done = nullptr;
@@ -94,7 +95,10 @@ struct irlosc_ctx {
         void* u[R16_TRAIN] = {};
         uint32_t* flags[R16_TRAIN] = {};
         double* trows[R16_TRAIN] = {};     // (dense-record trains: rows of the task pass)
-    } bank1;
+    };
+    static constexpr int MAX_XBANKS = 3;   // banks beside the context's own: trains of the fused path rotate over 1 + fq_xbanks of them
+    Bank xb[MAX_XBANKS];
+    int fq_xbanks = 2;                     // IRLOSC_FQ_BANKS = 2 .. 4 banks in all (default 3: k13 6.88 -> 7.00e8, four: 7.03e8, +2.4 GB each); the dense-record trains use xb[0] only
     hipEvent_t ev_join = nullptr;
     int fq_overlap = 1;                    // IRLOSC_FQ_OVERLAP=0: one bank, one stream (A/B measurements, tests)
     int r16_overlap = 1;                   // IRLOSC_R16_OVERLAP=0: the same switch for the trains of irlosc_step_resident on dense records
@@ -212,19 +216,21 @@ static void free_all(irlosc_ctx* c) {
     for (int k = 0; k < R16_TRAIN; ++k) if (c->fe_xside[k]) (void)hipFree(c->fe_xside[k]);
     for (int k = 0; k < R16_TRAIN; ++k) if (c->dtrows[k]) (void)hipFree(c->dtrows[k]);
     for (int k = 0; k < R16_TRAIN; ++k) if (c->lane_rec[k]) (void)hipFree(c->lane_rec[k]);
-    for (int k = 0; k < R16_TRAIN; ++k) {
-        if (c->bank1.xside[k]) (void)hipFree(c->bank1.xside[k]);
-        if (c->bank1.lane_rec[k]) (void)hipFree(c->bank1.lane_rec[k]);
-        if (c->bank1.list[k]) (void)hipFree(c->bank1.list[k]);
-        if (c->bank1.u[k]) (void)hipFree(c->bank1.u[k]);
-        if (c->bank1.flags[k]) (void)hipFree(c->bank1.flags[k]);
-        if (c->bank1.trows[k]) (void)hipFree(c->bank1.trows[k]);
+    for (irlosc_ctx::Bank& bk : c->xb) {
+        for (int k = 0; k < R16_TRAIN; ++k) {
+            if (bk.xside[k]) (void)hipFree(bk.xside[k]);
+            if (bk.lane_rec[k]) (void)hipFree(bk.lane_rec[k]);
+            if (bk.list[k]) (void)hipFree(bk.list[k]);
+            if (bk.u[k]) (void)hipFree(bk.u[k]);
+            if (bk.flags[k]) (void)hipFree(bk.flags[k]);
+            if (bk.trows[k]) (void)hipFree(bk.trows[k]);
+        }
+        if (bk.lane_count) (void)hipFree(bk.lane_count);
+        if (bk.count) (void)hipFree(bk.count);
+        if (bk.done) (void)hipEventDestroy(bk.done);
+        if (bk.st) (void)hipStreamDestroy(bk.st);
     }
-    if (c->bank1.lane_count) (void)hipFree(c->bank1.lane_count);
-    if (c->bank1.count) (void)hipFree(c->bank1.count);
-    if (c->bank1.done) (void)hipEventDestroy(c->bank1.done);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->bank1.st) (void)hipStreamDestroy(c->bank1.st);
     if (c->dlane_count) (void)hipFree(c->dlane_count);
     for (double* p : c->dqpos) if (p) (void)hipFree(p);
     for (double* p : c->dqvel) if (p) (void)hipFree(p);
@@ -764,7 +770,7 @@ static bool ensure_trows(irlosc_ctx* c, int n) {
     return true;
 }
 
-static int ensure_bank1(irlosc_ctx* c, int n, bool fused);
+static int ensure_xbank(irlosc_ctx* c, int which, int n, bool fused);
 
 template <typename T>
 static int row16_train(irlosc_ctx* c, const KParams<T>* ps, int n, bool tree, hipStream_t st, const int* pos = nullptr,
@@ -902,15 +908,15 @@ static int row16_resident(irlosc_ctx* c, int first_slot, int B, int iters, const
     const hipEvent_t outer_b = c->tev_begin, outer_e = c->tev_end;      // irlosc_time_trains brackets a one-train call itself
     // more than one train, untimed: odd trains on the second bank / stream, so that their first waves fill the tail of the train before
     // (a call of exactly one full train already allocates the second bank: a caller's warm-up then pays for it, not its timed loop)
-    const bool two = c->r16_overlap && !evs && iters >= R16_TRAIN && ensure_bank1(c, R16_TRAIN, false) == 0;
+    const bool two = c->r16_overlap && !evs && iters >= R16_TRAIN && ensure_xbank(c, 0, R16_TRAIN, false) == 0;
     if (two) {
         HIPCHK(c, hipEventRecord(c->ev_join, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->bank1.st, c->ev_join, 0));
+        HIPCHK(c, hipStreamWaitEvent(c->xb[0].st, c->ev_join, 0));
     }
     const irlosc_ctx::Bank* last_bank = nullptr;
     while (done < iters) {
         const int n = std::min((int)R16_TRAIN, iters - done);
-        const irlosc_ctx::Bank* bk = (two && (launch_no & 1)) ? &c->bank1 : nullptr;
+        const irlosc_ctx::Bank* bk = (two && (launch_no & 1)) ? &c->xb[0] : nullptr;
         KParams<T> ps[2][R16_TRAIN];        // [1]: steps whose slot qualifies for the tree form, [0]: the others
         int pos[2][R16_TRAIN];              // step of the train each sub-train step is
         int cnt[2] = {0, 0};
@@ -941,8 +947,8 @@ static int row16_resident(irlosc_ctx* c, int first_slot, int B, int iters, const
         ++launch_no;
     }
     if (two) {
-        HIPCHK(c, hipEventRecord(c->bank1.done, c->bank1.st));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->bank1.done, 0));
+        HIPCHK(c, hipEventRecord(c->xb[0].done, c->xb[0].st));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->xb[0].done, 0));
     }
     c->du = last_bank ? last_bank->u[c->cur] : c->du_set[c->cur];
     c->dflags = last_bank ? last_bank->flags[c->cur] : c->dflags_set[c->cur];
@@ -1191,6 +1197,7 @@ extern "C" int irlosc_set_model(irlosc_ctx* c, const irlosc_model* m) {
         c->fused = c->fe_lane && c->kernel == IRLOSC_KERNEL_ROW16 && !(e && !strcmp(e, "0"));
         const char* ov = getenv("IRLOSC_FQ_OVERLAP");      // "0": consecutive fused trains on one stream (A/B measurements, tests)
         c->fq_overlap = !(ov && !strcmp(ov, "0"));
+        { const char* nb = getenv("IRLOSC_FQ_BANKS"); const int v = nb ? atoi(nb) : 3; c->fq_xbanks = std::max(1, std::min(v, 1 + irlosc_ctx::MAX_XBANKS)) - 1; }
         const char* t = getenv("IRLOSC_FUSED_TRAIN");      // steps per launch pair of the fused path (A/B measurements)
         if (t && atoi(t) >= 1 && atoi(t) <= R16_TRAIN) c->fused_train = atoi(t);
     }
@@ -1444,9 +1451,9 @@ static irlosc_ctx::Bank bank0_of(irlosc_ctx* c) {
     return b;
 }
 
-// The second bank (see irlosc_ctx::Bank): same sizes as the first.  -> 0, or 1: not available (out of memory: one bank, no overlap)
-static int ensure_bank1(irlosc_ctx* c, int n, bool fused) {
-    irlosc_ctx::Bank& b = c->bank1;
+// A further bank (see irlosc_ctx::Bank): same sizes as the context's own.  -> 0, or 1: not available (out of memory: fewer banks)
+static int ensure_xbank(irlosc_ctx* c, int which, int n, bool fused) {
+    irlosc_ctx::Bank& b = c->xb[which];
     const size_t Bm = (size_t)c->cfg.max_batch, waves = (Bm + 63) / 64;
     auto get = [](void** p, size_t bytes) { return *p || hipMalloc(p, bytes) == hipSuccess; };
     bool ok = true;
@@ -1472,11 +1479,13 @@ static int fused_resident(irlosc_ctx* c, int first_slot, int B, int iters) {
     int done = 0, t = 0;
     const irlosc_ctx::Bank b0 = bank0_of(c);
     // more than one train: alternate banks / streams so that a train's first waves fill the tails of the one before (irlosc_ctx::Bank)
-    const bool two = c->fq_overlap && iters >= c->fused_train && c->fused_train > 1 && !c->tev_begin && ensure_bank1(c, c->fused_train, true) == 0;
-    if (two) {
-        HIPCHK(c, hipEventRecord(c->ev_join, c->stream));              // bank 1's stream starts behind whatever the main stream holds
-        HIPCHK(c, hipStreamWaitEvent(c->bank1.st, c->ev_join, 0));
+    int nx = 0;                                                        // banks beside the context's own that this call rotates over
+    if (c->fq_overlap && iters >= c->fused_train && c->fused_train > 1 && !c->tev_begin) {
+        const int want = std::min(c->fq_xbanks, (iters + c->fused_train - 1) / c->fused_train - 1);
+        while (nx < want && ensure_xbank(c, nx, c->fused_train, true) == 0) ++nx;
     }
+    if (nx) HIPCHK(c, hipEventRecord(c->ev_join, c->stream));          // the other banks' streams start behind whatever the main stream holds
+    for (int k = 0; k < nx; ++k) HIPCHK(c, hipStreamWaitEvent(c->xb[k].st, c->ev_join, 0));
     const irlosc_ctx::Bank* last = &b0;
     while (done < iters) {
         const int n = std::min(c->fused_train, iters - done);
@@ -1486,7 +1495,8 @@ static int fused_resident(irlosc_ctx* c, int first_slot, int B, int iters) {
             int rc = check_slot_q(c, slots[i], B);
             if (rc) return rc;
         }
-        const irlosc_ctx::Bank& bk = (two && (t & 1)) ? c->bank1 : b0;
+        const int which = t % (nx + 1);
+        const irlosc_ctx::Bank& bk = which ? c->xb[which - 1] : b0;
         int rc = c->cfg.dtype == IRLOSC_F64 ? fused_train<double>(c, slots, n, B, bk) : fused_train<float>(c, slots, n, B, bk);
         if (rc) return rc;
         last = &bk;
@@ -1494,9 +1504,9 @@ static int fused_resident(irlosc_ctx* c, int first_slot, int B, int iters) {
         done += n;
         ++t;
     }
-    if (two) {                                                         // and the main stream continues behind both
-        HIPCHK(c, hipEventRecord(c->bank1.done, c->bank1.st));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->bank1.done, 0));
+    for (int k = 0; k < nx; ++k) {                                     // and the main stream continues behind all of them
+        HIPCHK(c, hipEventRecord(c->xb[k].done, c->xb[k].st));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->xb[k].done, 0));
     }
     c->du = last->u[c->cur];
     c->dflags = last->flags[c->cur];
