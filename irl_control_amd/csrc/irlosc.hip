@@ -102,6 +102,7 @@ struct irlosc_ctx {
     hipEvent_t ev_join = nullptr;
     int fq_overlap = 1;                    // IRLOSC_FQ_OVERLAP=0: one bank, one stream (A/B measurements, tests)
     int r16_overlap = 1;                   // IRLOSC_R16_OVERLAP=0: the same switch for the trains of irlosc_step_resident on dense records
+    int r16_xbanks = 1;                    // IRLOSC_R16_BANKS = 2 .. 4 banks in all for those trains (default 2)
     int32_t* count_cur = nullptr;          // give-up counters of the most recent train (irlosc_giveup_counts)
     int lane_tier = -1;
     lane::RowMap lane_map{};
@@ -302,6 +303,8 @@ static int create_impl(irlosc_ctx* c) {
             c->task_pass = !(e && !strcmp(e, "0"));
             const char* ov = getenv("IRLOSC_R16_OVERLAP");
             c->r16_overlap = !(ov && !strcmp(ov, "0"));
+            const char* nb = getenv("IRLOSC_R16_BANKS");
+            c->r16_xbanks = std::max(1, std::min(nb ? atoi(nb) : 2, 1 + irlosc_ctx::MAX_XBANKS)) - 1;
         }
         HIPCHK(nullptr, hipMemsetAsync(c->dr16_count, 0, R16_TRAIN * sizeof(int32_t), c->stream));
     }
@@ -908,15 +911,18 @@ static int row16_resident(irlosc_ctx* c, int first_slot, int B, int iters, const
     const hipEvent_t outer_b = c->tev_begin, outer_e = c->tev_end;      // irlosc_time_trains brackets a one-train call itself
     // more than one train, untimed: odd trains on the second bank / stream, so that their first waves fill the tail of the train before
     // (a call of exactly one full train already allocates the second bank: a caller's warm-up then pays for it, not its timed loop)
-    const bool two = c->r16_overlap && !evs && iters >= R16_TRAIN && ensure_xbank(c, 0, R16_TRAIN, false) == 0;
-    if (two) {
-        HIPCHK(c, hipEventRecord(c->ev_join, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->xb[0].st, c->ev_join, 0));
+    int nx = 0;
+    if (c->r16_overlap && !evs && iters >= R16_TRAIN) {
+        const int want = std::min(c->r16_xbanks, std::max(1, (iters + R16_TRAIN - 1) / R16_TRAIN - 1));
+        while (nx < want && ensure_xbank(c, nx, R16_TRAIN, false) == 0) ++nx;
     }
+    if (nx) HIPCHK(c, hipEventRecord(c->ev_join, c->stream));
+    for (int k = 0; k < nx; ++k) HIPCHK(c, hipStreamWaitEvent(c->xb[k].st, c->ev_join, 0));
     const irlosc_ctx::Bank* last_bank = nullptr;
     while (done < iters) {
         const int n = std::min((int)R16_TRAIN, iters - done);
-        const irlosc_ctx::Bank* bk = (two && (launch_no & 1)) ? &c->xb[0] : nullptr;
+        const int which = launch_no % (nx + 1);
+        const irlosc_ctx::Bank* bk = which ? &c->xb[which - 1] : nullptr;
         KParams<T> ps[2][R16_TRAIN];        // [1]: steps whose slot qualifies for the tree form, [0]: the others
         int pos[2][R16_TRAIN];              // step of the train each sub-train step is
         int cnt[2] = {0, 0};
@@ -946,9 +952,9 @@ static int row16_resident(irlosc_ctx* c, int first_slot, int B, int iters, const
         done += n;
         ++launch_no;
     }
-    if (two) {
-        HIPCHK(c, hipEventRecord(c->xb[0].done, c->xb[0].st));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->xb[0].done, 0));
+    for (int k = 0; k < nx; ++k) {
+        HIPCHK(c, hipEventRecord(c->xb[k].done, c->xb[k].st));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->xb[k].done, 0));
     }
     c->du = last_bank ? last_bank->u[c->cur] : c->du_set[c->cur];
     c->dflags = last_bank ? last_bank->flags[c->cur] : c->dflags_set[c->cur];
