@@ -564,7 +564,10 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=sorted(MODES))
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
     ap.add_argument("--total-batch", type=int, default=0, help="instances over all GPUs (overrides --batch)")
-    ap.add_argument("--slots", type=int, default=4)
+    ap.add_argument("--slots", type=int, default=16,
+                    help="resident input batches the steps rotate over.  Consecutive trains of 8 steps run on two streams, so two trains "
+                         "are in flight: with 16 slots they never read the same batch (with fewer, the second reader of a batch is served "
+                         "from the Infinity Cache and the rate is inflated: profiles/NOTES.md, round 6)")
     ap.add_argument("--layout", default="k13")
     ap.add_argument("--kernel", type=int, default=-1, help="override: 0 auto, 1 generic, 3 row16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
