@@ -23,7 +23,7 @@ from irl_control_amd.rigid_body import RigidBodyModel              # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=400)
-ap.add_argument("--slots", type=int, default=4)
+ap.add_argument("--slots", type=int, default=16)      # (two trains are in flight: fewer slots let the second reader of a batch hit the Infinity Cache, NOTES round 6)
 ap.add_argument("--oracle", type=int, default=256)
 ap.add_argument("--layouts", default="")
 ap.add_argument("--dtype", default="f64")
