@@ -6,7 +6,8 @@
 A "step" is one pass of the OSC hot path over one resident batch of B synthetic Dual-UR5 instances per GPU
 (default: B = 65 536, n = 25 joints, layout k13 = both arms xyz+abg and the base yaw, gravity and null-space
 terms on: BASELINE.json configs[2]).  Inputs are resident in HBM before the timed region; `--slots` distinct
-batches are rotated so that successive launches do not re-hit the 256 MiB Infinity Cache.
+batches (default 16) are rotated so that neither successive launches nor the two trains of 8 steps that are in flight at a time
+(consecutive trains run on two streams) re-hit a batch in the 256 MiB Infinity Cache.
 
 --workload names where the dense records (M, J, dq, bias, EE poses: 8 536 B per instance in float64) come from:
   physical   (default) SURVEY.md section 8d's "true CRBA on random qpos": uniformly random joint states of the Dual-UR5, their
